@@ -1,0 +1,445 @@
+"""ORACLE -- test infrastructure only, never a product path.
+
+CPU (numpy, fp32) restatement of the Tiny-NewsRec data-parallel training hot
+path: UniLMv2 news encoder -> additive-attention pooling -> user encoder ->
+dot-product scorer -> stage-2 multi-teacher KD loss, with a hand-derived
+backward and the AMSGrad update.  It is the checker the HIP path is compared
+with (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg) and nothing
+under tiny-newsrec_amd/ may import it.
+
+Pinning: the reference ships no tests or golden vectors, so
+this file is pinned against outputs of the reference's own Python, imported
+once in the build container by tests/golden/make_golden.py and committed as
+tests/golden/*.npz (tests/test_oracle_golden.py, fp32, rtol 2e-4 / atol 2e-5).
+
+Citations are file:line under /root/reference/Tiny-NewsRec/ unless prefixed.
+Third-party arithmetic restated from transformers==3.0.2 (README.md:10):
+BertSelfOutput / BertOutput = dense -> dropout(off) -> LayerNorm(x + residual),
+BertIntermediate = dense -> erf-GELU (call sites tnlrv3/modeling.py:279,296-297).
+"""
+import math
+
+import numpy as np
+from scipy.special import erf as _erf
+
+F32 = np.float32
+PFX = "student.news_encoder."
+BERT = PFX + "bert_model.bert."
+
+
+# --------------------------------------------------------------------------- #
+# relative position bias  (tnlrv3/modeling.py:345-373, used at :458-463)
+# --------------------------------------------------------------------------- #
+# Bucket edges of the log branch for num_buckets=32 (16 per direction),
+# max_exact=8, max_distance=128.  The reference evaluates
+# 8 + int(log(n/8)/log(16)*8) in fp32; the integer edges below are what that
+# produces (checked for every n in [0, 511] against the imported reference,
+# tests/golden/relpos.npz) and avoid re-deriving fp32 log rounding at n=16,32,64.
+_LOG_EDGES = (12, 16, 23, 32, 46, 64, 91)
+
+
+def relative_position_bucket(rel, num_buckets=32, max_distance=128):
+    """rel = key_pos - query_pos (int array) -> bucket ids, bidirectional."""
+    assert num_buckets == 32 and max_distance == 128, "edges are tabulated for the tnlrv3 config"
+    rel = np.asarray(rel, dtype=np.int64)
+    half = num_buckets // 2
+    n = np.abs(rel)
+    large = 8 + np.searchsorted(np.asarray(_LOG_EDGES), n, side="right")
+    large = np.minimum(large, half - 1)
+    return (rel > 0).astype(np.int64) * half + np.where(n < 8, n, large)
+
+
+def relpos_bias_table(weight, L):
+    """weight (A, 32) = bert.rel_pos_bias.weight -> (A, L, L) additive bias.
+
+    Equals the per-call (N, A, L, L) tensor of tnlrv3/modeling.py:459-463
+    (one_hot @ Linear, permuted) for position_ids = arange(L)."""
+    pos = np.arange(L)
+    bucket = relative_position_bucket(pos[None, :] - pos[:, None])   # [i, j] = j - i
+    return np.ascontiguousarray(weight[:, bucket]).astype(F32)
+
+
+# --------------------------------------------------------------------------- #
+# primitives
+# --------------------------------------------------------------------------- #
+def layer_norm_fwd(x, g, b, eps):
+    mu = x.mean(-1, keepdims=True, dtype=F32)
+    xc = x - mu
+    var = (xc * xc).mean(-1, keepdims=True, dtype=F32)
+    rstd = (1.0 / np.sqrt(var + F32(eps))).astype(F32)
+    xh = xc * rstd
+    return (xh * g + b).astype(F32), (xh, rstd)
+
+
+def layer_norm_bwd(dy, cache, g):
+    xh, rstd = cache
+    dg = (dy * xh).reshape(-1, xh.shape[-1]).sum(0)
+    db = dy.reshape(-1, xh.shape[-1]).sum(0)
+    dxh = dy * g
+    dx = rstd * (dxh - dxh.mean(-1, keepdims=True) - xh * (dxh * xh).mean(-1, keepdims=True))
+    return dx.astype(F32), dg.astype(F32), db.astype(F32)
+
+
+def gelu(x):
+    return (x * 0.5 * (1.0 + _erf(x / F32(math.sqrt(2.0))))).astype(F32)
+
+
+def gelu_grad(x):
+    cdf = 0.5 * (1.0 + _erf(x / F32(math.sqrt(2.0))))
+    pdf = np.exp(-0.5 * x * x) * F32(1.0 / math.sqrt(2.0 * math.pi))
+    return (cdf + x * pdf).astype(F32)
+
+
+def softmax(x, axis=-1):
+    m = x.max(axis, keepdims=True)
+    e = np.exp(x - m)
+    return (e / e.sum(axis, keepdims=True)).astype(F32)
+
+
+def log_softmax(x, axis=-1):
+    m = x.max(axis, keepdims=True)
+    z = x - m
+    return (z - np.log(np.exp(z).sum(axis, keepdims=True))).astype(F32)
+
+
+def linear(x, w, b=None):
+    y = x @ w.T
+    return y + b if b is not None else y
+
+
+# --------------------------------------------------------------------------- #
+# encoder  (tnlrv3/modeling.py:133-178, 181-342, 421-476)
+# --------------------------------------------------------------------------- #
+def embeddings_fwd(P, ids, eps=1e-12):
+    """BertEmbeddings.forward tnlrv3/modeling.py:153-178: word + pos[arange] + type[0] -> LN."""
+    L = ids.shape[1]
+    e = (P[BERT + "embeddings.word_embeddings.weight"][ids]
+         + P[BERT + "embeddings.position_embeddings.weight"][:L][None]
+         + P[BERT + "embeddings.token_type_embeddings.weight"][0][None, None])
+    y, _ = layer_norm_fwd(e.astype(F32), P[BERT + "embeddings.LayerNorm.weight"],
+                          P[BERT + "embeddings.LayerNorm.bias"], eps)
+    return y
+
+
+def _lp(l):
+    return BERT + "encoder.layer.%d." % l
+
+
+def bert_layer_fwd(P, l, x, mask_add, rel, A, eps=1e-12):
+    """BertLayer.forward tnlrv3/modeling.py:299-308 (+ BertSelfAttention :205-272).
+
+    x (N,L,H); mask_add (N,L) = (1-mask)*-10000 (:454); rel (A,L,L)."""
+    p = _lp(l)
+    N, L, H = x.shape
+    d = H // A
+    q = linear(x, P[p + "attention.self.query.weight"], P[p + "attention.self.query.bias"])
+    k = linear(x, P[p + "attention.self.key.weight"], P[p + "attention.self.key.bias"])
+    v = linear(x, P[p + "attention.self.value.weight"], P[p + "attention.self.value.bias"])
+    qh = q.reshape(N, L, A, d).transpose(0, 2, 1, 3)
+    kh = k.reshape(N, L, A, d).transpose(0, 2, 1, 3)
+    vh = v.reshape(N, L, A, d).transpose(0, 2, 1, 3)
+    s = (qh @ kh.transpose(0, 1, 3, 2)) / F32(math.sqrt(d))
+    s = s + mask_add[:, None, None, :] + rel[None]
+    pr = softmax(s, -1)
+    ctx = (pr @ vh).transpose(0, 2, 1, 3).reshape(N, L, H)
+    ao = linear(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"])
+    h1, ln1 = layer_norm_fwd((ao + x).astype(F32), P[p + "attention.output.LayerNorm.weight"],
+                             P[p + "attention.output.LayerNorm.bias"], eps)
+    u = linear(h1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"]).astype(F32)
+    g = gelu(u)
+    f = linear(g, P[p + "output.dense.weight"], P[p + "output.dense.bias"])
+    y, ln2 = layer_norm_fwd((f + h1).astype(F32), P[p + "output.LayerNorm.weight"],
+                            P[p + "output.LayerNorm.bias"], eps)
+    cache = dict(x=x, qh=qh, kh=kh, vh=vh, pr=pr, ctx=ctx, ln1=ln1, h1=h1, u=u, g=g, ln2=ln2)
+    return y, cache
+
+
+def bert_layer_bwd(P, l, dy, c, A, need_dx=True, need_dw=True):
+    """Backward of bert_layer_fwd.  Returns (dx or None, {param: grad})."""
+    p = _lp(l)
+    G = {}
+    x = c["x"]
+    N, L, H = x.shape
+    d = H // A
+    M = N * L
+    r2 = lambda t: t.reshape(M, -1)
+    dypre, dg2, db2 = layer_norm_bwd(dy, c["ln2"], P[p + "output.LayerNorm.weight"])
+    dgact = dypre @ P[p + "output.dense.weight"]
+    du = (dgact * gelu_grad(c["u"])).astype(F32)
+    dh1 = dypre + du @ P[p + "intermediate.dense.weight"]
+    dh1pre, dg1, db1 = layer_norm_bwd(dh1.astype(F32), c["ln1"], P[p + "attention.output.LayerNorm.weight"])
+    dctx = dh1pre @ P[p + "attention.output.dense.weight"]
+    dch = dctx.reshape(N, L, A, d).transpose(0, 2, 1, 3)
+    pr, qh, kh, vh = c["pr"], c["qh"], c["kh"], c["vh"]
+    dp = dch @ vh.transpose(0, 1, 3, 2)
+    dvh = pr.transpose(0, 1, 3, 2) @ dch
+    ds = pr * (dp - (dp * pr).sum(-1, keepdims=True))
+    sc = F32(1.0 / math.sqrt(d))
+    dqh = (ds @ kh) * sc
+    dkh = (ds.transpose(0, 1, 3, 2) @ qh) * sc
+    back = lambda t: t.transpose(0, 2, 1, 3).reshape(N, L, H)
+    dq, dk, dv = back(dqh), back(dkh), back(dvh)
+    if need_dw:
+        G[p + "output.LayerNorm.weight"], G[p + "output.LayerNorm.bias"] = dg2, db2
+        G[p + "output.dense.weight"] = r2(dypre).T @ r2(c["g"])
+        G[p + "output.dense.bias"] = r2(dypre).sum(0)
+        G[p + "intermediate.dense.weight"] = r2(du).T @ r2(c["h1"])
+        G[p + "intermediate.dense.bias"] = r2(du).sum(0)
+        G[p + "attention.output.LayerNorm.weight"], G[p + "attention.output.LayerNorm.bias"] = dg1, db1
+        G[p + "attention.output.dense.weight"] = r2(dh1pre).T @ r2(c["ctx"])
+        G[p + "attention.output.dense.bias"] = r2(dh1pre).sum(0)
+        for nm, t in (("query", dq), ("key", dk), ("value", dv)):
+            G[p + "attention.self.%s.weight" % nm] = r2(t).T @ r2(x)
+            G[p + "attention.self.%s.bias" % nm] = r2(t).sum(0)
+        G = {k_: v_.astype(F32) for k_, v_ in G.items()}
+    dx = None
+    if need_dx:
+        dx = (dh1pre + dq @ P[p + "attention.self.query.weight"] + dk @ P[p + "attention.self.key.weight"]
+              + dv @ P[p + "attention.self.value.weight"]).astype(F32)
+    return dx, G
+
+
+# --------------------------------------------------------------------------- #
+# AttentionPooling  (model_bert.py:8-34)
+# --------------------------------------------------------------------------- #
+def att_pool_fwd(x, w1, b1, w2, b2, mask=None):
+    """alpha = exp(fc2(tanh(fc1 x))) [*mask] / (sum + 1e-8); out = sum alpha x.  No max-subtraction."""
+    e = np.tanh(linear(x, w1, b1)).astype(F32)                 # (n,k,Q)
+    al = np.exp(linear(e, w2, b2))[..., 0].astype(F32)         # (n,k)
+    if mask is not None:
+        al = al * mask
+    den = al.sum(1, keepdims=True) + F32(1e-8)
+    w = (al / den).astype(F32)
+    out = (w[..., None] * x).sum(1).astype(F32)
+    return out, dict(x=x, e=e, al=al, den=den, w=w, mask=mask)
+
+
+def att_pool_bwd(dout, c, w1, w2):
+    x, e, w, den = c["x"], c["e"], c["w"], c["den"]
+    dx = w[..., None] * dout[:, None, :]
+    dw = (x * dout[:, None, :]).sum(-1)                        # (n,k)
+    dal = (dw - (dw * w).sum(1, keepdims=True)) / den
+    da = dal * c["al"]          # al already carries the mask factor: d/da (exp(a) m) = exp(a) m
+    de = da[..., None] * w2[0][None, None, :]
+    dpre = (de * (1.0 - e * e)).astype(F32)
+    Q = e.shape[-1]
+    g_w2 = (da[..., None] * e).reshape(-1, Q).sum(0)[None, :]
+    g_b2 = da.sum().reshape(1)
+    g_w1 = dpre.reshape(-1, Q).T @ x.reshape(-1, x.shape[-1])
+    g_b1 = dpre.reshape(-1, Q).sum(0)
+    dx = dx + dpre @ w1
+    return dx.astype(F32), g_w1.astype(F32), g_b1.astype(F32), g_w2.astype(F32), g_b2.astype(F32)
+
+
+# --------------------------------------------------------------------------- #
+# NewsEncoder / UserEncoder / ModelBert  (model_bert.py:103-205)
+# --------------------------------------------------------------------------- #
+def split_tokens(x2l):
+    """(N, 2L) -> ids (N,L), mask (N,L)   model_bert.py:124-127."""
+    L = x2l.shape[1] // 2
+    return x2l[:, :L], x2l[:, L:]
+
+
+def encoder_fwd(P, ids, mask, n_layers, A, keep_from=None):
+    """TuringNLRv3Model.forward tnlrv3/modeling.py:421-476 -> last hidden state.
+
+    keep_from: first layer whose cache is kept for backward (None = keep none)."""
+    mask_add = ((1.0 - mask.astype(F32)) * F32(-10000.0)).astype(F32)
+    x = embeddings_fwd(P, ids)
+    rel = relpos_bias_table(P[BERT + "rel_pos_bias.weight"], ids.shape[1])
+    caches = {}
+    hidden = [x]
+    for l in range(n_layers):
+        x, c = bert_layer_fwd(P, l, x, mask_add, rel, A)
+        hidden.append(x)
+        if keep_from is not None and l >= keep_from:
+            caches[l] = c
+    return x, caches, hidden
+
+
+def news_encoder_fwd(P, x2l, n_layers, A, keep_from=None):
+    """NewsEncoder.forward model_bert.py:119-137, pooling == 'att' (no mask), then dense."""
+    ids, mask = split_tokens(x2l)
+    h, caches, hidden = encoder_fwd(P, ids, mask, n_layers, A, keep_from)
+    nv, pc = att_pool_fwd(h, P[PFX + "attn.att_fc1.weight"], P[PFX + "attn.att_fc1.bias"],
+                          P[PFX + "attn.att_fc2.weight"], P[PFX + "attn.att_fc2.bias"])
+    out = linear(nv, P[PFX + "dense.weight"], P[PFX + "dense.bias"]).astype(F32)
+    return out, dict(layers=caches, pool=pc, nv=nv, hidden=hidden)
+
+
+def news_encoder_bwd(P, dout, c, A, trainable_layers):
+    G = {}
+    G[PFX + "dense.weight"] = (dout.T @ c["nv"]).astype(F32)
+    G[PFX + "dense.bias"] = dout.sum(0).astype(F32)
+    dnv = dout @ P[PFX + "dense.weight"]
+    dh, g1, gb1, g2, gb2 = att_pool_bwd(dnv, c["pool"], P[PFX + "attn.att_fc1.weight"],
+                                        P[PFX + "attn.att_fc2.weight"])
+    G[PFX + "attn.att_fc1.weight"], G[PFX + "attn.att_fc1.bias"] = g1, gb1
+    G[PFX + "attn.att_fc2.weight"], G[PFX + "attn.att_fc2.bias"] = g2, gb2
+    if trainable_layers:
+        lo = min(trainable_layers)
+        for l in sorted(c["layers"].keys(), reverse=True):
+            dh, g = bert_layer_bwd(P, l, dh, c["layers"][l], A, need_dx=(l > lo),
+                                   need_dw=(l in trainable_layers))
+            G.update(g)
+    return G
+
+
+def user_encoder_fwd(P, pfx, news_vecs, log_mask, user_log_mask):
+    """UserEncoder.forward model_bert.py:155-176, model != 'NRMS'."""
+    w1, b1 = P[pfx + "attn.att_fc1.weight"], P[pfx + "attn.att_fc1.bias"]
+    w2, b2 = P[pfx + "attn.att_fc2.weight"], P[pfx + "attn.att_fc2.bias"]
+    if user_log_mask:
+        out, c = att_pool_fwd(news_vecs, w1, b1, w2, b2, mask=log_mask)
+        c["blend"] = False
+        return out, c
+    m = log_mask[..., None]
+    hv = (news_vecs * m + P[pfx + "pad_doc"][None] * (1.0 - m)).astype(F32)
+    out, c = att_pool_fwd(hv, w1, b1, w2, b2)
+    c["blend"] = True
+    c["m"] = m
+    return out, c
+
+
+def user_encoder_bwd(P, pfx, dout, c):
+    dhv, g1, gb1, g2, gb2 = att_pool_bwd(dout, c, P[pfx + "attn.att_fc1.weight"], P[pfx + "attn.att_fc2.weight"])
+    G = {pfx + "attn.att_fc1.weight": g1, pfx + "attn.att_fc1.bias": gb1,
+         pfx + "attn.att_fc2.weight": g2, pfx + "attn.att_fc2.bias": gb2}
+    if c["blend"]:
+        m = c["m"]
+        G[pfx + "pad_doc"] = (dhv * (1.0 - m)).sum((0, 1))[None].astype(F32)
+        dnews = (dhv * m).astype(F32)
+    else:
+        G[pfx + "pad_doc"] = np.zeros_like(P[pfx + "pad_doc"])
+        dnews = dhv
+    return dnews, G
+
+
+def cross_entropy_rows(score, label):
+    """F.cross_entropy(reduction='none')."""
+    ls = log_softmax(score, -1)
+    return -ls[np.arange(score.shape[0]), label]
+
+
+# --------------------------------------------------------------------------- #
+# Model.forward: stage-2 multi-teacher KD  (model_bert.py:262-305)
+# --------------------------------------------------------------------------- #
+def model_fwd(P, cfg, history, history_mask, candidate, label, teacher_hist, teacher_cand, keep=True):
+    """Returns dict with total/distill/emb/target losses, student_score and a cache.
+
+    cfg: dict(n_layers, heads, trainable_layers, user_log_mask, temperature, coef).
+    history (B,U,2L) int; history_mask (B,U) f32; candidate (B,C,2L); label (B,);
+    teacher_hist / teacher_cand: lists of (B,U,D) / (B,C,D)."""
+    B, U, W2 = history.shape
+    C = candidate.shape[1]
+    A, nl = cfg["heads"], cfg["n_layers"]
+    tr = sorted(cfg["trainable_layers"])
+    keep_from = (min(tr) if tr else nl) if keep else None
+    # ModelBert.forward :187-205 -- candidates and history share the encoder; rows are independent,
+    # so one pass over the concatenation equals the reference's two calls.
+    allx = np.concatenate([history.reshape(B * U, W2), candidate.reshape(B * C, W2)], 0)
+    vec, nc = news_encoder_fwd(P, allx, nl, A, keep_from)
+    D = vec.shape[1]
+    hist = vec[:B * U].reshape(B, U, D)
+    cand = vec[B * U:].reshape(B, C, D)
+    user, uc = user_encoder_fwd(P, "student.user_encoder.", hist, history_mask, cfg["user_log_mask"])
+    score = np.einsum("bcd,bd->bc", cand, user).astype(F32)
+    S = np.concatenate([hist, cand], 1)                              # :270
+    target = cross_entropy_rows(score, label).mean(dtype=F32)         # :271
+    T = len(teacher_hist)
+    t_scores, t_losses, NE, UE, projs, tus, tups, Tcat = [], [], [], [], [], [], [], []
+    for i in range(T):
+        tn = np.concatenate([teacher_hist[i], teacher_cand[i]], 1).astype(F32)      # :277
+        W, b = P["transform_matrix.%d.weight" % i], P["transform_matrix.%d.bias" % i]
+        pr = linear(tn, W, b).astype(F32)                                           # :278
+        NE.append(((S - pr) ** 2).mean(-1).mean(-1))                                # :279-280
+        tu, _ = user_encoder_fwd(P, "teachers.%d." % i, teacher_hist[i].astype(F32), history_mask,
+                                 cfg["user_log_mask"])                              # :282
+        tup = linear(tu, W, b).astype(F32)                                          # :283
+        UE.append(((user - tup) ** 2).mean(-1))                                     # :284
+        ts = np.einsum("bcd,bd->bc", teacher_cand[i].astype(F32), tu).astype(F32)   # :286-287
+        t_scores.append(ts)
+        t_losses.append(cross_entropy_rows(ts, label))                              # :288
+        projs.append(pr); tus.append(tu); tups.append(tup); Tcat.append(tn)
+    tw = softmax(-np.stack(t_losses, -1), -1)                                       # :292-293
+    ts_mix = np.einsum("bct,bt->bc", np.stack(t_scores, -1), tw).astype(F32)        # :295-297
+    tau = F32(cfg["temperature"])
+    pT = softmax(ts_mix / tau, -1)
+    distill = (-(pT * log_softmax(score / tau, -1)).sum(-1)).mean(dtype=F32)        # :208-219
+    NEs, UEs = np.stack(NE, -1), np.stack(UE, -1)
+    emb = (NEs * tw).sum(-1).mean(dtype=F32) + (UEs * tw).sum(-1).mean(dtype=F32)   # :300-303
+    total = distill + F32(cfg["coef"]) * target + emb                               # :305
+    out = dict(total_loss=F32(total), distill_loss=F32(distill), emb_loss=F32(emb), target_loss=F32(target),
+               student_score=score, hist=hist, cand=cand, user=user, teacher_weights=tw,
+               teacher_scores=ts_mix)
+    out["cache"] = dict(nc=nc, uc=uc, S=S, projs=projs, tus=tus, tups=tups, Tcat=Tcat, pT=pT, tw=tw,
+                        label=label, B=B, U=U, C=C, D=D)
+    return out
+
+
+def model_bwd(P, cfg, out):
+    """d total_loss / d every trainable parameter -> {state_dict key: grad}.
+
+    Trainable set = run.py:101-112: heads + transform_matrix + encoder.layer[i], i in trainable_layers.
+    teacher_weights do not depend on any trainable parameter (teachers frozen, :101-102)."""
+    c = out["cache"]
+    B, U, C, D = c["B"], c["U"], c["C"], c["D"]
+    tw, S, label = c["tw"], c["S"], c["label"]
+    score, user, cand = out["student_score"], out["user"], out["cand"]
+    tau, coef = F32(cfg["temperature"]), F32(cfg["coef"])
+    G = {}
+    onehot = np.zeros_like(score)
+    onehot[np.arange(B), label] = 1.0
+    dscore = ((softmax(score / tau, -1) - c["pT"]) / tau + coef * (softmax(score, -1) - onehot)) / F32(B)
+    dS = np.zeros_like(S)
+    duser = np.zeros_like(user)
+    npos = S.shape[1]
+    for i in range(len(c["projs"])):
+        w_i = tw[:, i]
+        dne = (2.0 / (npos * D * B)) * w_i[:, None, None] * (S - c["projs"][i])      # d emb / d S
+        dS += dne
+        due = (2.0 / (D * B)) * w_i[:, None] * (user - c["tups"][i])
+        duser += due
+        gW = (-dne).reshape(-1, D).T @ c["Tcat"][i].reshape(-1, D) + (-due).T @ c["tus"][i]
+        gb = (-dne).reshape(-1, D).sum(0) + (-due).sum(0)
+        G["transform_matrix.%d.weight" % i] = gW.astype(F32)
+        G["transform_matrix.%d.bias" % i] = gb.astype(F32)
+    dcand = dS[:, U:].copy() + dscore[:, :, None] * user[:, None, :]
+    duser = duser + np.einsum("bc,bcd->bd", dscore, cand)
+    dhist_u, gu = user_encoder_bwd(P, "student.user_encoder.", duser.astype(F32), c["uc"])
+    G.update(gu)
+    dhist = dS[:, :U] + dhist_u
+    dvec = np.concatenate([dhist.reshape(B * U, D), dcand.reshape(B * C, D)], 0).astype(F32)
+    G.update(news_encoder_bwd(P, dvec, c["nc"], cfg["heads"], set(cfg["trainable_layers"])))
+    return G
+
+
+# --------------------------------------------------------------------------- #
+# PLM-NR ModelBert.forward  (PLM-NR/model_bert.py:187-207): same encoders + CE
+# --------------------------------------------------------------------------- #
+def plmnr_fwd(P, cfg, history, history_mask, candidate, label):
+    z = model_fwd(P, dict(cfg, temperature=1.0, coef=1.0), history, history_mask, candidate, label, [], [],
+                  keep=False)
+    return z["target_loss"], z["student_score"]
+
+
+# --------------------------------------------------------------------------- #
+# optimiser  (run.py:134: torch.optim.Adam(lr, amsgrad=True), torch defaults)
+# --------------------------------------------------------------------------- #
+def amsgrad_step(p, g, m, v, vmax, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """One torch.optim.Adam(amsgrad=True) update, in place; `step` is the 1-based count after increment."""
+    m *= F32(b1); m += F32(1 - b1) * g
+    v *= F32(b2); v += F32(1 - b2) * g * g
+    np.maximum(vmax, v, out=vmax)
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    denom = np.sqrt(vmax) / F32(math.sqrt(bc2)) + F32(eps)
+    p -= F32(lr / bc1) * (m / denom)
+    return p
+
+
+# --------------------------------------------------------------------------- #
+# utils.acc  (utils.py:79-83)
+# --------------------------------------------------------------------------- #
+def acc(y_true, y_hat):
+    return F32((np.argmax(y_hat, -1) == y_true).sum() / y_true.shape[0])

@@ -1,0 +1,237 @@
+"""Generate tests/golden/*.npz by executing the REFERENCE's own Python in this container.
+
+Run once here (the reference is read-only at /root/reference and does not
+exist on the GPU box):  python tests/golden/make_golden.py
+Only inputs/outputs (data) are written; weights come from the shared
+deterministic generator tiny-newsrec_amd/hashinit.py, so no weight files and no
+reference text are committed.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
+import hashinit  # noqa: E402
+import ref_shim  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+TINY_CFG = dict(ref_shim.BASE_CFG, hidden_size=64, num_attention_heads=4, intermediate_size=256,
+                vocab_size=128, max_position_embeddings=64, num_hidden_layers=2)
+TINY_ARGS = dict(news_dim=32, news_query_vector_dim=16, user_query_vector_dim=16, user_log_length=6,
+                 npratio=2, num_words_title=10)
+
+
+def fill(model, seed):
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            v.copy_(torch.from_numpy(hashinit.init_tensor(seed, k, tuple(v.shape))))
+    return {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def make_inputs(seed, B, U, C, L, vocab, T, D, n_news=40):
+    """MIND-shaped synthetic batch: (history (B,U,2L), mask (B,U), candidate (B,C,2L), label, teacher lists)."""
+    lens = hashinit.hash_randint(seed, "len", (n_news + 1,), 3, L + 1)
+    toks = hashinit.hash_randint(seed, "tok", (n_news + 1, L), 1, vocab)
+    comb = np.zeros((n_news + 1, 2 * L), np.int64)
+    for i in range(1, n_news + 1):
+        comb[i, :lens[i]] = toks[i, :lens[i]]
+        comb[i, L:L + lens[i]] = 1
+    hl = hashinit.hash_randint(seed, "hl", (B,), 0, U + 1)
+    hl[0] = U
+    if B > 1:
+        hl[1] = 0                                  # empty history: every slot is the pad news
+    hidx = hashinit.hash_randint(seed, "hidx", (B, U), 1, n_news + 1)
+    mask = np.zeros((B, U), np.float32)
+    for b in range(B):
+        hidx[b, :U - hl[b]] = 0
+        mask[b, U - hl[b]:] = 1
+    if B > 2 and hl[2] > 0:
+        hidx[2, U - 1] = 0                         # unknown id inside the history: index 0 but mask 1
+    cidx = hashinit.hash_randint(seed, "cidx", (B, C), 1, n_news + 1)
+    label = hashinit.hash_randint(seed, "label", (B,), 0, C)
+    temb = [hashinit.hash_normal(seed, "temb%d" % i, (n_news + 1, D), std=0.3) for i in range(T)]
+    return (comb[hidx], mask, comb[cidx], label, [t[hidx] for t in temb], [t[cidx] for t in temb])
+
+
+def grad_samples(seed, name, g, k=64):
+    flat = g.reshape(-1)
+    idx = hashinit.hash_randint(seed, "gs." + name, (min(k, flat.size),), 0, flat.size)
+    return idx, flat[idx]
+
+
+def run_model(R, cfg_json, args_over, trainable, seed, B, T, full_grads):
+    a = ref_shim.make_args(config_name=ref_shim.write_config(cfg_json), num_teachers=T, batch_size=B,
+                           **args_over)
+    model = R.model_bert.Model(a)
+    P = fill(model, seed)
+    # run.py:101-112 freeze policy
+    for p in model.teachers.parameters():
+        p.requires_grad = False
+    for p in model.student.news_encoder.bert_model.parameters():
+        p.requires_grad = False
+    for i, layer in enumerate(model.student.news_encoder.bert_model.bert.encoder.layer):
+        if i in trainable:
+            for p in layer.parameters():
+                p.requires_grad = True
+    L = a.num_words_title
+    inp = make_inputs(seed, B, a.user_log_length, a.npratio + 1, L, cfg_json["vocab_size"], T, a.news_dim)
+    hist, mask, cand, label, th, tc = inp
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    out = model(tt(hist), tt(mask), tt(cand), tt(label), [tt(x) for x in th], [tt(x) for x in tc])
+    total, distill, emb, target, score = out
+    total.backward()
+    # intermediate tensors for op-by-op pinning
+    with torch.no_grad():
+        s2, hv, cv, uv = model.student(tt(hist), tt(mask), tt(cand))
+        ids = tt(np.concatenate([hist.reshape(-1, 2 * L), cand.reshape(-1, 2 * L)], 0))
+        bo = model.student.news_encoder.bert_model(ids[:, :L], ids[:, L:])
+        hidden = [h.numpy() for h in bo[3]]
+    rec = dict(total=total.item(), distill=distill.item(), emb=emb.item(), target=target.item(),
+               score=score.detach().numpy(), hist_vec=hv.numpy(), cand_vec=cv.numpy(), user_vec=uv.numpy(),
+               in_hist=hist, in_mask=mask, in_cand=cand, in_label=label)
+    for i in range(T):
+        rec["in_th%d" % i] = th[i]
+        rec["in_tc%d" % i] = tc[i]
+    nkeep = 6 if full_grads else 3
+    for li, h in enumerate(hidden):
+        rec["hidden%d" % li] = h if full_grads else h[:nkeep]
+    gnames = []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.numpy()
+        gnames.append(name)
+        rec["gnorm." + name] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        if full_grads:
+            rec["grad." + name] = g
+        else:
+            idx, val = grad_samples(seed, name, g)
+            rec["gidx." + name] = idx
+            rec["gval." + name] = val
+    rec["grad_names"] = np.array(gnames)
+    rec["meta"] = np.array([seed, B, T, a.user_log_length, a.npratio + 1, L, a.news_dim,
+                            cfg_json["num_attention_heads"], a.num_student_layers])
+    rec["trainable"] = np.array(sorted(trainable))
+    rec["flags"] = np.array([float(a.user_log_mask), a.temperature, a.coef])
+    return rec, P
+
+
+def golden_relpos(R):
+    rel = torch.arange(-511, 512)
+    b = R.modeling.relative_position_bucket(rel, num_buckets=32, max_distance=128).numpy()
+    out = dict(rel=rel.numpy(), bucket=b)
+    w = hashinit.init_tensor(3, "student.news_encoder.bert_model.bert.rel_pos_bias.weight", (12, 32))
+    lin = torch.nn.Linear(32, 12, bias=False)
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(w))
+    for L in (24, 30, 128):
+        pos = torch.arange(L)[None]
+        rp = pos.unsqueeze(-2) - pos.unsqueeze(-1)
+        bk = R.modeling.relative_position_bucket(rp, num_buckets=32, max_distance=128)
+        t = lin(torch.nn.functional.one_hot(bk, 32).float()).permute(0, 3, 1, 2)[0]
+        out["table%d" % L] = t.detach().numpy()
+    out["weight"] = w
+    np.savez_compressed(os.path.join(HERE, "relpos.npz"), **out)
+
+
+def golden_datapath(R):
+    d = os.path.join(HERE, "data")
+    os.makedirs(d, exist_ok=True)
+    rnd = random.Random(5)
+    words = "stocks rally as markets open lower after fed signals rate cut storm hits coast team wins final".split()
+    with open(os.path.join(d, "news.tsv"), "w") as f:
+        for i in range(1, 41):
+            n = rnd.randint(0, 3) if i % 13 == 0 else rnd.randint(3, 45 if i % 7 == 0 else 12)
+            title = " ".join(rnd.choice(words) for _ in range(n))
+            f.write("N%d\tcat%d\tsub%d\t%s\tabs\turl\t[]\t[]\n" % (i, i % 4, i % 9, title))
+    lines = []
+    for j in range(12):
+        nh = [0, 3, 60, 50, 49, 1][j % 6] if j < 6 else rnd.randint(0, 70)
+        hist = ["N%d" % rnd.randint(1, 40) for _ in range(nh)]
+        if j % 4 == 2 and hist:
+            hist[rnd.randrange(len(hist))] = "N999"      # unknown id -> index 0, mask stays 1
+        pos = "N%d" % rnd.randint(1, 40)
+        negs = ["N%d" % rnd.randint(1, 44) for _ in range(4)]
+        lines.append("%d\tU%d\t11/15/2019 8:55:22 AM\t%s\t%s\t%s" % (j, j, " ".join(hist), pos, " ".join(negs)))
+    for r in range(3):
+        with open(os.path.join(d, "behaviors_np4_%d.tsv" % r), "w") as f:
+            f.write("\n".join(lines[r::3]) + "\n")
+    a = ref_shim.make_args(num_teachers=2, news_dim=8)
+    news, news_index, cat, sub = R.preprocess.read_news_bert(os.path.join(d, "news.tsv"), a, "train")
+    nt, nm, _, _ = R.preprocess.get_doc_input_bert(news, news_index, cat, sub, a)
+    comb = np.concatenate([nt, nm], -1)
+    temb = [hashinit.hash_normal(11, "dp_temb%d" % i, (comb.shape[0], 8)) for i in range(2)]
+    dl = R.dataloader.DataLoaderTrain(data_dir=d, filename_pat="behaviors_np4_*.tsv", args=a, world_size=1,
+                                      worker_rank=0, cuda_device_idx=0, news_index=news_index,
+                                      news_combined=comb, teacher_embs=temb, word_dict=None,
+                                      enable_prefetch=False, enable_shuffle=False, enable_gpu=False)
+    random.seed(7)
+    out = dl._process([l.encode() for l in lines])
+    random.seed(7)
+    labels = [random.randint(0, a.npratio) for _ in lines]
+    rec = dict(news_ids=np.array(list(news_index.keys())), news_index=np.array(list(news_index.values())),
+               news_combined=comb, log_ids=out[0].numpy(), log_mask=out[1].numpy(), input_ids=out[2].numpy(),
+               targets=out[3].numpy(), labels_seed7=np.array(labels), lines=np.array(lines),
+               th0=out[4][0].numpy(), tc1=out[5][1].numpy())
+    assert (out[3].numpy() == np.array(labels)).all()
+    # sharding rule (streaming.py:40-58); TF reader itself cannot run here
+    for w in (1, 2, 3):
+        for r in range(w):
+            for sh in (False, True):
+                fs = R.streaming.get_worker_files(d, r, w, "behaviors_np4_*.tsv", sh, 3)
+                rec["files_w%d_r%d_s%d" % (w, r, int(sh))] = np.array([os.path.basename(x) for x in fs])
+    np.savez_compressed(os.path.join(HERE, "datapath.npz"), **rec)
+
+
+def golden_amsgrad():
+    rng = np.random.RandomState(0)
+    p0 = [rng.randn(5, 7).astype(np.float32), rng.randn(11).astype(np.float32)]
+    ps = [torch.nn.Parameter(torch.from_numpy(x.copy())) for x in p0]
+    opt = torch.optim.Adam(ps, lr=1e-2, amsgrad=True)
+    rec = dict(p0_0=p0[0], p0_1=p0[1])
+    for s in range(3):
+        gs = [(rng.randn(*x.shape) * (3.0 if s == 0 else 0.3)).astype(np.float32) for x in p0]
+        for p, g in zip(ps, gs):
+            p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        for i in range(2):
+            rec["g%d_%d" % (s, i)] = gs[i]
+            rec["p%d_%d" % (s + 1, i)] = ps[i].detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "amsgrad.npz"), **rec)
+
+
+def main():
+    R = ref_shim.load_reference()
+    golden_relpos(R)
+    golden_datapath(R)
+    golden_amsgrad()
+    # tiny model: every intermediate + full gradients (pins the oracle's forward AND backward op by op)
+    k = 0
+    for T, ulm, tau in ((1, False, 1.0), (4, False, 2.0), (4, True, 1.0), (2, True, 2.0)):
+        for trainable in ((0, 1), (1,)):
+            rec, _ = run_model(R, TINY_CFG, dict(TINY_ARGS, num_student_layers=2, user_log_mask=ulm,
+                                                 temperature=tau, coef=0.2), trainable, seed=100 + k, B=4, T=T,
+                               full_grads=True)
+            np.savez_compressed(os.path.join(HERE, "tiny_model_%d.npz" % k), **rec)
+            k += 1
+    # full size (H=768, demo.sh shapes U=50 C=5 L=30 D=256): outputs + gradient norms / samples only
+    full = [(2, (0, 1), 2, False, 1.0, 21), (4, (2, 3), 4, False, 1.0, 22), (4, (2, 3), 1, True, 2.0, 23)]
+    for k, (nl, trainable, T, ulm, tau, seed) in enumerate(full):
+        cfg = dict(ref_shim.BASE_CFG, num_hidden_layers=nl)
+        rec, _ = run_model(R, cfg, dict(num_student_layers=nl, user_log_mask=ulm, temperature=tau, coef=0.2),
+                           trainable, seed=seed, B=2, T=T, full_grads=False)
+        np.savez_compressed(os.path.join(HERE, "full_model_%d.npz" % k), **rec)
+        print("full", k, rec["total"], rec["distill"], rec["emb"], rec["target"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""Shared by CPU and GPU tests: rebuild a golden case's weights / inputs / config from its npz."""
+import os
+
+import numpy as np
+
+import hashinit
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TINY = dict(H=64, A=4, I=256, vocab=128, max_pos=64, Q=16)
+FULL = dict(H=768, A=12, I=3072, vocab=30522, max_pos=512, Q=200)
+
+
+def state_shapes(dims, n_layers, D, T):
+    """state_dict key schema of model_bert.Model."""
+    H, I, Q = dims["H"], dims["I"], dims["Q"]
+    s = {}
+    for i in range(T):
+        s["teachers.%d.pad_doc" % i] = (1, D)
+        s["teachers.%d.attn.att_fc1.weight" % i] = (Q, D)
+        s["teachers.%d.attn.att_fc1.bias" % i] = (Q,)
+        s["teachers.%d.attn.att_fc2.weight" % i] = (1, Q)
+        s["teachers.%d.attn.att_fc2.bias" % i] = (1,)
+    b = "student.news_encoder.bert_model.bert."
+    s[b + "embeddings.word_embeddings.weight"] = (dims["vocab"], H)
+    s[b + "embeddings.position_embeddings.weight"] = (dims["max_pos"], H)
+    s[b + "embeddings.token_type_embeddings.weight"] = (2, H)
+    s[b + "embeddings.LayerNorm.weight"] = (H,)
+    s[b + "embeddings.LayerNorm.bias"] = (H,)
+    for l in range(n_layers):
+        p = b + "encoder.layer.%d." % l
+        for nm in ("query", "key", "value"):
+            s[p + "attention.self.%s.weight" % nm] = (H, H)
+            s[p + "attention.self.%s.bias" % nm] = (H,)
+        s[p + "attention.output.dense.weight"] = (H, H)
+        s[p + "attention.output.dense.bias"] = (H,)
+        s[p + "attention.output.LayerNorm.weight"] = (H,)
+        s[p + "attention.output.LayerNorm.bias"] = (H,)
+        s[p + "intermediate.dense.weight"] = (I, H)
+        s[p + "intermediate.dense.bias"] = (I,)
+        s[p + "output.dense.weight"] = (H, I)
+        s[p + "output.dense.bias"] = (H,)
+        s[p + "output.LayerNorm.weight"] = (H,)
+        s[p + "output.LayerNorm.bias"] = (H,)
+    s[b + "pooler.dense.weight"] = (H, H)
+    s[b + "pooler.dense.bias"] = (H,)
+    s[b + "rel_pos_bias.weight"] = (dims["A"], 32)
+    s["student.news_encoder.bert_model.classifier.weight"] = (2, H)
+    s["student.news_encoder.bert_model.classifier.bias"] = (2,)
+    s["student.news_encoder.attn.att_fc1.weight"] = (Q, H)
+    s["student.news_encoder.attn.att_fc1.bias"] = (Q,)
+    s["student.news_encoder.attn.att_fc2.weight"] = (1, Q)
+    s["student.news_encoder.attn.att_fc2.bias"] = (1,)
+    s["student.news_encoder.dense.weight"] = (D, H)
+    s["student.news_encoder.dense.bias"] = (D,)
+    s["student.user_encoder.pad_doc"] = (1, D)
+    s["student.user_encoder.attn.att_fc1.weight"] = (Q, D)
+    s["student.user_encoder.attn.att_fc1.bias"] = (Q,)
+    s["student.user_encoder.attn.att_fc2.weight"] = (1, Q)
+    s["student.user_encoder.attn.att_fc2.bias"] = (1,)
+    for i in range(T):
+        s["transform_matrix.%d.weight" % i] = (D, D)
+        s["transform_matrix.%d.bias" % i] = (D,)
+    return s
+
+
+def load_case(name):
+    """-> (z npz, P weights, cfg, inputs tuple)."""
+    z = np.load(os.path.join(GOLDEN, name))
+    seed, B, T, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
+    dims = TINY if name.startswith("tiny") else FULL
+    P = hashinit.init_state_dict(seed, state_shapes(dims, nl, D, T))
+    ulm, tau, coef = [float(x) for x in z["flags"]]
+    cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]],
+               user_log_mask=bool(ulm), temperature=tau, coef=coef)
+    inp = (z["in_hist"], z["in_mask"], z["in_cand"], z["in_label"],
+           [z["in_th%d" % i] for i in range(T)], [z["in_tc%d" % i] for i in range(T)])
+    return z, P, cfg, inp

@@ -1,0 +1,118 @@
+"""CPU: the numpy oracle against vectors captured from the imported reference (tests/golden/make_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_case
+from oracle import data_oracle as DO
+from oracle import newsrec_oracle as O
+
+RTOL, ATOL = 2e-4, 2e-5      # fp32 restatement vs fp32 reference (different summation orders)
+
+
+def test_relpos_bucket_every_distance():
+    z = np.load(os.path.join(GOLDEN, "relpos.npz"))
+    assert (O.relative_position_bucket(z["rel"]) == z["bucket"]).all()
+    for L in (24, 30, 128):
+        assert np.array_equal(O.relpos_bias_table(z["weight"], L), z["table%d" % L])
+
+
+def test_amsgrad_three_steps():
+    z = np.load(os.path.join(GOLDEN, "amsgrad.npz"))
+    for i in range(2):
+        p = z["p0_%d" % i].copy()
+        m, v, vm = np.zeros_like(p), np.zeros_like(p), np.zeros_like(p)
+        for s in range(3):
+            O.amsgrad_step(p, z["g%d_%d" % (s, i)], m, v, vm, s + 1, lr=1e-2)
+            np.testing.assert_allclose(p, z["p%d_%d" % (s + 1, i)], rtol=1e-5, atol=1e-6)
+
+
+def test_datapath_bit_exact():
+    z = np.load(os.path.join(GOLDEN, "datapath.npz"))
+    news_index = {str(k): int(v) for k, v in zip(z["news_ids"], z["news_index"])}
+    comb = z["news_combined"]
+    assert comb.dtype == np.int32 and (comb[0] == 0).all()
+    lines = [str(x) for x in z["lines"]]
+    h, m, c, y = DO.decode_batch(lines, news_index, 50, 4, labels=z["labels_seed7"])
+    temb = None
+    import hashinit
+    temb = [hashinit.hash_normal(11, "dp_temb%d" % i, (comb.shape[0], 8)) for i in range(2)]
+    out = DO.gather_batch(h, m, c, y, comb, temb)
+    assert np.array_equal(out[0], z["log_ids"]) and out[0].dtype == np.int64
+    assert np.array_equal(out[1], z["log_mask"])
+    assert np.array_equal(out[2], z["input_ids"])
+    assert np.array_equal(out[3], z["targets"])
+    assert np.array_equal(out[4][0], z["th0"]) and np.array_equal(out[5][1], z["tc1"])
+    # label draw reproduces random.randint order of dataloader.py:136
+    import random
+    random.seed(7)
+    _, _, c2, y2 = DO.decode_batch(lines, news_index, 50, 4)
+    assert np.array_equal(y2, z["targets"]) and np.array_equal(c2, c)
+    d = os.path.join(GOLDEN, "data")
+    for w in (1, 2, 3):
+        for r in range(w):
+            for sh in (0, 1):
+                got = [os.path.basename(x) for x in DO.get_worker_files(d, r, w, "behaviors_np4_*.tsv", bool(sh), 3)]
+                assert got == [str(x) for x in z["files_w%d_r%d_s%d" % (w, r, sh)]]
+
+
+def test_datapath_known_answers():
+    # captured from the reference
+    ni = {"N10": 1, "N11": 2, "N12": 3, "N13": 4}
+    line = "1\tU1\tt\tN10 N11 N999\tN12\tN13 N10 N11 N13"
+    h, m, c, y = DO.decode_batch([line], ni, 50, 4, labels=[3])
+    assert h[0].tolist() == [0] * 47 + [1, 2, 0] and m[0].tolist() == [0] * 47 + [1, 1, 1]
+    assert c[0].tolist() == [4, 1, 2, 3, 4]
+    x, mk = DO.pad_to_fix_len(list(range(60)), 50)
+    assert x == list(range(10, 60)) and mk == [1] * 50
+    assert DO.pad_to_fix_len([], 3) == ([0, 0, 0], [0, 0, 0])
+
+
+def _check_model(name, full_grads):
+    z, P, cfg, inp = load_case(name)
+    out = O.model_fwd(P, cfg, *inp)
+    for k, g in (("total_loss", "total"), ("distill_loss", "distill"), ("emb_loss", "emb"), ("target_loss", "target")):
+        np.testing.assert_allclose(out[k], z[g], rtol=RTOL, atol=ATOL, err_msg=k)
+    np.testing.assert_allclose(out["student_score"], z["score"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out["hist"], z["hist_vec"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out["cand"], z["cand_vec"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out["user"], z["user_vec"], rtol=RTOL, atol=ATOL)
+    hid = out["cache"]["nc"]["hidden"]
+    for li, h in enumerate(hid):
+        ref = z["hidden%d" % li]
+        np.testing.assert_allclose(h[:ref.shape[0]], ref, rtol=1e-3, atol=2e-4, err_msg="hidden%d" % li)
+    G = O.model_bwd(P, cfg, out)
+    names = [str(n) for n in z["grad_names"]]
+    assert set(G.keys()) >= set(names), set(names) - set(G.keys())
+    for n in names:
+        g = G[n]
+        ref_norm = float(z["gnorm." + n])
+        if n.endswith("self.key.bias") or n.endswith("att_fc2.bias"):
+            # mathematical no-ops (a per-query / per-row constant that softmax / the pooling normaliser
+            # removes): the reference's gradient is rounding noise
+            assert np.sqrt((g.astype(np.float64) ** 2).sum()) < 1e-4 and ref_norm < 1e-4
+            continue
+        np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), ref_norm, rtol=1e-3, atol=1e-9,
+                                   err_msg=n)      # atol: fp32 cancellation noise floor of O(1) operands
+        scale = ref_norm / np.sqrt(g.size) + 1e-12
+        scale = max(scale, float(np.abs(z["grad." + n] if full_grads else z["gval." + n]).max()))
+        if full_grads:
+            np.testing.assert_allclose(g, z["grad." + n], rtol=2e-3, atol=2e-3 * scale + 1e-10, err_msg=n)
+        else:
+            np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], z["gval." + n], rtol=2e-3,
+                                       atol=2e-3 * scale + 1e-10, err_msg=n)
+    # parameters outside the trainable set receive no gradient in the reference either
+    lo = "encoder.layer.%d." % min(cfg["trainable_layers"])
+    assert not any("embeddings" in k or "rel_pos" in k for k in G)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "tiny_model_*.npz"))))
+def test_tiny_model_forward_backward(name):
+    _check_model(name, True)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "full_model_*.npz"))))
+def test_full_model_forward_backward(name):
+    _check_model(name, False)
