@@ -1,0 +1,181 @@
+/* libtnr_hip.so -- C ABI of the MI355X (gfx950) hot path of Tiny-NewsRec training.
+ *
+ * The reference has no FFI layer: the path sits behind Python modules and every
+ * device op is a stock ATen kernel.  Each entry point
+ * below replaces the ATen ops the cited reference lines launch.  Citations are
+ * /root/reference/Tiny-NewsRec/<file>:<line>.
+ *
+ * Conventions:
+ *   - plain pointers + explicit sizes; every tensor pointer is DEVICE memory
+ *     owned by the caller (PyTorch allocator), including workspaces;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, a negative TNR_E* code otherwise; tnr_last_error()
+ *     returns a thread-local message; no C++ exception crosses the boundary;
+ *   - the library never calls hipSetDevice: the caller's current device rules;
+ *   - 16-bit activations are bf16 (TNR_BF16); "ld" arguments are row strides in
+ *     ELEMENTS; row-major everywhere.
+ */
+#ifndef TNR_HIP_H
+#define TNR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNR_OK 0
+#define TNR_EINVAL (-1)      /* bad shape / alignment / null pointer */
+#define TNR_EUNSUPPORTED (-2)
+#define TNR_ELAUNCH (-3)     /* hipGetLastError() after a launch */
+
+#define TNR_BF16 0
+#define TNR_F16 1            /* reserved */
+#define TNR_F32 2
+
+/* gemm epilogue flags */
+#define TNR_EPI_BIAS 1       /* + bias[n] (fp32) */
+#define TNR_EPI_GELU 2       /* erf-GELU (transformers BertIntermediate, call site tnlrv3/modeling.py:305) */
+#define TNR_EPI_TANH 4       /* model_bert.py:25 */
+#define TNR_EPI_RES 8        /* + res[m,n] (bf16) : BertSelfOutput/BertOutput residual, tnlrv3/modeling.py:287,306 */
+#define TNR_EPI_MULDGELU 16  /* * gelu'(aux[m,n])  : backward of TNR_EPI_GELU */
+#define TNR_EPI_OUTF32 32    /* C is fp32 instead of bf16 */
+#define TNR_EPI_AUXOUT 64    /* also store the pre-activation (acc+bias) to aux (bf16) */
+
+int tnr_version(void);
+const char* tnr_last_error(void);
+
+/* ---- encoder --------------------------------------------------------------------------------- */
+
+/* relative_position_bucket + one_hot + Linear(32->A) hoisted to one (A,32,32) fp32 table
+ * (tnlrv3/modeling.py:345-373, 458-463).  weight (A,32) fp32.  Entries with i>=L or j>=L are 0. */
+int tnr_relpos_table(const float* weight, int A, int L, float* table, void* stream);
+
+/* BertEmbeddings.forward (tnlrv3/modeling.py:153-178) + extended mask (:446-454), reading the padded
+ * token batch directly: tok = (N, 2L) int64 rows [ids | mask] (model_bert.py:124-127).
+ * out (N*L, H) bf16 ; mask_add (N,32) fp32 = (1-mask)*-10000, and -inf-like (-1e30) for j>=L. */
+int tnr_embed_ln_fwd(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
+                     const float* type0, const float* gamma, const float* beta, float eps,
+                     void* out, float* mask_add, void* stream);
+
+/* C[M,N] = epilogue(A[M,K] . B[N,K]^T).  bf16 operands, fp32 MFMA accumulation.
+ * Forward Linear (tnlrv3/modeling.py:236-248, transformers BertSelfOutput/BertIntermediate/BertOutput),
+ * and its dgrad when B is the transposed weight copy.  N % 128 == 0, K % 64 == 0, any M >= 1. */
+int tnr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                void* aux, int64_t ldaux, int flags, void* stream);
+
+/* dW[N,K] (fp32) = dY[M,N]^T . X[M,K] : weight gradient of a Linear.  Reduction over M is split into
+ * `splits` slabs in `ws` (fp32, splits*N*K elements) and summed in fixed order (deterministic).
+ * Rows [M, Mpad) of dY and X must be zero, Mpad = roundup(M, 64) ; N % 128 == 0, K % 128 == 0.
+ * accumulate != 0 adds into dW. */
+int tnr_gemm_tn_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
+                      int64_t M, int64_t N, int64_t K, float* ws, int splits, int accumulate, void* stream);
+int64_t tnr_gemm_tn_ws_elems(int64_t N, int64_t K, int splits);
+
+/* LayerNorm over the last dim (H % 256 == 0), eps inside the sqrt (torch.nn.LayerNorm).
+ * fwd: y = LN(x) ; stats (M,2) fp32 = (mean, rstd) kept for backward. */
+int tnr_ln_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* stats,
+               int64_t M, int H, void* stream);
+/* bwd: dx = LN'(dy) ; dgamma/dbeta partial sums go to part (nblk,2,H) fp32 then are reduced into
+ * dgamma, dbeta (may be null when the layer is frozen). */
+int tnr_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+               float* dgamma, float* dbeta, float* part, int64_t M, int H, void* stream);
+int64_t tnr_ln_bwd_part_elems(int64_t M, int H);
+
+/* BertSelfAttention.multi_head_attention (tnlrv3/modeling.py:205-231) for L <= 32, head size 64:
+ * softmax(Q K^T / 8 + mask_add + rel) V, heads merged.  qkv (N*L, 3*A*64) bf16 = [q | k | v];
+ * rel (A,32,32) fp32 from tnr_relpos_table ; ctx (N*L, A*64) bf16. */
+int tnr_attn_l32_fwd(const void* qkv, const float* mask_add, const float* rel, void* ctx,
+                     int64_t n_seq, int L, int A, void* stream);
+/* backward: recomputes the probabilities ; dqkv (N*L, 3*A*64) bf16. */
+int tnr_attn_l32_bwd(const void* qkv, const float* mask_add, const float* rel, const void* dctx,
+                     void* dqkv, int64_t n_seq, int L, int A, void* stream);
+
+/* column sums (bias gradients): out[n] (+)= sum_m X[m,n] ; X bf16 or fp32 (dtype) ; part (nblk,N) fp32 */
+int tnr_colsum(const void* X, int64_t ldx, int dtype, int64_t M, int64_t N, float* out, float* part,
+               int accumulate, void* stream);
+int64_t tnr_colsum_part_elems(int64_t M, int64_t N);
+
+/* ---- heads ----------------------------------------------------------------------------------- */
+
+/* AttentionPooling over the L tokens of each title, no mask (model_bert.py:15-34 called at :133).
+ * e (N*L, lde) fp32 = tanh(fc1 y) from tnr_gemm_nt (padded columns must be 0) ; w2 (Q) ; b2 scalar.
+ * out: nv (N,H) fp32, alpha (N,32) fp32 normalised weights, den (N) fp32 = sum exp + 1e-8. */
+int tnr_attpool_fwd(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
+                    float* nv, float* alpha, float* den, int64_t n_seq, int L, int H, void* stream);
+/* backward: dnv (N,H) fp32 -> dy_direct (N*L,H) bf16 = alpha*dnv ; dpre (N*L, lddpre) bf16 =
+ * d tanh-preactivation (padded cols 0) ; dw2_part (N,Q) ; db2_part (N). */
+int tnr_attpool_bwd(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
+                    const float* alpha, const float* den, void* dy_direct, void* dpre, int64_t lddpre,
+                    float* dw2_part, float* db2_part, int64_t n_seq, int L, int H, void* stream);
+
+/* small fp32 GEMM on the f32 MFMA (exact fp32):  for z in [0,batch):
+ *   C_z[m,n] = alpha * sum_k A_z(m,k) B_z(n,k) + bias_z[n] + beta * C_z[m,n]
+ * A_z(m,k) = A[z*sA + row(m)*a_rs + k*a_cs], row(m) = a_idx ? a_idx[m] : m ; likewise B (no gather). */
+int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA, const int32_t* a_idx,
+              const float* B, int64_t b_rs, int64_t b_cs, int64_t sB,
+              float* C, int64_t ldc, int64_t sC, const float* bias, int64_t sBias,
+              int64_t M, int64_t N, int64_t K, int batch, float alpha, float beta, void* stream);
+
+/* out[z, out_row0 + r, :] = tbl[z, idx[r], :]  (dataloader.py:140-144 teacher-embedding gather, done on
+ * device from resident tables instead of on the host) */
+int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, int64_t n_idx, int D, int n_model,
+                    float* out, int64_t out_rows, int64_t out_row0, void* stream);
+
+/* UserEncoder.forward (model_bert.py:155-176, model != NRMS) + scorer bmm (:204 / :286-287) for
+ * `n_model` encoders at once (student and/or frozen teachers), one workgroup per (impression, model).
+ * vec: (n_model, R, D) fp32 row tables ; hidx (B,U) / cidx (B,C) int32 row ids ; mask (B,U) fp32.
+ * params are stacked per model: pad (n_model,D), w1 (n_model,Q,D), b1 (n_model,Q), w2 (n_model,Q), b2 (n_model).
+ * out: user (n_model,B,D), score (n_model,B,C), saved e (n_model,B,U,Q), alpha (n_model,B,U), den (n_model,B). */
+int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const int32_t* cidx, const float* mask,
+                       const float* pad, const float* w1, const float* b1, const float* w2, const float* b2,
+                       int user_log_mask, float* user, float* score, float* e, float* alpha, float* den,
+                       int n_model, int B, int U, int C, int D, int Q, void* stream);
+/* backward of the student's user encoder: duser (B,D) -> dvec rows hidx (+=), and per-impression
+ * partial parameter gradients part (B, Q*D + Q + Q + 1 + D) laid out [w1|b1|w2|b2|pad]. */
+int tnr_user_bwd(const float* vec, const int32_t* hidx, const float* mask, const float* pad, const float* w1,
+                 const float* w2, int user_log_mask, const float* duser, const float* e, const float* alpha,
+                 const float* den, float* dvec, float* part, int B, int U, int D, int Q, void* stream);
+
+int64_t tnr_user_bwd_part_stride(int D, int Q);
+/* backward of the scorer bmm (model_bert.py:204): dvec[cidx[b,c]] += dscore[b,c]*user[b] ;
+ * duser[b] += sum_c dscore[b,c]*vec[cidx[b,c]] */
+int tnr_score_bwd(const float* vec, const int32_t* cidx, const float* user, const float* dscore, float* dvec,
+                  float* duser, int B, int C, int D, void* stream);
+
+/* Model.forward losses (model_bert.py:271, 288-305; kd_ce_loss :208-219): teacher CE -> weights
+ * softmax(-CE) -> mixed soft labels -> distill + coef*target, and d/d student_score.
+ * s_score (B,C) ; t_score (T,B,C) ; out: tw (B,T), dscore (B,C), losses[0..1] = distill, target. */
+int tnr_kd_score_loss(const float* s_score, const float* t_score, const int64_t* label, float temperature,
+                      float coef, float* tw, float* dscore, float* losses, int B, int C, int T, void* stream);
+/* embedding KD (model_bert.py:277-284, 300-303) on stacked rows: per impression U+C news rows then 1
+ * user row.  S (B,U+C+1,D) student rows ; P (T,B,U+C+1,D) projected teacher rows ; tw (B,T).
+ * out: emb loss (scalar, += into losses[2]) ; dS (B,U+C+1,D) ; dP (T,B,U+C+1,D). */
+int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* loss, float* dS, float* dP,
+                      float* part, int B, int rows, int D, int T, void* stream);
+
+/* out[i] (+)= sum_r part[r*stride + i] , i < n  (fixed order) */
+int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
+                    void* stream);
+
+/* ---- optimiser ------------------------------------------------------------------------------- */
+
+/* torch.optim.Adam(amsgrad=True) (run.py:134) on a flat fp32 parameter buffer ; step = 1-based count.
+ * grad_scale multiplies g first (1/world for the data-parallel average, run.py:145-149). */
+int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step,
+                     float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* refresh bf16 weight copies after an update: desc = n_desc * 8 int64 on DEVICE:
+ * {src fp32 ptr, rows, cols, dst ptr (or 0), dst ld, dstT ptr (or 0), dstT ld, unused}
+ * dst[r*ld + c] = bf16(src[r,c]) ; dstT[c*ldT + r] = bf16(src[r,c]). */
+int tnr_refresh_shadows(const int64_t* desc, int n_desc, int64_t total_tiles, const int64_t* tile_start,
+                        void* stream);
+
+/* elementwise helpers */
+int tnr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int tnr_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

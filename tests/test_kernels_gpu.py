@@ -1,0 +1,453 @@
+"""GPU parity, kernel by kernel: every C-ABI entry point against the numpy oracle on seeded inputs.
+
+Integer-valued operands give bit-exact checks of the MFMA fragment / LDS-swizzle / transposed-read
+layouts (asymmetric data, so a row<->col swap cannot hide); random operands check the fused epilogues.
+Tolerances: bf16 outputs carry one rounding of 2^-9 relative -> rtol 1e-2 on bf16 tensors; fp32 heads
+1e-4."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import tnr_hip as T                      # noqa: E402
+from oracle import newsrec_oracle as O   # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(x, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t.to(dt) if dt is not None else t
+
+
+def bf(x):
+    """numpy fp32 -> bf16-rounded fp32 (round to nearest even), what the kernels see."""
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def test_library_loads():
+    assert T.query("tnr_version") == 1
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (130, 256, 128), (257, 128, 192), (1000, 768, 768)])
+def test_gemm_nt_integer_exact(M, N, K):
+    rs = np.random.RandomState(M + N + K)
+    A = rs.randint(-3, 4, (M, K)).astype(np.float32)
+    B = rs.randint(-3, 4, (N, K)).astype(np.float32)
+    B[:, 0] += np.arange(N) % 5          # asymmetric
+    A[:, 1] += np.arange(M) % 3
+    a, b = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    c = torch.full((M, N), 7.0, device=DEV, dtype=torch.float32)
+    T.call("tnr_gemm_nt", a, K, b, K, c, N, M, N, K, None, None, 0, None, 0, T.EPI_OUTF32)
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy(), A @ B.T)
+
+
+def test_gemm_nt_epilogues():
+    M, N, K = 333, 384, 256
+    A, B = bf(rnd((M, K), 1)), bf(rnd((N, K), 2, 0.1))
+    bias, res, aux = rnd((N,), 3), bf(rnd((M, N), 4)), bf(rnd((M, N), 5))
+    a, b = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    ref = A @ B.T
+    cases = {
+        T.EPI_BIAS: ref + bias,
+        T.EPI_BIAS | T.EPI_GELU: O.gelu(ref + bias),
+        T.EPI_BIAS | T.EPI_TANH | T.EPI_OUTF32: np.tanh(ref + bias),
+        T.EPI_BIAS | T.EPI_RES: ref + bias + res,
+        T.EPI_RES: ref + res,
+        T.EPI_MULDGELU: ref * O.gelu_grad(aux),
+        0: ref,
+    }
+    for flags, want in cases.items():
+        out_f32 = bool(flags & T.EPI_OUTF32)
+        c = torch.zeros((M, N), device=DEV, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        T.call("tnr_gemm_nt", a, K, b, K, c, N, M, N, K, dev(bias), dev(res, torch.bfloat16), N,
+               dev(aux, torch.bfloat16), N, flags)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(c.float().cpu().numpy(), want, rtol=1e-2 if not out_f32 else 1e-4,
+                                   atol=2e-2 if not out_f32 else 1e-4, err_msg="flags=%d" % flags)
+    # AUXOUT: pre-activation stored beside the GELU output
+    c = torch.zeros((M, N), device=DEV, dtype=torch.bfloat16)
+    u = torch.zeros((M, N), device=DEV, dtype=torch.bfloat16)
+    T.call("tnr_gemm_nt", a, K, b, K, c, N, M, N, K, dev(bias), None, 0, u, N, T.EPI_BIAS | T.EPI_GELU | T.EPI_AUXOUT)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(u.float().cpu().numpy(), ref + bias, rtol=1e-2, atol=2e-2)
+    np.testing.assert_allclose(c.float().cpu().numpy(), O.gelu(ref + bias), rtol=1e-2, atol=2e-2)
+
+
+def test_gemm_nt_does_not_touch_rows_past_M():
+    M, N, K = 100, 128, 64
+    a = dev(rnd((M, K), 1), torch.bfloat16)
+    b = dev(rnd((N, K), 2), torch.bfloat16)
+    c = torch.full((128, N), 5.0, device=DEV, dtype=torch.bfloat16)
+    T.call("tnr_gemm_nt", a, K, b, K, c, N, M, N, K, None, None, 0, None, 0, 0)
+    torch.cuda.synchronize()
+    assert (c[M:].float() == 5.0).all()
+
+
+def test_gemm_nt_rejects_bad_shapes():
+    a = torch.zeros((8, 64), device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(T.TnrError):
+        T.call("tnr_gemm_nt", a, 64, a, 64, a, 100, 8, 100, 64, None, None, 0, None, 0, 0)
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (200, 256, 128, 2), (1000, 128, 384, 4), (3300, 768, 256, 16)])
+def test_gemm_tn_wgrad_integer_exact(M, N, K, splits):
+    rs = np.random.RandomState(M + N)
+    Mp = (M + 63) // 64 * 64
+    dY = np.zeros((Mp, N), np.float32)
+    X = np.zeros((Mp, K), np.float32)
+    dY[:M] = rs.randint(-2, 3, (M, N))
+    X[:M] = rs.randint(-2, 3, (M, K))
+    X[:M, 0] += np.arange(M) % 3
+    dY[:M, 1] += np.arange(M) % 2
+    ws = torch.zeros(T.query("tnr_gemm_tn_ws_elems", N, K, splits), device=DEV)
+    dW = torch.full((N, K), 3.0, device=DEV)
+    T.call("tnr_gemm_tn_wgrad", dev(dY, torch.bfloat16), N, dev(X, torch.bfloat16), K, dW, K, M, N, K, ws, splits, 0)
+    torch.cuda.synchronize()
+    want = dY.T @ X
+    assert np.array_equal(dW.cpu().numpy(), want)
+    T.call("tnr_gemm_tn_wgrad", dev(dY, torch.bfloat16), N, dev(X, torch.bfloat16), K, dW, K, M, N, K, ws, splits, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(dW.cpu().numpy(), 2 * want)
+
+
+# ------------------------------------------------------------------------------------------------ rows
+def test_relpos_table_exact():
+    w = rnd((12, 32), 3)
+    for L in (24, 30, 32):
+        t = torch.zeros((12, 32, 32), device=DEV)
+        T.call("tnr_relpos_table", dev(w), 12, L, t)
+        torch.cuda.synchronize()
+        got = t.cpu().numpy()
+        assert np.array_equal(got[:, :L, :L], O.relpos_bias_table(w, L))
+        assert (got[:, L:, :] == 0).all() and (got[:, :, L:] == 0).all()
+
+
+def test_embed_ln_and_mask():
+    N, L, H, V = 37, 30, 768, 500
+    rs = np.random.RandomState(0)
+    ids = rs.randint(0, V, (N, L))
+    mask = (rs.rand(N, L) > 0.3).astype(np.int64)
+    mask[3] = 0
+    tok = np.concatenate([ids, mask], 1).astype(np.int64)
+    P = {O.BERT + "embeddings.word_embeddings.weight": rnd((V, H), 1),
+         O.BERT + "embeddings.position_embeddings.weight": rnd((512, H), 2),
+         O.BERT + "embeddings.token_type_embeddings.weight": rnd((2, H), 3),
+         O.BERT + "embeddings.LayerNorm.weight": 1 + rnd((H,), 4, 0.1),
+         O.BERT + "embeddings.LayerNorm.bias": rnd((H,), 5, 0.1)}
+    out = torch.zeros((N * L, H), device=DEV, dtype=torch.bfloat16)
+    madd = torch.zeros((N, 32), device=DEV)
+    T.call("tnr_embed_ln_fwd", dev(tok), N, L, H, *[dev(P[k]) for k in P][:2],
+           dev(P[O.BERT + "embeddings.token_type_embeddings.weight"][0]),
+           dev(P[O.BERT + "embeddings.LayerNorm.weight"]), dev(P[O.BERT + "embeddings.LayerNorm.bias"]), 1e-12, out, madd)
+    torch.cuda.synchronize()
+    want = O.embeddings_fwd(P, ids).reshape(N * L, H)
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=1e-2, atol=1e-2)
+    m = madd.cpu().numpy()
+    assert np.array_equal(m[:, :L], (1.0 - mask.astype(np.float32)) * -10000.0)
+    assert (m[:, L:] <= -1e29).all()
+
+
+@pytest.mark.parametrize("M", [5, 257])
+def test_layernorm_fwd_bwd(M):
+    H = 768
+    x, dy = bf(rnd((M, H), 1, 2.0)), bf(rnd((M, H), 2))
+    g, b = 1 + rnd((H,), 3, 0.1), rnd((H,), 4, 0.1)
+    y = torch.zeros((M, H), device=DEV, dtype=torch.bfloat16)
+    st = torch.zeros((M, 2), device=DEV)
+    T.call("tnr_ln_fwd", dev(x, torch.bfloat16), dev(g), dev(b), 1e-12, y, st, M, H)
+    yref, cache = O.layer_norm_fwd(x, g, b, 1e-12)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.float().cpu().numpy(), yref, rtol=1e-2, atol=1e-2)
+    dx = torch.zeros((M, H), device=DEV, dtype=torch.bfloat16)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    part = torch.zeros(T.query("tnr_ln_bwd_part_elems", M, H), device=DEV)
+    T.call("tnr_ln_bwd", dev(dy, torch.bfloat16), dev(x, torch.bfloat16), st, dev(g), dx, dg, db, part, M, H)
+    torch.cuda.synchronize()
+    dxr, dgr, dbr = O.layer_norm_bwd(dy, cache, g)
+    np.testing.assert_allclose(dx.float().cpu().numpy(), dxr, rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(dg.cpu().numpy(), dgr, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), dbr, rtol=1e-3, atol=1e-3)
+
+
+def test_colsum_and_reduce():
+    M, N = 1234, 768
+    x = bf(rnd((M, N), 1))
+    out = torch.ones(N, device=DEV)
+    part = torch.zeros(T.query("tnr_colsum_part_elems", M, N), device=DEV)
+    T.call("tnr_colsum", dev(x, torch.bfloat16), N, T.BF16, M, N, out, part, 1)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), 1 + x.sum(0), rtol=1e-4, atol=1e-3)
+    xf = rnd((77, 256), 2)
+    out2 = torch.zeros(256, device=DEV)
+    part2 = torch.zeros(T.query("tnr_colsum_part_elems", 77, 256), device=DEV)
+    T.call("tnr_colsum", dev(xf), 256, T.F32, 77, 256, out2, part2, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out2.cpu().numpy(), xf.sum(0), rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, mask, rel, N, L, A):
+    d = 64
+    q, k, v = [qkv[:, i * A * d:(i + 1) * A * d].reshape(N, L, A, d).transpose(0, 2, 1, 3) for i in range(3)]
+    s = q @ k.transpose(0, 1, 3, 2) / 8.0 + ((1.0 - mask) * -10000.0)[:, None, None, :] + rel[None]
+    p = O.softmax(s.astype(np.float32), -1)
+    return q, k, v, p, (p @ v).transpose(0, 2, 1, 3).reshape(N * L, A * d)
+
+
+@pytest.mark.parametrize("N,L,A", [(3, 30, 12), (2, 32, 2), (5, 7, 3), (1, 1, 1)])
+def test_attention_fwd_bwd(N, L, A):
+    d = 64
+    rs = np.random.RandomState(N * 100 + L)
+    qkv = bf(rnd((N * L, 3 * A * d), 1, 1.0))
+    mask = (rs.rand(N, L) > 0.3).astype(np.float32)
+    mask[0, :] = 1
+    if N > 1:
+        mask[1, :] = 0          # all-pad title: finite uniform softmax over -10000
+    w = rnd((A, 32), 2, 0.5)
+    rel = O.relpos_bias_table(w, L)
+    tok = np.concatenate([np.ones((N, L)), mask], 1).astype(np.int64)
+    # mask_add / rel table through their own kernels (the real call chain)
+    H = 768
+    madd = torch.zeros((N, 32), device=DEV)
+    scratch = torch.zeros((N * L, H), device=DEV, dtype=torch.bfloat16)
+    z = torch.zeros((600, H), device=DEV)
+    T.call("tnr_embed_ln_fwd", dev(tok), N, L, H, z, z, z[0], z[0], z[0], 1e-12, scratch, madd)
+    relt = torch.zeros((A, 32, 32), device=DEV)
+    T.call("tnr_relpos_table", dev(w), A, L, relt)
+    ctx = torch.zeros((N * L, A * d), device=DEV, dtype=torch.bfloat16)
+    T.call("tnr_attn_l32_fwd", dev(qkv, torch.bfloat16), madd, relt, ctx, N, L, A)
+    torch.cuda.synchronize()
+    q, k, v, p, want = _attn_ref(qkv, mask, rel, N, L, A)
+    np.testing.assert_allclose(ctx.float().cpu().numpy(), want, rtol=2e-2, atol=2e-2)
+    # backward
+    dctx = bf(rnd((N * L, A * d), 3))
+    dqkv = torch.zeros((N * L, 3 * A * d), device=DEV, dtype=torch.bfloat16)
+    T.call("tnr_attn_l32_bwd", dev(qkv, torch.bfloat16), madd, relt, dev(dctx, torch.bfloat16), dqkv, N, L, A)
+    torch.cuda.synchronize()
+    dch = dctx.reshape(N, L, A, d).transpose(0, 2, 1, 3)
+    dp = dch @ v.transpose(0, 1, 3, 2)
+    dv = p.transpose(0, 1, 3, 2) @ dch
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True))
+    dq = ds @ k / 8.0
+    dk = ds.transpose(0, 1, 3, 2) @ q / 8.0
+    back = lambda t: t.transpose(0, 2, 1, 3).reshape(N * L, A * d)
+    want_d = np.concatenate([back(dq), back(dk), back(dv)], 1)
+    got = dqkv.float().cpu().numpy()
+    scale = np.abs(want_d).max()
+    np.testing.assert_allclose(got, want_d, rtol=3e-2, atol=3e-2 * scale)
+
+
+# ------------------------------------------------------------------------------------------------ heads
+def test_attpool_fwd_bwd():
+    N, L, H, Q, QP = 9, 30, 768, 200, 256
+    y = bf(rnd((N, L, H), 1))
+    w1, b1 = rnd((Q, H), 2, 0.05), rnd((Q,), 3, 0.05)
+    w2, b2 = rnd((1, Q), 4, 0.2), rnd((1,), 5, 0.05)
+    out, c = O.att_pool_fwd(y, w1, b1, w2, b2)
+    e = np.zeros((N * L, QP), np.float32)
+    e[:, :Q] = c["e"].reshape(N * L, Q)
+    nv = torch.zeros((N, H), device=DEV)
+    alpha = torch.zeros((N, 32), device=DEV)
+    den = torch.zeros(N, device=DEV)
+    yd, ed = dev(y.reshape(N * L, H), torch.bfloat16), dev(e)
+    T.call("tnr_attpool_fwd", yd, ed, QP, dev(w2[0]), dev(b2), Q, nv, alpha, den, N, L, H)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nv.cpu().numpy(), out, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(alpha.cpu().numpy()[:, :L], c["w"], rtol=1e-4, atol=1e-6)
+    dnv = rnd((N, H), 6)
+    dx, g1, gb1, g2, gb2 = O.att_pool_bwd(dnv, c, w1, w2)
+    dyd = torch.zeros((N * L, H), device=DEV, dtype=torch.bfloat16)
+    dpre = torch.ones((N * L, QP), device=DEV, dtype=torch.bfloat16)
+    dw2p, db2p = torch.zeros((N, Q), device=DEV), torch.zeros(N, device=DEV)
+    T.call("tnr_attpool_bwd", yd, ed, QP, dev(w2[0]), Q, dev(dnv), alpha, den, dyd, dpre, QP, dw2p, db2p, N, L, H)
+    torch.cuda.synchronize()
+    direct = c["w"][..., None] * dnv[:, None, :]
+    np.testing.assert_allclose(dyd.float().cpu().numpy(), direct.reshape(N * L, H), rtol=1e-2, atol=1e-3)
+    da = c["w"] * ((y * dnv[:, None, :]).sum(-1) - ((y * dnv[:, None, :]).sum(-1) * c["w"]).sum(1, keepdims=True))
+    dpre_ref = da[..., None] * w2[0][None, None, :] * (1 - c["e"] ** 2)
+    got = dpre.float().cpu().numpy()
+    np.testing.assert_allclose(got[:, :Q], dpre_ref.reshape(N * L, Q), rtol=1e-2, atol=1e-2 * np.abs(dpre_ref).max())
+    assert (got[:, Q:] == 0).all()
+    np.testing.assert_allclose(dw2p.sum(0).cpu().numpy(), g2[0], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(db2p.sum().cpu().numpy(), gb2[0], rtol=1e-3, atol=1e-4)
+
+
+def test_sgemm_variants():
+    M, N, K, Z = 150, 200, 77, 3
+    A, B, bias, C0 = rnd((Z, M, K), 1), rnd((Z, N, K), 2), rnd((Z, N), 3), rnd((Z, M, N), 4)
+    c = dev(C0.copy())
+    T.call("tnr_sgemm", dev(A), K, 1, M * K, None, dev(B), K, 1, N * K, c, N, M * N, dev(bias), N, M, N, K, Z, 0.5, 2.0)
+    torch.cuda.synchronize()
+    want = 0.5 * np.einsum("zmk,znk->zmn", A, B) + bias[:, None, :] + 2.0 * C0
+    np.testing.assert_allclose(c.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    # transposed A (dW = dY^T X) : A(m,k) = dY[k, m]
+    dY, X = rnd((300, 64), 5), rnd((300, 48), 6)
+    c2 = torch.zeros((64, 48), device=DEV)
+    T.call("tnr_sgemm", dev(dY), 1, 64, 0, None, dev(X), 1, 48, 0, c2, 48, 0, None, 0, 64, 48, 300, 1, 1.0, 0.0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(c2.cpu().numpy(), dY.T @ X, rtol=1e-4, atol=1e-4)
+
+
+def _user_params(nm, D, Q, seed):
+    return dict(pad=rnd((nm, D), seed), w1=rnd((nm, Q, D), seed + 1, 0.05), b1=rnd((nm, Q), seed + 2, 0.05),
+                w2=rnd((nm, Q), seed + 3, 0.2), b2=rnd((nm,), seed + 4, 0.05))
+
+
+@pytest.mark.parametrize("ulm", [0, 1])
+def test_user_score_fwd_bwd(ulm):
+    nm, B, U, C, D, Q, R = 3, 5, 50, 5, 256, 200, 400
+    rs = np.random.RandomState(ulm)
+    vec = rnd((nm, R, D), 1, 0.3)
+    hidx = rs.permutation(R)[:B * U].reshape(B, U).astype(np.int32)
+    cidx = rs.randint(0, R, (B, C)).astype(np.int32)
+    mask = (rs.rand(B, U) > 0.4).astype(np.float32)
+    mask[0] = 1
+    mask[1] = 0
+    pr = _user_params(nm, D, Q, 10)
+    user, score = torch.zeros((nm, B, D), device=DEV), torch.zeros((nm, B, C), device=DEV)
+    e, alpha, den = torch.zeros((nm, B, U, Q), device=DEV), torch.zeros((nm, B, U), device=DEV), torch.zeros((nm, B), device=DEV)
+    dv = {k: dev(v) for k, v in pr.items()}
+    T.call("tnr_user_score_fwd", dev(vec), R, dev(hidx), dev(cidx), dev(mask), dv["pad"], dv["w1"], dv["b1"], dv["w2"],
+           dv["b2"], ulm, user, score, e, alpha, den, nm, B, U, C, D, Q)
+    torch.cuda.synchronize()
+    caches = []
+    for z in range(nm):
+        P = {"p.pad_doc": pr["pad"][z][None], "p.attn.att_fc1.weight": pr["w1"][z], "p.attn.att_fc1.bias": pr["b1"][z],
+             "p.attn.att_fc2.weight": pr["w2"][z][None], "p.attn.att_fc2.bias": pr["b2"][z:z + 1]}
+        uref, c = O.user_encoder_fwd(P, "p.", vec[z][hidx], mask, bool(ulm))
+        caches.append((P, c))
+        np.testing.assert_allclose(user[z].cpu().numpy(), uref, rtol=1e-4, atol=1e-5)
+        sref = np.einsum("bcd,bd->bc", vec[z][cidx], uref)
+        np.testing.assert_allclose(score[z].cpu().numpy(), sref, rtol=1e-4, atol=1e-4)
+    # backward of model 0
+    duser = rnd((B, D), 7)
+    P, c = caches[0]
+    dnews, G = O.user_encoder_bwd(P, "p.", duser, c)
+    dvec = torch.zeros((R, D), device=DEV)
+    ps = T.query("tnr_user_bwd_part_stride", D, Q)
+    part = torch.zeros((B, ps), device=DEV)
+    T.call("tnr_user_bwd", dev(vec[0]), dev(hidx), dev(mask), dv["pad"], dv["w1"], dv["w2"], ulm, dev(duser), e, alpha, den,
+           dvec, part, B, U, D, Q)
+    torch.cuda.synchronize()
+    want = np.zeros((R, D), np.float32)
+    np.add.at(want, hidx.reshape(-1), dnews.reshape(-1, D))
+    np.testing.assert_allclose(dvec.cpu().numpy(), want, rtol=1e-3, atol=1e-5)
+    p = part.sum(0).cpu().numpy()
+    o = 0
+    for key, n in (("p.attn.att_fc1.weight", Q * D), ("p.attn.att_fc1.bias", Q), ("p.attn.att_fc2.weight", Q),
+                   ("p.attn.att_fc2.bias", 1), ("p.pad_doc", D)):
+        ref = G[key].reshape(-1)
+        if key.endswith("att_fc2.bias"):      # mathematical no-op (cancels in the normaliser): rounding noise only
+            assert abs(p[o]) < 1e-3 and abs(ref[0]) < 1e-3
+        else:
+            np.testing.assert_allclose(p[o:o + n], ref, rtol=2e-3, atol=2e-3 * (np.abs(ref).max() + 1e-6), err_msg=key)
+        o += n
+
+
+@pytest.mark.parametrize("T_,tau", [(4, 1.0), (1, 2.0), (0, 1.0)])
+def test_kd_score_loss(T_, tau):
+    B, C, coef = 37, 5, 0.2
+    rs = np.random.RandomState(T_)
+    s, ts = rnd((B, C), 1), rnd((max(T_, 1), B, C), 2)
+    y = rs.randint(0, C, B)
+    tw = torch.zeros((B, max(T_, 1)), device=DEV)
+    dscore, losses = torch.zeros((B, C), device=DEV), torch.zeros(4, device=DEV)
+    T.call("tnr_kd_score_loss", dev(s), dev(ts) if T_ else None, dev(y), tau, coef, tw if T_ else None, dscore, losses,
+           B, C, T_)
+    torch.cuda.synchronize()
+    target = O.cross_entropy_rows(s, y).mean()
+    oh = np.eye(C, dtype=np.float32)[y]
+    g = coef * (O.softmax(s) - oh)
+    if T_:
+        tl = np.stack([O.cross_entropy_rows(ts[i], y) for i in range(T_)], -1)
+        w = O.softmax(-tl, -1)
+        mix = np.einsum("tbc,bt->bc", ts[:T_], w)
+        pT = O.softmax(mix / tau)
+        distill = (-(pT * O.log_softmax(s / tau)).sum(-1)).mean()
+        g = g + (O.softmax(s / tau) - pT) / tau
+        np.testing.assert_allclose(tw.cpu().numpy(), w, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(losses[0].item(), distill, rtol=1e-4)
+    np.testing.assert_allclose(losses[1].item(), target, rtol=1e-4)
+    np.testing.assert_allclose(dscore.cpu().numpy(), g / B, rtol=1e-3, atol=1e-6)
+
+
+def test_kd_embed_loss():
+    B, rows, D, T_ = 4, 56, 256, 3
+    S, P, tw = rnd((B, rows, D), 1, 0.3), rnd((T_, B, rows, D), 2, 0.3), O.softmax(rnd((B, T_), 3))
+    dS, dP = torch.zeros((B, rows, D), device=DEV), torch.zeros((T_, B, rows, D), device=DEV)
+    loss, part = torch.zeros(1, device=DEV), torch.zeros(B * rows, device=DEV)
+    T.call("tnr_kd_embed_loss", dev(S), dev(P), dev(tw), loss, dS, dP, part, B, rows, D, T_)
+    torch.cuda.synchronize()
+    ne = np.stack([((S[:, :-1] - P[i][:, :-1]) ** 2).mean(-1).mean(-1) for i in range(T_)], -1)
+    ue = np.stack([((S[:, -1] - P[i][:, -1]) ** 2).mean(-1) for i in range(T_)], -1)
+    want = (ne * tw).sum(-1).mean() + (ue * tw).sum(-1).mean()
+    np.testing.assert_allclose(loss.item(), want, rtol=1e-4)
+    scale = np.full((rows,), 1.0 / (rows - 1), np.float32)
+    scale[-1] = 1.0
+    dSr = np.zeros_like(S)
+    for i in range(T_):
+        ci = tw[:, i][:, None, None] * scale[None, :, None] * 2.0 / (D * B)
+        dSr += ci * (S - P[i])
+        np.testing.assert_allclose(dP[i].cpu().numpy(), -ci * (S - P[i]), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(dS.cpu().numpy(), dSr, rtol=1e-4, atol=1e-8)
+
+
+def test_score_bwd_and_gather():
+    B, C, D, R = 6, 5, 256, 100
+    rs = np.random.RandomState(0)
+    vec, user, dscore = rnd((R, D), 1), rnd((B, D), 2), rnd((B, C), 3)
+    cidx = rs.permutation(R)[:B * C].reshape(B, C).astype(np.int32)
+    dvec, duser = torch.zeros((R, D), device=DEV), torch.ones((B, D), device=DEV)
+    T.call("tnr_score_bwd", dev(vec), dev(cidx), dev(user), dev(dscore), dvec, duser, B, C, D)
+    torch.cuda.synchronize()
+    want = np.zeros((R, D), np.float32)
+    want[cidx.reshape(-1)] = (dscore[:, :, None] * user[:, None, :]).reshape(-1, D)
+    np.testing.assert_allclose(dvec.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(duser.cpu().numpy(), 1 + np.einsum("bc,bcd->bd", dscore, vec[cidx]), rtol=1e-4, atol=1e-5)
+    tbl = rnd((2, R, D), 4)
+    idx = rs.randint(0, R, 33).astype(np.int32)
+    out = torch.zeros((2, 40, D), device=DEV)
+    T.call("tnr_gather_rows", dev(tbl), R, dev(idx), 33, D, 2, out, 40, 5)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy()[:, 5:38], tbl[:, idx])
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def test_amsgrad_matches_reference_golden(golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "amsgrad.npz"))
+    for i in range(2):
+        p = dev(z["p0_%d" % i].reshape(-1).copy())
+        m, v, vm = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+        for s in range(3):
+            T.call("tnr_amsgrad_step", p, dev(z["g%d_%d" % (s, i)].reshape(-1)), m, v, vm, p.numel(), s + 1, 1e-2, 0.9,
+                   0.999, 1e-8, 1.0)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(p.cpu().numpy(), z["p%d_%d" % (s + 1, i)].reshape(-1), rtol=1e-5, atol=1e-6)
+
+
+def test_refresh_shadows():
+    w1, w2 = rnd((200, 768), 1), rnd((768, 96), 2)
+    s1, s2 = dev(w1), dev(w2)
+    d1 = torch.zeros((256, 768), device=DEV, dtype=torch.bfloat16)
+    d1t = torch.zeros((768, 256), device=DEV, dtype=torch.bfloat16)
+    d2t = torch.zeros((96, 800), device=DEV, dtype=torch.bfloat16)
+    tiles = [((200 + 31) // 32) * (768 // 32), (768 // 32) * 3]
+    desc = torch.tensor([[s1.data_ptr(), 200, 768, d1.data_ptr(), 768, d1t.data_ptr(), 256, 0],
+                         [s2.data_ptr(), 768, 96, 0, 0, d2t.data_ptr(), 800, 0]], dtype=torch.int64, device=DEV)
+    start = torch.tensor([0, tiles[0], tiles[0] + tiles[1]], dtype=torch.int64, device=DEV)
+    T.call("tnr_refresh_shadows", desc, 2, sum(tiles), start)
+    torch.cuda.synchronize()
+    assert np.array_equal(d1.float().cpu().numpy()[:200], bf(w1)) and (d1[200:] == 0).all()
+    assert np.array_equal(d1t.float().cpu().numpy()[:, :200], bf(w1).T)
+    assert np.array_equal(d2t.float().cpu().numpy()[:, :768], bf(w2).T)

@@ -1,0 +1,310 @@
+// Fused self-attention for short titles (L <= 32, head size 64): one wavefront per (sequence, head).
+//
+// Reference ops replaced (tnlrv3/modeling.py:205-231): transpose_for_scores x3, matmul(Q,K^T), /sqrt(64),
+// + attention_mask, + rel_pos, softmax, matmul(P,V), permute+contiguous.
+//
+// MFMA v_mfma_f32_32x32x16_bf16 on a single 32x32 score tile.  Scores are produced TRANSPOSED
+// (S^T = K.Q^T) so a lane owns one query column with its keys in registers: the softmax reductions are
+// in-lane plus one lane^32 exchange, and the probability tile is directly the A operand of P.V
+// (accumulator-as-operand, k order permuted: element jj of lane half h is key 16s + 8(jj>>2) + 4h + (jj&3)).
+// V is staged row-major in a wave-private 4 KB LDS tile and read with ds_read_b64_tr_b16 in that order.
+#include "common.h"
+
+namespace {
+
+constexpr float NEG_BIG = -3.0e38f;
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+// B-operand fragment (k = rows of the LDS tile in accumulator-permuted order, col = 32*ct + (lane&31))
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int s, int ct, int lane) {
+    const int g16 = lane >> 4, hh = g16 >> 1, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int row = 16 * s + 4 * hh + q;
+    const int col = ct * 32 + 16 * (g16 & 1) + 4 * p;
+    bf16x4 v0 = ds_read_tr16(tile + row * 128 + col * 2);
+    bf16x4 v1 = ds_read_tr16(tile + (row + 8) * 128 + col * 2);
+    return cat4(v0, v1);
+}
+
+// accumulator tile (regs = rows) -> two A-operand fragments of X^T
+__device__ __forceinline__ void acc_to_frags(const f32x16& x, bf16x8 (&f)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) f[s][jj] = (bf16)x[8 * s + jj];
+}
+
+// write an accumulator tile (row = (r&3)+8(r>>2)+4h, col = 32*ct + lane&31) into a [32][64] bf16 LDS tile
+__device__ __forceinline__ void acc_to_lds(char* tile, const f32x16& x, int ct, int lane, float scale) {
+    const int h = lane >> 5, c = ct * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        *(bf16*)(tile + row * 128 + c * 2) = (bf16)(x[r] * scale);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
+                                                       const float* __restrict__ rel, bf16* __restrict__ ctx,
+                                                       int64_t n_pairs, int L, int A) {
+    __shared__ __attribute__((aligned(16))) char lds[4][4096];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t pair = (int64_t)blockIdx.x * 4 + w;
+    const bool valid = pair < n_pairs;
+    if (!valid) pair = n_pairs - 1;
+    const int64_t n = pair / A;
+    const int a = (int)(pair - n * A);
+    const int HD = A * 64;
+    const int64_t ldq = 3 * HD;
+    const int row = lane & 31, h = lane >> 5;
+    const int rowc = row < L ? row : L - 1;
+    char* my = lds[w];
+
+    const bf16* qp = qkv + (n * L + rowc) * ldq + a * 64 + 8 * h;
+    bf16x8 qf[4], kf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *(const bf16x8*)(qp + 16 * s);
+        kf[s] = *(const bf16x8*)(qp + HD + 16 * s);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
+        int rc = r < L ? r : L - 1;
+        *(bf16x8*)(my + r * 128 + c * 16) = *(const bf16x8*)(qkv + (n * L + rc) * ldq + 2 * HD + a * 64 + c * 8);
+    }
+    f32x16 st = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
+
+    const float* relp = rel + a * 1024 + row * 32;
+    const float* mp = mask_add + n * 32;
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 mk = *(const f32x4*)(mp + 8 * g + 4 * h);
+        f32x4 rl = *(const f32x4*)(relp + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = st[4 * g + e] * 0.125f + mk[e] + rl[e];
+            st[4 * g + e] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        st[r] = __expf(st[r] - mx);
+        sum += st[r];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] *= inv;
+    bf16x8 pf[2];
+    acc_to_frags(st, pf);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        o[ct] = zero16();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[s], tr_frag(my, s, ct, lane), o[ct], 0, 0, 0);
+    }
+    acc_to_lds(my, o[0], 0, lane, 1.0f);
+    acc_to_lds(my, o[1], 1, lane, 1.0f);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
+        if (valid && r < L) *(bf16x8*)(ctx + (n * L + r) * HD + a * 64 + c * 8) = *(const bf16x8*)(my + r * 128 + c * 16);
+    }
+}
+
+// Backward: recompute P in both orientations, then dV = P^T dO, dS = P*(dP - rowsum(dP*P)),
+// dQ = dS K / 8, dK = dS^T Q / 8.
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
+                                                       const float* __restrict__ rel, const bf16* __restrict__ dctx,
+                                                       bf16* __restrict__ dqkv, int64_t n_pairs, int L, int A) {
+    // per wave: K tile, dO tile, Q tile (each 4 KB, row-major [32][64]) + 256 B of row statistics
+    __shared__ __attribute__((aligned(16))) char lds[4][3 * 4096 + 256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t pair = (int64_t)blockIdx.x * 4 + w;
+    const bool valid = pair < n_pairs;
+    if (!valid) pair = n_pairs - 1;
+    const int64_t n = pair / A;
+    const int a = (int)(pair - n * A);
+    const int HD = A * 64;
+    const int64_t ldq = 3 * HD;
+    const int row = lane & 31, h = lane >> 5;
+    const int rowc = row < L ? row : L - 1;
+    char* tK = lds[w];
+    char* tO = tK + 4096;
+    char* tQ = tK + 8192;
+    float* stat = (float*)(tK + 12288);          // [0..31] = max + log(sum) per query, [32..63] = D per query
+
+    const bf16* qp = qkv + (n * L + rowc) * ldq + a * 64 + 8 * h;
+    const bf16* dop = dctx + (n * L + rowc) * HD + a * 64 + 8 * h;
+    bf16x8 qf[4], kf[4], vf[4], df[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *(const bf16x8*)(qp + 16 * s);
+        kf[s] = *(const bf16x8*)(qp + HD + 16 * s);
+        vf[s] = *(const bf16x8*)(qp + 2 * HD + 16 * s);
+        df[s] = *(const bf16x8*)(dop + 16 * s);
+        if (row >= L) {                            // padded query rows must not contribute to dK / dV
+#pragma unroll
+            for (int e = 0; e < 8; ++e) df[s][e] = (bf16)0.f;
+        }
+        int off = row * 128 + (16 * s + 8 * h) * 2;
+        *(bf16x8*)(tK + off) = kf[s];
+        *(bf16x8*)(tO + off) = df[s];
+        *(bf16x8*)(tQ + off) = qf[s];
+    }
+    const float* mp = mask_add + n * 32;
+
+    // ---- transposed orientation: lanes = queries, regs = keys
+    f32x16 st = zero16(), dpt = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], df[s], dpt, 0, 0, 0);
+    }
+    {
+        const float* relp = rel + a * 1024 + row * 32;
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 mk = *(const f32x4*)(mp + 8 * g + 4 * h);
+            f32x4 rl = *(const f32x4*)(relp + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = st[4 * g + e] * 0.125f + mk[e] + rl[e];
+                st[4 * g + e] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = __expf(st[r] - mx);
+            sum += st[r];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        float dsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] *= inv;
+            dsum += st[r] * dpt[r];
+        }
+        dsum += __shfl_xor(dsum, 32, 64);
+        if (h == 0) {
+            stat[row] = mx + __logf(sum);
+            stat[32 + row] = dsum;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = st[r] * (dpt[r] - dsum);      // dS^T
+    }
+    bf16x8 dstf[2];
+    acc_to_frags(st, dstf);
+    f32x16 dq[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        dq[ct] = zero16();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            dq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dstf[s], tr_frag(tK, s, ct, lane), dq[ct], 0, 0, 0);
+    }
+
+    // ---- natural orientation: lanes = keys, regs = queries
+    f32x16 sn = zero16(), dpn = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s], kf[s], sn, 0, 0, 0);
+        dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[s], vf[s], dpn, 0, 0, 0);
+    }
+    {
+        const float mk = mp[row];                  // this lane's key
+        const float* relc = rel + a * 1024 + row;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 lse = *(const f32x4*)(stat + 8 * g + 4 * h);
+            f32x4 dd = *(const f32x4*)(stat + 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int qi = 8 * g + 4 * h + e;
+                float p = __expf(sn[4 * g + e] * 0.125f + mk + relc[qi * 32] - lse[e]);
+                sn[4 * g + e] = p;
+                dpn[4 * g + e] = p * (dpn[4 * g + e] - dd[e]);           // dS
+            }
+        }
+    }
+    bf16x8 pnf[2], dsf[2];
+    acc_to_frags(sn, pnf);
+    acc_to_frags(dpn, dsf);
+    f32x16 dv[2], dk[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        dv[ct] = zero16();
+        dk[ct] = zero16();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            dv[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pnf[s], tr_frag(tO, s, ct, lane), dv[ct], 0, 0, 0);
+            dk[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[s], tr_frag(tQ, s, ct, lane), dk[ct], 0, 0, 0);
+        }
+    }
+    // ---- stage the three gradient tiles (rows = token, cols = head dim) and store coalesced
+    acc_to_lds(tK, dq[0], 0, lane, 0.125f);
+    acc_to_lds(tK, dq[1], 1, lane, 0.125f);
+    acc_to_lds(tO, dk[0], 0, lane, 0.125f);
+    acc_to_lds(tO, dk[1], 1, lane, 0.125f);
+    acc_to_lds(tQ, dv[0], 0, lane, 1.0f);
+    acc_to_lds(tQ, dv[1], 1, lane, 1.0f);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
+        if (valid && r < L) {
+            bf16* dst = dqkv + (n * L + r) * ldq + a * 64 + c * 8;
+            *(bf16x8*)(dst) = *(const bf16x8*)(tK + r * 128 + c * 16);
+            *(bf16x8*)(dst + HD) = *(const bf16x8*)(tO + r * 128 + c * 16);
+            *(bf16x8*)(dst + 2 * HD) = *(const bf16x8*)(tQ + r * 128 + c * 16);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tnr_attn_l32_fwd(const void* qkv, const float* mask_add, const float* rel, void* ctx, int64_t n_seq,
+                                int L, int A, void* stream) {
+    TNR_CHECK_ARG(qkv && mask_add && rel && ctx, "tnr_attn_l32_fwd: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 32 && A >= 1 && n_seq >= 1, "tnr_attn_l32_fwd: need 1<=L<=32");
+    TNR_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 16) == 0, "tnr_attn_l32_fwd: 16-byte alignment");
+    int64_t pairs = n_seq * A;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)qkv, mask_add, rel, (bf16*)ctx, pairs, L, A);
+    TNR_CHECK_LAUNCH("tnr_attn_l32_fwd");
+    return TNR_OK;
+}
+
+extern "C" int tnr_attn_l32_bwd(const void* qkv, const float* mask_add, const float* rel, const void* dctx, void* dqkv,
+                                int64_t n_seq, int L, int A, void* stream) {
+    TNR_CHECK_ARG(qkv && mask_add && rel && dctx && dqkv, "tnr_attn_l32_bwd: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 32 && A >= 1 && n_seq >= 1, "tnr_attn_l32_bwd: need 1<=L<=32");
+    TNR_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)dctx % 16) == 0 && ((uintptr_t)dqkv % 16) == 0,
+                  "tnr_attn_l32_bwd: 16-byte alignment");
+    int64_t pairs = n_seq * A;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)qkv, mask_add, rel, (const bf16*)dctx, (bf16*)dqkv, pairs, L, A);
+    TNR_CHECK_LAUNCH("tnr_attn_l32_bwd");
+    return TNR_OK;
+}

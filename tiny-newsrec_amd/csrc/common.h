@@ -1,0 +1,66 @@
+// Shared device/host helpers for libtnr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tnr_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define WAVE 64
+
+void tnr_set_error(const char* fmt, ...);
+
+#define TNR_CHECK_ARG(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            tnr_set_error(__VA_ARGS__);   \
+            return TNR_EINVAL;            \
+        }                                 \
+    } while (0)
+
+#define TNR_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            tnr_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return TNR_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = __expf(-0.5f * x * x) * 0.39894228040143268f;
+    return cdf + x * pdf;
+}
+
+// async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+// transposed LDS read: per 16-lane group a 4-row x 16-col block of 16-bit elements, delivered
+// column-major (lane i gets column i, rows 0..3); lane 4q+p supplies the address of row q, cols 4p..4p+3.
+__device__ __forceinline__ bf16x4 ds_read_tr16(const void* lds_ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)lds_ptr);
+}

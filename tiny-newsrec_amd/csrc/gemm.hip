@@ -1,0 +1,329 @@
+// bf16 MFMA GEMMs for the encoder's Linear layers (forward, dgrad, wgrad).
+//
+//   tnr_gemm_nt       C[M,N] = epi(A[M,K] . B[N,K]^T)   both operands K-contiguous
+//   tnr_gemm_tn_wgrad dW[N,K] = dY[M,N]^T . X[M,K]      both operands M-strided -> transposed LDS reads
+//
+// Tile 128x128, 4 waves (2x2), each wave 64x64 = 4x4 tiles of v_mfma_f32_16x16x32_bf16.
+// Operands are staged global -> LDS with global_load_lds (16 B per lane, lane-linear LDS image); the
+// XOR swizzle that makes the fragment reads bank-conflict free is applied on the per-lane SOURCE
+// address and again on the read address (cdna_hip_programming.md section 5.4 rule 21).  Two LDS buffers,
+// next tile's loads issued before the current tile's MFMAs, one barrier per K tile; 64 KB LDS per
+// workgroup -> 2 workgroups per CU overlap each other's barrier stalls.
+#include "common.h"
+
+namespace {
+
+struct NTArgs {
+    const bf16* A; int64_t lda;
+    const bf16* B; int64_t ldb;
+    void* C; int64_t ldc;
+    int M, N, K;
+    const float* bias;
+    const bf16* res; int64_t ldres;
+    bf16* aux; int64_t ldaux;
+    int flags;
+};
+
+constexpr int TILE_BYTES = 128 * 128;   // one operand tile: 128 rows x 64 bf16
+constexpr int BUF_BYTES = 2 * TILE_BYTES;
+
+// bijective XCD remap: blocks b and b+8 share an XCD (round-robin dispatch), give every XCD a
+// contiguous run of the tile order so that neighbouring tiles (same A rows) hit one L2.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int nbn = g.N >> 7;
+    const int nbm = (g.M + 127) >> 7;
+    const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+    const int bm = wg / nbn, bn = wg - bm * nbn;
+
+    // ---- staging: 4 A pieces + 4 B pieces of 1 KiB (8 rows x 128 B) per wave and K tile
+    const bf16* asrc[4];
+    const bf16* bsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row = (w * 4 + q) * 8 + (lane >> 3);
+        int chunk = (lane & 7) ^ (row & 7);
+        int gm = bm * 128 + row;
+        gm = gm < g.M ? gm : g.M - 1;                       // rows past M are computed but never stored
+        asrc[q] = g.A + (int64_t)gm * g.lda + chunk * 8;
+        bsrc[q] = g.B + (int64_t)(bn * 128 + row) * g.ldb + chunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * BUF_BYTES + (w * 4) * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(asrc[q] + kt * 64, base + q * 1024);
+            glds16(bsrc[q] + kt * 64, base + TILE_BYTES + q * 1024);
+        }
+    };
+
+    // fragment read offsets inside a tile: row = 16*t + (lane&15), 16-B chunk = 4*s + (lane>>4)
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K >> 6;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sa = smem + cur * BUF_BYTES + (wm * 64) * 128;
+        const char* sb = smem + cur * BUF_BYTES + TILE_BYTES + (wn * 64) * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+            // operands swapped: D = Bfrag . Afrag^T, so a lane holds C[m = lane&15][n = 4*(lane>>4) + r]
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: 4 consecutive n per lane and tile
+    const int flags = g.flags;
+    const int m_base = bm * 128 + wm * 64 + (lane & 15);
+    const int n_base = bn * 128 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n_base + j * 16;
+        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (flags & TNR_EPI_BIAS) bv = *(const f32x4*)(g.bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + i * 16;
+            if (m >= g.M) continue;
+            f32x4 v = acc[i][j] + bv;
+            if (flags & TNR_EPI_AUXOUT) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+                *(bf16x4*)(g.aux + (int64_t)m * g.ldaux + n) = o;
+            }
+            if (flags & TNR_EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (flags & TNR_EPI_TANH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            }
+            if (flags & TNR_EPI_MULDGELU) {
+                bf16x4 u = *(const bf16x4*)(g.aux + (int64_t)m * g.ldaux + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+            }
+            if (flags & TNR_EPI_RES) {
+                bf16x4 rr = *(const bf16x4*)(g.res + (int64_t)m * g.ldres + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (flags & TNR_EPI_OUTF32) {
+                *(f32x4*)((float*)g.C + (int64_t)m * g.ldc + n) = v;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+                *(bf16x4*)((bf16*)g.C + (int64_t)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: out tile 128 (n) x 128 (k), reduction over m in steps of 64.  LDS tiles are [64 m][128 cols]
+// bf16 (256-B rows); fragments come from ds_read_b64_tr_b16.  32-B column pairs are XOR-swizzled by
+// (row&3) | ((row>>3)&1)<<2 so the 8 rows a 32-lane half touches cover all 64 banks once.
+struct TNArgs {
+    const bf16* dY; int64_t lddy;
+    const bf16* X; int64_t ldx;
+    float* ws;                 // (splits, N, K) fp32 slabs
+    int Mt;                    // number of 64-row m tiles (Mpad / 64)
+    int N, K;
+    int tiles_per_split;
+};
+
+__device__ __forceinline__ int tn_swz(int row) { return (((row & 3) | (((row >> 3) & 1) << 2)) << 1); }
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wn = w >> 1, wk = w & 1;          // wave tile: 64 n x 64 k
+    const int nbk = g.K >> 7;
+    const int bn = blockIdx.x / nbk, bk = blockIdx.x - bn * nbk;
+    const int z = blockIdx.y;
+    const int mt0 = z * g.tiles_per_split;
+    int mt1 = mt0 + g.tiles_per_split;
+    if (mt1 > g.Mt) mt1 = g.Mt;
+
+    // staging: each tile = 64 rows x 256 B = 16 pieces of 1 KiB (4 rows); 4 pieces per wave per operand
+    const bf16* ysrc[4];
+    const bf16* xsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row = (w * 4 + q) * 4 + (lane >> 4);
+        int chunk = (lane & 15) ^ tn_swz(row);
+        ysrc[q] = g.dY + (int64_t)row * g.lddy + bn * 128 + chunk * 8;
+        xsrc[q] = g.X + (int64_t)row * g.ldx + bk * 128 + chunk * 8;
+    }
+    auto stage = [&](int buf, int mt) {
+        char* base = smem + buf * BUF_BYTES + (w * 4) * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            glds16(ysrc[q] + (int64_t)mt * 64 * g.lddy, base + q * 1024);
+            glds16(xsrc[q] + (int64_t)mt * 64 * g.ldx, base + TILE_BYTES + q * 1024);
+        }
+    };
+
+    // tr-read byte offsets: m row = 32*s + 8*(lane>>4) + q (+4), q = (lane&15)>>2, p = lane&3 ;
+    // 16-col tile t -> logical 16-B chunk 2*t + (p>>1), byte (p&1)*8 inside it
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    int roff[2][2], rswz[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = 32 * s + 8 * g16 + q4 + 4 * h;
+            roff[s][h] = row * 256 + (p4 & 1) * 8;
+            rswz[s][h] = tn_swz(row);
+        }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (mt0 < mt1) {
+        stage(0, mt0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int mt = mt0; mt < mt1; ++mt) {
+            const int cur = (mt - mt0) & 1;
+            if (mt + 1 < mt1) stage(cur ^ 1, mt + 1);
+            const char* sy = smem + cur * BUF_BYTES;
+            const char* sx = smem + cur * BUF_BYTES + TILE_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 yf[4], xf[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    int cy = 2 * (wn * 4 + t) + (p4 >> 1);
+                    int cx = 2 * (wk * 4 + t) + (p4 >> 1);
+                    bf16x4 y0 = ds_read_tr16(sy + roff[s][0] + ((cy ^ rswz[s][0]) << 4));
+                    bf16x4 y1 = ds_read_tr16(sy + roff[s][1] + ((cy ^ rswz[s][1]) << 4));
+                    bf16x4 x0 = ds_read_tr16(sx + roff[s][0] + ((cx ^ rswz[s][0]) << 4));
+                    bf16x4 x1 = ds_read_tr16(sx + roff[s][1] + ((cx ^ rswz[s][1]) << 4));
+                    yf[t] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    xf[t] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                // D[row = k (regs)][col = n (lane&15)] : A operand = X^T fragment, B operand = dY fragment
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], yf[i], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    // slab store: lane holds dW[n = .. + (lane&15)][k = .. + 4*(lane>>4) + r]
+    float* slab = g.ws + (int64_t)z * g.N * g.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int n = bn * 128 + wn * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k = bk * 128 + wk * 64 + j * 16 + (lane >> 4) * 4;
+            *(f32x4*)(slab + (int64_t)n * g.K + k) = acc[i][j];
+        }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t NK, int K, float* out,
+                                   int64_t ldo, int accumulate) {
+    int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= NK) return;
+    f32x4 s = *(const f32x4*)(ws + i4);
+    for (int z = 1; z < splits; ++z) s += *(const f32x4*)(ws + (int64_t)z * NK + i4);
+    int64_t n = i4 / K, k = i4 - n * K;
+    float* o = out + n * ldo + k;
+    if (accumulate) s += *(const f32x4*)o;
+    *(f32x4*)o = s;
+}
+
+}  // namespace
+
+extern "C" int tnr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                           int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                           void* aux, int64_t ldaux, int flags, void* stream) {
+    TNR_CHECK_ARG(A && B && C, "tnr_gemm_nt: null operand");
+    TNR_CHECK_ARG(M >= 1 && N >= 128 && (N % 128) == 0 && K >= 64 && (K % 64) == 0,
+                  "tnr_gemm_nt: need N%%128==0, K%%64==0 (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
+    TNR_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0 && lda >= K && ldb >= K && ldc >= N,
+                  "tnr_gemm_nt: bad leading dimension");
+    TNR_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
+                  "tnr_gemm_nt: operands must be 16-byte aligned");
+    TNR_CHECK_ARG(!(flags & TNR_EPI_BIAS) || bias, "tnr_gemm_nt: TNR_EPI_BIAS without bias");
+    TNR_CHECK_ARG(!(flags & TNR_EPI_RES) || (res && (ldres % 4) == 0), "tnr_gemm_nt: TNR_EPI_RES without res");
+    TNR_CHECK_ARG(!(flags & (TNR_EPI_MULDGELU | TNR_EPI_AUXOUT)) || (aux && (ldaux % 4) == 0),
+                  "tnr_gemm_nt: aux required");
+    TNR_CHECK_ARG(M < (1 << 24), "tnr_gemm_nt: M too large");
+    NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags};
+    int nwg = (int)(((M + 127) / 128) * (N / 128));
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(nwg), dim3(256), 2 * BUF_BYTES, (hipStream_t)stream, g);
+    TNR_CHECK_LAUNCH("tnr_gemm_nt");
+    return TNR_OK;
+}
+
+extern "C" int64_t tnr_gemm_tn_ws_elems(int64_t N, int64_t K, int splits) { return N * K * (int64_t)splits; }
+
+extern "C" int tnr_gemm_tn_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
+                                 int64_t lddw, int64_t M, int64_t N, int64_t K, float* ws, int splits,
+                                 int accumulate, void* stream) {
+    TNR_CHECK_ARG(dY && X && dW && ws, "tnr_gemm_tn_wgrad: null operand");
+    TNR_CHECK_ARG(M >= 1 && (N % 128) == 0 && (K % 128) == 0 && N >= 128 && K >= 128,
+                  "tnr_gemm_tn_wgrad: need N%%128==0, K%%128==0 (N=%ld K=%ld)", (long)N, (long)K);
+    TNR_CHECK_ARG((lddy % 8) == 0 && (ldx % 8) == 0 && (lddw % 4) == 0 && lddy >= N && ldx >= K && lddw >= K,
+                  "tnr_gemm_tn_wgrad: bad leading dimension");
+    TNR_CHECK_ARG(((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)dW % 16) == 0 &&
+                      ((uintptr_t)ws % 16) == 0, "tnr_gemm_tn_wgrad: operands must be 16-byte aligned");
+    int Mt = (int)((M + 63) / 64);
+    TNR_CHECK_ARG(splits >= 1 && splits <= 64, "tnr_gemm_tn_wgrad: splits out of range");
+    if (splits > Mt) splits = Mt;
+    int tps = (Mt + splits - 1) / splits;
+    splits = (Mt + tps - 1) / tps;
+    TNArgs g{(const bf16*)dY, lddy, (const bf16*)X, ldx, ws, Mt, (int)N, (int)K, tps};
+    dim3 grid((unsigned)((N / 128) * (K / 128)), (unsigned)splits);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 2 * BUF_BYTES, (hipStream_t)stream, g);
+    TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad");
+    int64_t NK = N * K;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((NK / 4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)ws, splits, NK, (int)K, dW, lddw, accumulate);
+    TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad/reduce");
+    return TNR_OK;
+}

@@ -1,0 +1,607 @@
+// Heads of the recommender: additive-attention pooling, user encoder + dot-product scorer, KD losses.
+// All fp32 (raw exp without max-subtraction as in model_bert.py:27-32 needs fp32 range), reductions as
+// wavefront reductions, fixed summation order (no float atomics).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// AttentionPooling over title tokens (model_bert.py:15-34, no mask).  One workgroup per title.
+__global__ __launch_bounds__(256) void attpool_fwd_kernel(const bf16* __restrict__ y, const float* __restrict__ e,
+                                                          int64_t lde, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, int Q, float* __restrict__ nv,
+                                                          float* __restrict__ alpha, float* __restrict__ den, int L, int H) {
+    __shared__ float al[32];
+    const int64_t n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = w; i < L; i += 4) {
+        const float* er = e + (n * L + i) * lde;
+        float s = 0.f;
+        for (int q = lane; q < Q; q += 64) s += er[q] * w2[q];
+        s = wave_sum(s);
+        if (lane == 0) al[i] = __expf(s + b2[0]);
+    }
+    __syncthreads();
+    float d = 0.f;
+    for (int i = 0; i < L; ++i) d += al[i];
+    d += 1e-8f;
+    if (tid < 32) alpha[n * 32 + tid] = tid < L ? al[tid] / d : 0.f;
+    if (tid == 0) den[n] = d;
+    for (int c = tid * 4; c < H; c += 1024) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < L; ++i) {
+            bf16x4 v = *(const bf16x4*)(y + (n * L + i) * H + c);
+            float wi = al[i] / d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += wi * (float)v[r];
+        }
+        *(f32x4*)(nv + n * H + c) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    }
+}
+
+__global__ __launch_bounds__(256) void attpool_bwd_kernel(const bf16* __restrict__ y, const float* __restrict__ e,
+                                                          int64_t lde, const float* __restrict__ w2, int Q,
+                                                          const float* __restrict__ dnv, const float* __restrict__ alpha,
+                                                          bf16* __restrict__ dy, bf16* __restrict__ dpre, int64_t lddpre,
+                                                          float* __restrict__ dw2_part, float* __restrict__ db2_part,
+                                                          int L, int H) {
+    __shared__ float dw[32], da[32];
+    const int64_t n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = w; i < L; i += 4) {
+        float s = 0.f;
+        for (int c = lane * 4; c < H; c += 256) {
+            bf16x4 v = *(const bf16x4*)(y + (n * L + i) * H + c);
+            f32x4 g = *(const f32x4*)(dnv + n * H + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += g[r] * (float)v[r];
+        }
+        s = wave_sum(s);
+        if (lane == 0) dw[i] = s;
+    }
+    __syncthreads();
+    float S = 0.f;
+    for (int i = 0; i < L; ++i) S += dw[i] * alpha[n * 32 + i];
+    if (tid < L) da[tid] = alpha[n * 32 + tid] * (dw[tid] - S);      // d loss / d (fc2 output) of token tid
+    __syncthreads();
+    for (int c = tid * 4; c < H; c += 1024) {
+        f32x4 g = *(const f32x4*)(dnv + n * H + c);
+        for (int i = 0; i < L; ++i) {
+            float wi = alpha[n * 32 + i];
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)(wi * g[r]);
+            *(bf16x4*)(dy + (n * L + i) * H + c) = o;
+        }
+    }
+    for (int q = tid; q < lddpre; q += 256) {
+        float sw2 = 0.f;
+        float wq = q < Q ? w2[q] : 0.f;
+        for (int i = 0; i < L; ++i) {
+            float ev = q < Q ? e[(n * L + i) * lde + q] : 0.f;
+            dpre[(n * L + i) * lddpre + q] = (bf16)(da[i] * wq * (1.f - ev * ev));
+            sw2 += da[i] * ev;
+        }
+        if (q < Q) dw2_part[n * Q + q] = sw2;
+    }
+    if (tid == 0) {
+        float s = 0.f;
+        for (int i = 0; i < L; ++i) s += da[i];
+        db2_part[n] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small batched fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain): tile 64x64, BK 16
+struct SgemmArgs {
+    const float* A; int64_t a_rs, a_cs, sA;
+    const float* B; int64_t b_rs, b_cs, sB;
+    float* C; int64_t ldc, sC;
+    const float* bias; int64_t sBias;
+    int M, N, K;
+    float alpha, beta;
+};
+
+__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
+    __shared__ float As[64][17], Bs[64][17];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int z = blockIdx.z;
+    const float* A = g.A + z * g.sA;
+    const float* B = g.B + z * g.sB;
+    float* C = g.C + z * g.sC;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool a_kfast = g.a_cs == 1, b_kfast = g.b_cs == 1;
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int idx = tid + 256 * q;
+            int ra = a_kfast ? idx >> 4 : idx & 63, ka = a_kfast ? idx & 15 : idx >> 6;
+            int rb = b_kfast ? idx >> 4 : idx & 63, kb = b_kfast ? idx & 15 : idx >> 6;
+            float av = 0.f, bv = 0.f;
+            if (m0 + ra < g.M && k0 + ka < g.K) av = A[(int64_t)(m0 + ra) * g.a_rs + (int64_t)(k0 + ka) * g.a_cs];
+            if (n0 + rb < g.N && k0 + kb < g.K) bv = B[(int64_t)(n0 + rb) * g.b_rs + (int64_t)(k0 + kb) * g.b_cs];
+            As[ra][ka] = av;
+            Bs[rb][kb] = bv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            float a = As[wm * 32 + (lane & 31)][kk + (lane >> 5)];
+            float b = Bs[wn * 32 + (lane & 31)][kk + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n >= g.N) return;
+    const float bv = g.bias ? g.bias[z * g.sBias + n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M) {
+            float v = g.alpha * acc[r] + bv;
+            float* c = C + (int64_t)m * g.ldc + n;
+            if (g.beta != 0.f) v += g.beta * *c;
+            *c = v;
+        }
+    }
+}
+
+// rows of per-model tables gathered into a dense (n_model, n_idx, D) array
+__global__ void gather_rows_kernel(const float* __restrict__ tbl, int64_t R, const int32_t* __restrict__ idx,
+                                   int64_t n_idx, int D, float* __restrict__ out, int64_t out_rows, int64_t out_row0) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int d4 = D / 4;
+    int64_t total = n_idx * d4;
+    if (t >= total) return;
+    int z = blockIdx.y;
+    int64_t r = t / d4;
+    int c = (int)(t - r * d4) * 4;
+    *(f32x4*)(out + ((int64_t)z * out_rows + out_row0 + r) * D + c) =
+        *(const f32x4*)(tbl + ((int64_t)z * R + idx[r]) * D + c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// UserEncoder (model_bert.py:155-176) + scorer (:204).  One workgroup per (impression, model).
+constexpr int MAXU = 64;
+
+template <bool FWD>
+__device__ __forceinline__ void load_hv(float* hv, const float* vec, const int32_t* hidx, const float* mask,
+                                        const float* pad, int user_log_mask, int U, int D, int tid) {
+    for (int t = tid; t < U * (D / 4); t += 256) {
+        int u = t / (D / 4), c = (t - u * (D / 4)) * 4;
+        f32x4 v = *(const f32x4*)(vec + (int64_t)hidx[u] * D + c);
+        if (!user_log_mask) {
+            float m = mask[u];
+            f32x4 p = *(const f32x4*)(pad + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * m + p[r] * (1.f - m);
+        }
+        *(f32x4*)(hv + u * D + c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void user_score_fwd_kernel(
+    const float* __restrict__ vec, int64_t R, const int32_t* __restrict__ hidx, const int32_t* __restrict__ cidx,
+    const float* __restrict__ mask, const float* __restrict__ pad, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int user_log_mask,
+    float* __restrict__ user, float* __restrict__ score, float* __restrict__ e_out, float* __restrict__ alpha,
+    float* __restrict__ den, int B, int U, int C, int D, int Q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* hv = (float*)smem;                 // [U][D]
+    float* es = hv + U * D;                   // [U][Q]
+    float* al = es + U * Q;                   // [MAXU]
+    float* us = al + MAXU;                    // [D]
+    const int b = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    vec += (int64_t)z * R * D;
+    pad += (int64_t)z * D;
+    w1 += (int64_t)z * Q * D;
+    b1 += (int64_t)z * Q;
+    w2 += (int64_t)z * Q;
+    hidx += (int64_t)b * U;
+    cidx += (int64_t)b * C;
+    mask += (int64_t)b * U;
+    load_hv<true>(hv, vec, hidx, mask, pad, user_log_mask, U, D, tid);
+    __syncthreads();
+    // fc1 + tanh: thread q keeps U accumulators; hv rows are LDS broadcasts
+    for (int q = tid; q < Q; q += 256) {
+        float acc[MAXU];
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) acc[u] = 0.f;
+        const float* wr = w1 + (int64_t)q * D;
+        for (int d = 0; d < D; d += 4) {
+            f32x4 wv = *(const f32x4*)(wr + d);
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u)
+                if (u < U) {
+                    f32x4 h = *(const f32x4*)(hv + u * D + d);
+                    acc[u] += h[0] * wv[0] + h[1] * wv[1] + h[2] * wv[2] + h[3] * wv[3];
+                }
+        }
+        float bq = b1[q];
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u)
+            if (u < U) {
+                float ev = tanhf(acc[u] + bq);
+                es[u * Q + q] = ev;
+                e_out[(((int64_t)z * B + b) * U + u) * Q + q] = ev;
+            }
+    }
+    __syncthreads();
+    for (int u = w; u < U; u += 4) {
+        float s = 0.f;
+        for (int q = lane; q < Q; q += 64) s += es[u * Q + q] * w2[q];
+        s = wave_sum(s);
+        if (lane == 0) {
+            float a = __expf(s + b2[z]);
+            if (user_log_mask) a *= mask[u];
+            al[u] = a;
+        }
+    }
+    __syncthreads();
+    float dsum = 0.f;
+    for (int u = 0; u < U; ++u) dsum += al[u];
+    dsum += 1e-8f;
+    if (tid < U) alpha[((int64_t)z * B + b) * U + tid] = al[tid] / dsum;
+    if (tid == 0) den[(int64_t)z * B + b] = dsum;
+    for (int d = tid; d < D; d += 256) {
+        float s = 0.f;
+        for (int u = 0; u < U; ++u) s += (al[u] / dsum) * hv[u * D + d];
+        us[d] = s;
+        user[((int64_t)z * B + b) * D + d] = s;
+    }
+    __syncthreads();
+    for (int c = w; c < C; c += 4) {
+        const float* cr = vec + (int64_t)cidx[c] * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += cr[d] * us[d];
+        s = wave_sum(s);
+        if (lane == 0) score[((int64_t)z * B + b) * C + c] = s;
+    }
+}
+
+// backward of the student's user encoder; D must be <= 256*DV with DV columns per thread
+__global__ __launch_bounds__(256) void user_bwd_kernel(
+    const float* __restrict__ vec, const int32_t* __restrict__ hidx, const float* __restrict__ mask,
+    const float* __restrict__ pad, const float* __restrict__ w1, const float* __restrict__ w2, int user_log_mask,
+    const float* __restrict__ duser, const float* __restrict__ e, const float* __restrict__ alpha,
+    float* __restrict__ dvec, float* __restrict__ part, int U, int D, int Q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* hv = (float*)smem;                 // [U][D]
+    float* dpt = hv + U * D;                  // [Q][MAXU]  (d tanh-preactivation, transposed)
+    float* dw = dpt + Q * MAXU;               // [MAXU]
+    float* da = dw + MAXU;                    // [MAXU]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    hidx += (int64_t)b * U;
+    mask += (int64_t)b * U;
+    duser += (int64_t)b * D;
+    e += (int64_t)b * U * Q;
+    alpha += (int64_t)b * U;
+    const int64_t pstride = (int64_t)Q * D + 2 * Q + 1 + D;
+    float* p_w1 = part + b * pstride;
+    float* p_b1 = p_w1 + (int64_t)Q * D;
+    float* p_w2 = p_b1 + Q;
+    float* p_b2 = p_w2 + Q;
+    float* p_pad = p_b2 + 1;
+    load_hv<false>(hv, vec, hidx, mask, pad, user_log_mask, U, D, tid);
+    __syncthreads();
+    for (int u = w; u < U; u += 4) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += duser[d] * hv[u * D + d];
+        s = wave_sum(s);
+        if (lane == 0) dw[u] = s;
+    }
+    __syncthreads();
+    float S = 0.f;
+    for (int u = 0; u < U; ++u) S += dw[u] * alpha[u];
+    if (tid < MAXU) da[tid] = tid < U ? alpha[tid] * (dw[tid] - S) : 0.f;
+    __syncthreads();
+    for (int q = tid; q < Q; q += 256) {
+        float wq = w2[q], sb1 = 0.f, sw2 = 0.f;
+        for (int u = 0; u < MAXU; ++u) {
+            float v = 0.f;
+            if (u < U) {
+                float ev = e[u * Q + q];
+                v = da[u] * wq * (1.f - ev * ev);
+                sw2 += da[u] * ev;
+            }
+            dpt[q * MAXU + u] = v;
+            sb1 += v;
+        }
+        p_b1[q] = sb1;
+        p_w2[q] = sw2;
+    }
+    if (tid == 0) {
+        float s = 0.f;
+        for (int u = 0; u < U; ++u) s += da[u];
+        p_b2[0] = s;
+    }
+    __syncthreads();
+    for (int d = tid; d < D; d += 256) {
+        float hcol[MAXU], acc[MAXU];
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+            hcol[u] = u < U ? hv[u * D + d] : 0.f;
+            acc[u] = 0.f;
+        }
+        for (int q = 0; q < Q; ++q) {
+            float wv = w1[(int64_t)q * D + d];
+            float g = 0.f;
+#pragma unroll
+            for (int u4 = 0; u4 < MAXU; u4 += 4) {
+                f32x4 dp = *(const f32x4*)(dpt + q * MAXU + u4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    g += dp[r] * hcol[u4 + r];
+                    acc[u4 + r] += dp[r] * wv;
+                }
+            }
+            p_w1[(int64_t)q * D + d] = g;
+        }
+        float du = duser[d], dp_pad = 0.f;
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u)
+            if (u < U) {
+                float g = alpha[u] * du + acc[u];
+                float m = user_log_mask ? 1.f : mask[u];
+                dp_pad += g * (1.f - m);
+                dvec[(int64_t)hidx[u] * D + d] += g * m;
+            }
+        p_pad[d] = dp_pad;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// score-level KD losses (model_bert.py:271, 286-298): one thread per impression, fixed-order block sum
+__global__ __launch_bounds__(256) void kd_score_loss_kernel(const float* __restrict__ s_score,
+                                                            const float* __restrict__ t_score,
+                                                            const int64_t* __restrict__ label, float tau, float coef,
+                                                            float* __restrict__ tw, float* __restrict__ dscore,
+                                                            float* __restrict__ losses, int B, int C, int T) {
+    __shared__ float red[2][256];
+    float l_distill = 0.f, l_target = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const int y = (int)label[b];
+        // teacher CE and weights softmax(-CE)
+        float ce[16], mxw = -3.0e38f;
+        for (int i = 0; i < T; ++i) {
+            const float* ts = t_score + ((int64_t)i * B + b) * C;
+            float mx = -3.0e38f;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, ts[c]);
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += __expf(ts[c] - mx);
+            ce[i] = -(ts[y] - mx - __logf(se));
+            mxw = fmaxf(mxw, -ce[i]);
+        }
+        float sw = 0.f;
+        for (int i = 0; i < T; ++i) {
+            ce[i] = __expf(-ce[i] - mxw);
+            sw += ce[i];
+        }
+        for (int i = 0; i < T; ++i) {
+            ce[i] /= sw;
+            tw[(int64_t)b * T + i] = ce[i];
+        }
+        // mixed teacher scores, student log-softmax at temperature tau and at 1
+        const float* ss = s_score + (int64_t)b * C;
+        float mt = -3.0e38f, ms = -3.0e38f, ms1 = -3.0e38f;
+        float tm[16];
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+            for (int i = 0; i < T; ++i) v += t_score[((int64_t)i * B + b) * C + c] * ce[i];
+            tm[c] = v / tau;
+            mt = fmaxf(mt, tm[c]);
+            ms = fmaxf(ms, ss[c] / tau);
+            ms1 = fmaxf(ms1, ss[c]);
+        }
+        float zt = 0.f, zs = 0.f, zs1 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            zt += __expf(tm[c] - mt);
+            zs += __expf(ss[c] / tau - ms);
+            zs1 += __expf(ss[c] - ms1);
+        }
+        float lzs = __logf(zs), lzs1 = __logf(zs1), d = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float pT = __expf(tm[c] - mt) / zt;
+            float ls = ss[c] / tau - ms - lzs;
+            d -= pT * ls;
+            float pS = __expf(ls);
+            float p1 = __expf(ss[c] - ms1 - lzs1);
+            float g = (T > 0 ? (pS - pT) / tau : 0.f) + coef * (p1 - (c == y ? 1.f : 0.f));
+            dscore[(int64_t)b * C + c] = g / (float)B;
+        }
+        if (T > 0) l_distill += d;
+        l_target += -(ss[y] - ms1 - lzs1);
+    }
+    red[0][threadIdx.x] = l_distill;
+    red[1][threadIdx.x] = l_target;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        losses[0] = red[0][0] / (float)B;
+        losses[1] = red[1][0] / (float)B;
+    }
+}
+
+// embedding-level KD (model_bert.py:277-284, 300-303): one wave per (impression, row)
+__global__ __launch_bounds__(256) void kd_embed_loss_kernel(const float* __restrict__ S, const float* __restrict__ P,
+                                                            const float* __restrict__ tw, float* __restrict__ dS,
+                                                            float* __restrict__ dP, float* __restrict__ part, int B,
+                                                            int rows, int D, int T) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (int64_t)B * rows) return;
+    const int b = (int)(wv / rows), r = (int)(wv - (int64_t)b * rows);
+    const float rowscale = r < rows - 1 ? 1.f / (float)(rows - 1) : 1.f;     // news rows are averaged, user row not
+    float loss = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        f32x4 s = *(const f32x4*)(S + wv * D + c);
+        f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < T; ++i) {
+            float wi = tw[(int64_t)b * T + i];
+            float ci = wi * rowscale * 2.f / ((float)D * (float)B);
+            int64_t off = (((int64_t)i * B + b) * rows + r) * D + c;
+            f32x4 df = s - *(const f32x4*)(P + off);
+            loss += wi * rowscale * (df[0] * df[0] + df[1] * df[1] + df[2] * df[2] + df[3] * df[3]);
+            g += ci * df;
+            *(f32x4*)(dP + off) = -ci * df;
+        }
+        *(f32x4*)(dS + wv * D + c) = g;
+    }
+    loss = wave_sum(loss);
+    if (lane == 0) part[wv] = loss / ((float)D * (float)B);
+}
+
+// dvec[row] += dscore[b,c] * user[b]  for candidate rows ; duser[b] += sum_c dscore[b,c] * cand[b,c]
+__global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict__ vec, const int32_t* __restrict__ cidx,
+                                                        const float* __restrict__ user, const float* __restrict__ dscore,
+                                                        float* __restrict__ dvec, float* __restrict__ duser, int C, int D) {
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float u = user[(int64_t)b * D + d], acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float g = dscore[(int64_t)b * C + c];
+            int64_t row = cidx[(int64_t)b * C + c];
+            acc += g * vec[row * D + d];
+            dvec[row * D + d] += g * u;
+        }
+        duser[(int64_t)b * D + d] += acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int tnr_attpool_fwd(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
+                               float* nv, float* alpha, float* den, int64_t n_seq, int L, int H, void* stream) {
+    TNR_CHECK_ARG(y && e && w2 && b2 && nv && alpha && den, "tnr_attpool_fwd: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 32 && (H % 4) == 0 && Q >= 1 && lde >= Q && n_seq >= 1, "tnr_attpool_fwd: bad shape");
+    hipLaunchKernelGGL(attpool_fwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, e,
+                       lde, w2, b2, Q, nv, alpha, den, L, H);
+    TNR_CHECK_LAUNCH("tnr_attpool_fwd");
+    return TNR_OK;
+}
+
+extern "C" int tnr_attpool_bwd(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
+                               const float* alpha, const float* den, void* dy_direct, void* dpre, int64_t lddpre,
+                               float* dw2_part, float* db2_part, int64_t n_seq, int L, int H, void* stream) {
+    (void)den;
+    TNR_CHECK_ARG(y && e && w2 && dnv && alpha && dy_direct && dpre && dw2_part && db2_part, "tnr_attpool_bwd: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 32 && (H % 4) == 0 && Q >= 1 && lde >= Q && lddpre >= Q && n_seq >= 1,
+                  "tnr_attpool_bwd: bad shape");
+    hipLaunchKernelGGL(attpool_bwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, e,
+                       lde, w2, Q, dnv, alpha, (bf16*)dy_direct, (bf16*)dpre, lddpre, dw2_part, db2_part, L, H);
+    TNR_CHECK_LAUNCH("tnr_attpool_bwd");
+    return TNR_OK;
+}
+
+extern "C" int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA, const int32_t* a_idx, const float* B,
+                         int64_t b_rs, int64_t b_cs, int64_t sB, float* C, int64_t ldc, int64_t sC, const float* bias,
+                         int64_t sBias, int64_t M, int64_t N, int64_t K, int batch, float alpha, float beta,
+                         void* stream) {
+    TNR_CHECK_ARG(A && B && C && M >= 1 && N >= 1 && K >= 1 && batch >= 1, "tnr_sgemm: bad argument");
+    TNR_CHECK_ARG(a_idx == nullptr, "tnr_sgemm: row gather is done by tnr_gather_rows");
+    SgemmArgs g{A, a_rs, a_cs, sA, B, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, (int)M, (int)N, (int)K, alpha, beta};
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)batch);
+    hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    TNR_CHECK_LAUNCH("tnr_sgemm");
+    return TNR_OK;
+}
+
+extern "C" int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, int64_t n_idx, int D, int n_model,
+                               float* out, int64_t out_rows, int64_t out_row0, void* stream) {
+    TNR_CHECK_ARG(tbl && idx && out && n_idx >= 1 && (D % 4) == 0 && n_model >= 1, "tnr_gather_rows: bad argument");
+    int64_t total = n_idx * (D / 4);
+    dim3 grid((unsigned)((total + 255) / 256), (unsigned)n_model);
+    hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, tbl, R, idx, n_idx, D, out, out_rows,
+                       out_row0);
+    TNR_CHECK_LAUNCH("tnr_gather_rows");
+    return TNR_OK;
+}
+
+static int user_shape_ok(int B, int U, int C, int D, int Q) {
+    return B >= 1 && U >= 1 && U <= MAXU && C >= 0 && (D % 4) == 0 && D >= 4 && Q >= 1;
+}
+
+extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const int32_t* cidx,
+                                  const float* mask, const float* pad, const float* w1, const float* b1, const float* w2,
+                                  const float* b2, int user_log_mask, float* user, float* score, float* e, float* alpha,
+                                  float* den, int n_model, int B, int U, int C, int D, int Q, void* stream) {
+    TNR_CHECK_ARG(vec && hidx && cidx && mask && pad && w1 && b1 && w2 && b2 && user && score && e && alpha && den,
+                  "tnr_user_score_fwd: null pointer");
+    TNR_CHECK_ARG(user_shape_ok(B, U, C, D, Q) && n_model >= 1, "tnr_user_score_fwd: bad shape (U <= %d)", MAXU);
+    size_t lds = sizeof(float) * ((size_t)U * D + (size_t)U * Q + MAXU + D);
+    TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_score_fwd: U*D + U*Q too large for LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)user_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(user_score_fwd_kernel, dim3((unsigned)B, (unsigned)n_model), dim3(256), lds, (hipStream_t)stream,
+                       vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, user, score, e, alpha, den, B, U, C,
+                       D, Q);
+    TNR_CHECK_LAUNCH("tnr_user_score_fwd");
+    return TNR_OK;
+}
+
+extern "C" int64_t tnr_user_bwd_part_stride(int D, int Q) { return (int64_t)Q * D + 2 * Q + 1 + D; }
+
+extern "C" int tnr_user_bwd(const float* vec, const int32_t* hidx, const float* mask, const float* pad, const float* w1,
+                            const float* w2, int user_log_mask, const float* duser, const float* e, const float* alpha,
+                            const float* den, float* dvec, float* part, int B, int U, int D, int Q, void* stream) {
+    (void)den;
+    TNR_CHECK_ARG(vec && hidx && mask && pad && w1 && w2 && duser && e && alpha && dvec && part, "tnr_user_bwd: null pointer");
+    TNR_CHECK_ARG(user_shape_ok(B, U, 0, D, Q), "tnr_user_bwd: bad shape (U <= %d)", MAXU);
+    size_t lds = sizeof(float) * ((size_t)U * D + (size_t)Q * MAXU + 2 * MAXU);
+    TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_bwd: too large for LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)user_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(user_bwd_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, vec, hidx, mask, pad, w1,
+                       w2, user_log_mask, duser, e, alpha, dvec, part, U, D, Q);
+    TNR_CHECK_LAUNCH("tnr_user_bwd");
+    return TNR_OK;
+}
+
+extern "C" int tnr_kd_score_loss(const float* s_score, const float* t_score, const int64_t* label, float temperature,
+                                 float coef, float* tw, float* dscore, float* losses, int B, int C, int T, void* stream) {
+    TNR_CHECK_ARG(s_score && label && dscore && losses && (T == 0 || (t_score && tw)), "tnr_kd_score_loss: null pointer");
+    TNR_CHECK_ARG(B >= 1 && C >= 1 && C <= 16 && T >= 0 && T <= 16, "tnr_kd_score_loss: need C<=16, T<=16");
+    hipLaunchKernelGGL(kd_score_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s_score, t_score, label,
+                       temperature, coef, tw, dscore, losses, B, C, T);
+    TNR_CHECK_LAUNCH("tnr_kd_score_loss");
+    return TNR_OK;
+}
+
+extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
+                               void* stream);
+
+extern "C" int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* loss, float* dS, float* dP,
+                                 float* part, int B, int rows, int D, int T, void* stream) {
+    TNR_CHECK_ARG(S && P && tw && loss && dS && dP && part, "tnr_kd_embed_loss: null pointer");
+    TNR_CHECK_ARG(B >= 1 && rows >= 2 && (D % 4) == 0 && T >= 1, "tnr_kd_embed_loss: bad shape");
+    int64_t waves = (int64_t)B * rows;
+    hipLaunchKernelGGL(kd_embed_loss_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, P, tw,
+                       dS, dP, part, B, rows, D, T);
+    TNR_CHECK_LAUNCH("tnr_kd_embed_loss");
+    return tnr_reduce_rows(part, waves, 1, 1, loss, 0, stream);
+}
+
+extern "C" int tnr_score_bwd(const float* vec, const int32_t* cidx, const float* user, const float* dscore, float* dvec,
+                             float* duser, int B, int C, int D, void* stream) {
+    TNR_CHECK_ARG(vec && cidx && user && dscore && dvec && duser && B >= 1 && C >= 1 && D >= 1, "tnr_score_bwd: bad argument");
+    hipLaunchKernelGGL(score_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, vec, cidx, user, dscore, dvec,
+                       duser, C, D);
+    TNR_CHECK_LAUNCH("tnr_score_bwd");
+    return TNR_OK;
+}

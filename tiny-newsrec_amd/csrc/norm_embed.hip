@@ -1,0 +1,346 @@
+// HBM-bound row kernels: embedding gather + LayerNorm, LayerNorm fwd/bwd, rel-pos table, column sums.
+// One wave per row of H = 256*V elements; each lane owns V runs of 4 consecutive elements
+// (8-byte bf16 / 16-byte fp32 accesses, 512 B coalesced per wave-instruction).
+#include "common.h"
+
+namespace {
+
+template <int V>
+__device__ __forceinline__ void row_stats(const float (&x)[V][4], int H, float& mean, float& rstd, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += x[v][r];
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float d = x[v][r] - mean;
+            q += d * d;
+        }
+    rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+}
+
+// tnlrv3/modeling.py:153-178 (word + pos + type0 -> LN) fused with the mask of :446-454
+template <int V>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict__ tok, int64_t n_tok, int L,
+                                                       const float* __restrict__ word, const float* __restrict__ pos,
+                                                       const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, bf16* __restrict__ out,
+                                                       float* __restrict__ mask_add) {
+    const int H = 256 * V;
+    const int lane = threadIdx.x & 63;
+    int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tok) return;
+    int64_t n = t / L;
+    int i = (int)(t - n * L);
+    int64_t id = tok[n * 2 * L + i];
+    if (lane == 0) {
+        int64_t mk = tok[n * 2 * L + L + i];
+        mask_add[n * 32 + i] = (1.0f - (float)mk) * -10000.0f;
+        if (i == 0)
+            for (int j = L; j < 32; ++j) mask_add[n * 32 + j] = -1e30f;
+    }
+    float x[V][4];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        int c = v * 256 + lane * 4;
+        f32x4 a = *(const f32x4*)(word + id * H + c);
+        f32x4 b = *(const f32x4*)(pos + (int64_t)i * H + c);
+        f32x4 d = *(const f32x4*)(type0 + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[v][r] = a[r] + b[r] + d[r];
+    }
+    float mean, rstd;
+    row_stats<V>(x, H, mean, rstd, eps);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        int c = v * 256 + lane * 4;
+        f32x4 gm = *(const f32x4*)(gamma + c);
+        f32x4 bt = *(const f32x4*)(beta + c);
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)((x[v][r] - mean) * rstd * gm[r] + bt[r]);
+        *(bf16x4*)(out + t * H + c) = o;
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ xin, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, bf16* __restrict__ y,
+                                                     float* __restrict__ stats, int64_t M) {
+    const int H = 256 * V;
+    const int lane = threadIdx.x & 63;
+    int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float x[V][4];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        bf16x4 a = *(const bf16x4*)(xin + m * H + v * 256 + lane * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[v][r] = (float)a[r];
+    }
+    float mean, rstd;
+    row_stats<V>(x, H, mean, rstd, eps);
+    if (stats && lane == 0) {
+        stats[m * 2] = mean;
+        stats[m * 2 + 1] = rstd;
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        int c = v * 256 + lane * 4;
+        f32x4 gm = *(const f32x4*)(gamma + c);
+        f32x4 bt = *(const f32x4*)(beta + c);
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)((x[v][r] - mean) * rstd * gm[r] + bt[r]);
+        *(bf16x4*)(y + m * H + c) = o;
+    }
+}
+
+// dx = rstd * (dxh - mean(dxh) - xh * mean(dxh*xh)), dxh = dy*gamma ; per-block partial dgamma/dbeta
+constexpr int LNB_ROWS = 64;   // rows per block (4 waves x 16 rows)
+template <int V>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ xin,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     bf16* __restrict__ dx, float* __restrict__ part, int64_t M) {
+    const int H = 256 * V;
+    __shared__ float red[4][2][256 * V];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float gm[V][4], dg[V][4], db[V][4];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        f32x4 t = *(const f32x4*)(gamma + v * 256 + lane * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gm[v][r] = t[r];
+            dg[v][r] = 0.f;
+            db[v][r] = 0.f;
+        }
+    }
+    for (int it = 0; it < LNB_ROWS / 4; ++it) {
+        int64_t m = (int64_t)blockIdx.x * LNB_ROWS + it * 4 + w;
+        if (m >= M) break;
+        float mean = stats[m * 2], rstd = stats[m * 2 + 1];
+        float xh[V][4], g[V][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            bf16x4 a = *(const bf16x4*)(xin + m * H + v * 256 + lane * 4);
+            bf16x4 d = *(const bf16x4*)(dy + m * H + v * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float dyv = (float)d[r];
+                xh[v][r] = ((float)a[r] - mean) * rstd;
+                g[v][r] = dyv * gm[v][r];
+                s1 += g[v][r];
+                s2 += g[v][r] * xh[v][r];
+                dg[v][r] += dyv * xh[v][r];
+                db[v][r] += dyv;
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)(rstd * (g[v][r] - s1 - xh[v][r] * s2));
+            *(bf16x4*)(dx + m * H + v * 256 + lane * 4) = o;
+        }
+    }
+    if (part == nullptr) return;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[w][0][v * 256 + lane * 4 + r] = dg[v][r];
+            red[w][1][v * 256 + lane * 4 + r] = db[v][r];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * H; c += 256) {
+        int k = c / H, h = c - k * H;
+        part[(int64_t)blockIdx.x * 2 * H + c] = red[0][k][h] + red[1][k][h] + red[2][k][h] + red[3][k][h];
+    }
+}
+
+// fixed-order sum over rows of a (rows, stride) fp32 matrix
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int64_t rows, int64_t stride, int64_t n,
+                                   float* __restrict__ out, int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t r = 0;
+    for (; r + 4 <= rows; r += 4) {
+        s0 += part[r * stride + i];
+        s1 += part[(r + 1) * stride + i];
+        s2 += part[(r + 2) * stride + i];
+        s3 += part[(r + 3) * stride + i];
+    }
+    for (; r < rows; ++r) s0 += part[r * stride + i];
+    float s = (s0 + s1) + (s2 + s3);
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// column sums: block (256 threads) owns 256 columns? no: 64 columns x 4 row-lanes, CS_ROWS rows per block
+constexpr int CS_ROWS = 512;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
+                                                     float* __restrict__ part) {
+    // thread handles 4 consecutive columns; 64 threads across 256 columns, 4 row groups
+    __shared__ float red[4][256];
+    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 256 + cg * 4;
+    const int64_t m0 = (int64_t)blockIdx.y * CS_ROWS;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        int64_t mend = m0 + CS_ROWS < M ? m0 + CS_ROWS : M;
+        for (int64_t m = m0 + rg; m < mend; m += 4) {
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 a = *(const bf16x4*)((const bf16*)X + m * ldx + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] += (float)a[r];
+            } else {
+                f32x4 a = *(const f32x4*)((const float*)X + m * ldx + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] += a[r];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[rg][cg * 4 + r] = s[r];
+    __syncthreads();
+    int t = threadIdx.x;
+    int64_t col = (int64_t)blockIdx.x * 256 + t;
+    if (col < N) part[(int64_t)blockIdx.y * N + col] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
+
+// tnlrv3/modeling.py:345-373 bucket (integer edges, see oracle) + the Linear(32->A) lookup of :462-463
+__device__ __forceinline__ int relpos_bucket(int rel) {
+    int n = rel < 0 ? -rel : rel;
+    int b;
+    if (n < 8) b = n;
+    else if (n < 12) b = 8;
+    else if (n < 16) b = 9;
+    else if (n < 23) b = 10;
+    else if (n < 32) b = 11;
+    else if (n < 46) b = 12;
+    else if (n < 64) b = 13;
+    else if (n < 91) b = 14;
+    else b = 15;
+    return (rel > 0 ? 16 : 0) + b;
+}
+__global__ void relpos_kernel(const float* __restrict__ weight, int A, int L, float* __restrict__ table) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= A * 1024) return;
+    int a = idx >> 10, i = (idx >> 5) & 31, j = idx & 31;
+    table[idx] = (i < L && j < L) ? weight[a * 32 + relpos_bucket(j - i)] : 0.f;
+}
+
+__global__ void cast_f2b_kernel(const float* __restrict__ s, bf16* __restrict__ d, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = (bf16)s[i];
+}
+__global__ void cast_b2f_kernel(const bf16* __restrict__ s, float* __restrict__ d, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = (float)s[i];
+}
+
+}  // namespace
+
+extern "C" int tnr_relpos_table(const float* weight, int A, int L, float* table, void* stream) {
+    TNR_CHECK_ARG(weight && table && A >= 1 && L >= 1 && L <= 32, "tnr_relpos_table: need 1<=L<=32");
+    hipLaunchKernelGGL(relpos_kernel, dim3((A * 1024 + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, A, L, table);
+    TNR_CHECK_LAUNCH("tnr_relpos_table");
+    return TNR_OK;
+}
+
+extern "C" int tnr_embed_ln_fwd(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
+                                const float* type0, const float* gamma, const float* beta, float eps, void* out,
+                                float* mask_add, void* stream) {
+    TNR_CHECK_ARG(tok && word && pos && type0 && gamma && beta && out && mask_add, "tnr_embed_ln_fwd: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 32 && n_seq >= 1, "tnr_embed_ln_fwd: need 1<=L<=32");
+    TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_embed_ln_fwd: H must be 256/512/768/1024");
+    int64_t n_tok = n_seq * L;
+    dim3 grid((unsigned)((n_tok + 3) / 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(V) hipLaunchKernelGGL(embed_ln_kernel<V>, grid, blk, 0, st, tok, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add)
+    switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+    TNR_CHECK_LAUNCH("tnr_embed_ln_fwd");
+    return TNR_OK;
+}
+
+extern "C" int tnr_ln_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* stats,
+                          int64_t M, int H, void* stream) {
+    TNR_CHECK_ARG(x && gamma && beta && y && M >= 1, "tnr_ln_fwd: null pointer");
+    TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_ln_fwd: H must be 256/512/768/1024");
+    dim3 grid((unsigned)((M + 3) / 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(V) hipLaunchKernelGGL(ln_fwd_kernel<V>, grid, blk, 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)y, stats, M)
+    switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+    TNR_CHECK_LAUNCH("tnr_ln_fwd");
+    return TNR_OK;
+}
+
+extern "C" int64_t tnr_ln_bwd_part_elems(int64_t M, int H) { return ((M + LNB_ROWS - 1) / LNB_ROWS) * 2 * H; }
+
+extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
+                               void* stream) {
+    TNR_CHECK_ARG(part && out && rows >= 1 && n >= 1, "tnr_reduce_rows: bad argument");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                       rows, stride, n, out, accumulate);
+    TNR_CHECK_LAUNCH("tnr_reduce_rows");
+    return TNR_OK;
+}
+
+extern "C" int tnr_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                          float* dgamma, float* dbeta, float* part, int64_t M, int H, void* stream) {
+    TNR_CHECK_ARG(dy && x && stats && gamma && dx && M >= 1, "tnr_ln_bwd: null pointer");
+    TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_ln_bwd: H must be 256/512/768/1024");
+    TNR_CHECK_ARG(!(dgamma || dbeta) || part, "tnr_ln_bwd: part workspace required for dgamma/dbeta");
+    int64_t nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
+    dim3 grid((unsigned)nblk), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    float* p = (dgamma || dbeta) ? part : nullptr;
+#define LAUNCH(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, blk, 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, p, M)
+    switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+    TNR_CHECK_LAUNCH("tnr_ln_bwd");
+    if (dgamma) { int rc = tnr_reduce_rows(part, nblk, 2 * H, H, dgamma, 0, stream); if (rc) return rc; }
+    if (dbeta) { int rc = tnr_reduce_rows(part + H, nblk, 2 * H, H, dbeta, 0, stream); if (rc) return rc; }
+    return TNR_OK;
+}
+
+extern "C" int64_t tnr_colsum_part_elems(int64_t M, int64_t N) { return ((M + CS_ROWS - 1) / CS_ROWS) * N; }
+
+extern "C" int tnr_colsum(const void* X, int64_t ldx, int dtype, int64_t M, int64_t N, float* out, float* part,
+                          int accumulate, void* stream) {
+    TNR_CHECK_ARG(X && out && part && M >= 1 && N >= 4 && (N % 4) == 0 && (ldx % 4) == 0, "tnr_colsum: bad argument");
+    TNR_CHECK_ARG(dtype == TNR_BF16 || dtype == TNR_F32, "tnr_colsum: dtype");
+    int64_t nby = (M + CS_ROWS - 1) / CS_ROWS;
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nby), blk(256);
+    if (dtype == TNR_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, blk, 0, (hipStream_t)stream, (const bf16*)X, ldx, M, N, part);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)X, ldx, M, N, part);
+    TNR_CHECK_LAUNCH("tnr_colsum");
+    return tnr_reduce_rows(part, nby, N, N, out, accumulate, stream);
+}
+
+extern "C" int tnr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    TNR_CHECK_ARG(src && dst && n >= 1, "tnr_cast_f32_to_bf16: bad argument");
+    hipLaunchKernelGGL(cast_f2b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n);
+    TNR_CHECK_LAUNCH("tnr_cast_f32_to_bf16");
+    return TNR_OK;
+}
+extern "C" int tnr_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+    TNR_CHECK_ARG(src && dst && n >= 1, "tnr_cast_bf16_to_f32: bad argument");
+    hipLaunchKernelGGL(cast_b2f_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, dst, n);
+    TNR_CHECK_LAUNCH("tnr_cast_bf16_to_f32");
+    return TNR_OK;
+}

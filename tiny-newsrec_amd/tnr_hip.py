@@ -1,0 +1,97 @@
+"""ctypes binding of libtnr_hip.so (include/tnr_hip.h).  No fallback: a missing library or a
+non-zero status raises.  torch supplies device memory and the current HIP stream only."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtnr_hip.so")
+
+BF16, F16, F32 = 0, 1, 2
+EPI_BIAS, EPI_GELU, EPI_TANH, EPI_RES, EPI_MULDGELU, EPI_OUTF32, EPI_AUXOUT = 1, 2, 4, 8, 16, 32, 64
+
+_c = ctypes
+_P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
+
+# name -> argument types (return type int unless listed in _RET)
+_SIG = {
+    "tnr_version": [],
+    "tnr_relpos_table": [_P, _I, _I, _P, _P],
+    "tnr_embed_ln_fwd": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "tnr_gemm_nt": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P, _L, _I, _P],
+    "tnr_gemm_tn_wgrad": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _P],
+    "tnr_gemm_tn_ws_elems": [_L, _L, _I],
+    "tnr_ln_fwd": [_P, _P, _P, _F, _P, _P, _L, _I, _P],
+    "tnr_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
+    "tnr_ln_bwd_part_elems": [_L, _I],
+    "tnr_attn_l32_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "tnr_attn_l32_bwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "tnr_colsum": [_P, _L, _I, _L, _L, _P, _P, _I, _P],
+    "tnr_colsum_part_elems": [_L, _L],
+    "tnr_attpool_fwd": [_P, _P, _L, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P],
+    "tnr_attpool_bwd": [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P],
+    "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _P],
+    "tnr_gather_rows": [_P, _L, _P, _L, _I, _I, _P, _L, _L, _P],
+    "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tnr_user_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "tnr_user_bwd_part_stride": [_I, _I],
+    "tnr_score_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "tnr_kd_score_loss": [_P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _P],
+    "tnr_kd_embed_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "tnr_reduce_rows": [_P, _L, _L, _L, _P, _I, _P],
+    "tnr_amsgrad_step": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
+    "tnr_refresh_shadows": [_P, _I, _L, _P, _P],
+    "tnr_cast_f32_to_bf16": [_P, _P, _L, _P],
+    "tnr_cast_bf16_to_f32": [_P, _P, _L, _P],
+}
+_RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_ln_bwd_part_elems": _L, "tnr_colsum_part_elems": _L,
+        "tnr_user_bwd_part_stride": _L}
+EXPORTS = sorted(_SIG) + ["tnr_last_error"]
+
+_lib = None
+
+
+class TnrError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libtnr_hip.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TnrError("libtnr_hip.so not built: run `make -C tiny-newsrec_amd/csrc` (or __graft_entry__.build())")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIG.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _RET.get(name, _I)
+        L.tnr_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an int-status entry point on torch's current stream (appended automatically)."""
+    L = lib()
+    conv = [_ptr(a) if (isinstance(a, torch.Tensor) or a is None) else a for a in args]
+    rc = getattr(L, name)(*conv, stream())
+    if rc != 0:
+        raise TnrError("%s failed (%d): %s" % (name, rc, L.tnr_last_error().decode()))
+
+
+def query(name, *args):
+    return getattr(lib(), name)(*args)
