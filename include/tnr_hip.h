@@ -57,6 +57,13 @@ int tnr_embed_ln_fwd(const int64_t* tok, int64_t n_seq, int L, int H, const floa
                      const float* type0, const float* gamma, const float* beta, float eps,
                      void* out, float* mask_add, void* stream);
 
+/* Same, with the token rows gathered on the device: news_combined (n_news+1, 2L) int32 is the resident
+ * table of preprocess.py:48-66 / run.py:53 and nidx (N) int32 the news indices of dataloader.py:129-138,
+ * so only indices cross PCIe per step (the reference ships the gathered int64 rows, dataloader.py:152-154). */
+int tnr_embed_ln_fwd_indexed(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
+                             const float* word, const float* pos, const float* type0, const float* gamma,
+                             const float* beta, float eps, void* out, float* mask_add, void* stream);
+
 /* C[M,N] = epilogue(A[M,K] . B[N,K]^T).  bf16 operands, fp32 MFMA accumulation.
  * Forward Linear (tnlrv3/modeling.py:236-248, transformers BertSelfOutput/BertIntermediate/BertOutput),
  * and its dgrad when B is the transposed weight copy.  N % 128 == 0, K % 64 == 0, any M >= 1. */
@@ -126,13 +133,13 @@ int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, int64_t n_i
  * `n_model` encoders at once (student and/or frozen teachers), one workgroup per (impression, model).
  * vec: (n_model, R, D) fp32 row tables ; hidx (B,U) / cidx (B,C) int32 row ids ; mask (B,U) fp32.
  * params are stacked per model: pad (n_model,D), w1 (n_model,Q,D), b1 (n_model,Q), w2 (n_model,Q), b2 (n_model).
- * out: user (n_model,B,D), score (n_model,B,C), saved e (n_model,B,U,Q), alpha (n_model,B,U), den (n_model,B). */
+ * out: user (model z at user + z*user_stride, (B,D)), score (n_model,B,C), saved e (n_model,B,U,Q), alpha (n_model,B,U), den (n_model,B). */
 int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const int32_t* cidx, const float* mask,
                        const float* pad, const float* w1, const float* b1, const float* w2, const float* b2,
-                       int user_log_mask, float* user, float* score, float* e, float* alpha, float* den,
-                       int n_model, int B, int U, int C, int D, int Q, void* stream);
+                       int user_log_mask, float* user, int64_t user_stride, float* score, float* e, float* alpha,
+                       float* den, int n_model, int B, int U, int C, int D, int Q, void* stream);
 /* backward of the student's user encoder: duser (B,D) -> dvec rows hidx (+=), and per-impression
- * partial parameter gradients part (B, Q*D + Q + Q + 1 + D) laid out [w1|b1|w2|b2|pad]. */
+ * partial parameter gradients part (B, Q*D + Q + Q + D + 1) laid out [w1|b1|w2|pad|b2]. */
 int tnr_user_bwd(const float* vec, const int32_t* hidx, const float* mask, const float* pad, const float* w1,
                  const float* w2, int user_log_mask, const float* duser, const float* e, const float* alpha,
                  const float* den, float* dvec, float* part, int B, int U, int D, int Q, void* stream);
@@ -148,11 +155,11 @@ int tnr_score_bwd(const float* vec, const int32_t* cidx, const float* user, cons
  * s_score (B,C) ; t_score (T,B,C) ; out: tw (B,T), dscore (B,C), losses[0..1] = distill, target. */
 int tnr_kd_score_loss(const float* s_score, const float* t_score, const int64_t* label, float temperature,
                       float coef, float* tw, float* dscore, float* losses, int B, int C, int T, void* stream);
-/* embedding KD (model_bert.py:277-284, 300-303) on stacked rows: per impression U+C news rows then 1
- * user row.  S (B,U+C+1,D) student rows ; P (T,B,U+C+1,D) projected teacher rows ; tw (B,T).
- * out: emb loss (scalar, += into losses[2]) ; dS (B,U+C+1,D) ; dP (T,B,U+C+1,D). */
+/* embedding KD (model_bert.py:277-284, 300-303) on stacked rows [B*U history | B*C candidate | B user]:
+ * S (Rtot,D) student rows ; P (T,Rtot,D) projected teacher rows ; tw (B,T) ; Rtot = B*(U+C+1).
+ * out: emb loss (scalar) ; dS (Rtot,D) ; dP (T,Rtot,D) ; part (Rtot) workspace. */
 int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* loss, float* dS, float* dP,
-                      float* part, int B, int rows, int D, int T, void* stream);
+                      float* part, int B, int U, int C, int D, int T, void* stream);
 
 /* out[i] (+)= sum_r part[r*stride + i] , i < n  (fixed order) */
 int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,

@@ -318,7 +318,7 @@ def test_user_score_fwd_bwd(ulm):
     e, alpha, den = torch.zeros((nm, B, U, Q), device=DEV), torch.zeros((nm, B, U), device=DEV), torch.zeros((nm, B), device=DEV)
     dv = {k: dev(v) for k, v in pr.items()}
     T.call("tnr_user_score_fwd", dev(vec), R, dev(hidx), dev(cidx), dev(mask), dv["pad"], dv["w1"], dv["b1"], dv["w2"],
-           dv["b2"], ulm, user, score, e, alpha, den, nm, B, U, C, D, Q)
+           dv["b2"], ulm, user, B * D, score, e, alpha, den, nm, B, U, C, D, Q)
     torch.cuda.synchronize()
     caches = []
     for z in range(nm):
@@ -345,7 +345,7 @@ def test_user_score_fwd_bwd(ulm):
     p = part.sum(0).cpu().numpy()
     o = 0
     for key, n in (("p.attn.att_fc1.weight", Q * D), ("p.attn.att_fc1.bias", Q), ("p.attn.att_fc2.weight", Q),
-                   ("p.attn.att_fc2.bias", 1), ("p.pad_doc", D)):
+                   ("p.pad_doc", D), ("p.attn.att_fc2.bias", 1)):
         ref = G[key].reshape(-1)
         if key.endswith("att_fc2.bias"):      # mathematical no-op (cancels in the normaliser): rounding noise only
             assert abs(p[o]) < 1e-3 and abs(ref[0]) < 1e-3
@@ -382,21 +382,24 @@ def test_kd_score_loss(T_, tau):
 
 
 def test_kd_embed_loss():
-    B, rows, D, T_ = 4, 56, 256, 3
-    S, P, tw = rnd((B, rows, D), 1, 0.3), rnd((T_, B, rows, D), 2, 0.3), O.softmax(rnd((B, T_), 3))
-    dS, dP = torch.zeros((B, rows, D), device=DEV), torch.zeros((T_, B, rows, D), device=DEV)
-    loss, part = torch.zeros(1, device=DEV), torch.zeros(B * rows, device=DEV)
-    T.call("tnr_kd_embed_loss", dev(S), dev(P), dev(tw), loss, dS, dP, part, B, rows, D, T_)
+    B, U, C, D, T_ = 4, 50, 5, 256, 3
+    nn, rt = B * (U + C), B * (U + C + 1)
+    S, P, tw = rnd((rt, D), 1, 0.3), rnd((T_, rt, D), 2, 0.3), O.softmax(rnd((B, T_), 3))
+    dS, dP = torch.zeros((rt, D), device=DEV), torch.zeros((T_, rt, D), device=DEV)
+    loss, part = torch.zeros(1, device=DEV), torch.zeros(rt, device=DEV)
+    T.call("tnr_kd_embed_loss", dev(S), dev(P), dev(tw), loss, dS, dP, part, B, U, C, D, T_)
     torch.cuda.synchronize()
-    ne = np.stack([((S[:, :-1] - P[i][:, :-1]) ** 2).mean(-1).mean(-1) for i in range(T_)], -1)
-    ue = np.stack([((S[:, -1] - P[i][:, -1]) ** 2).mean(-1) for i in range(T_)], -1)
+    # back to the reference's (B, U+C, D) news layout + (B, D) user layout
+    news = lambda X: np.concatenate([X[:B * U].reshape(B, U, D), X[B * U:nn].reshape(B, C, D)], 1)
+    ne = np.stack([((news(S) - news(P[i])) ** 2).mean(-1).mean(-1) for i in range(T_)], -1)
+    ue = np.stack([((S[nn:] - P[i][nn:]) ** 2).mean(-1) for i in range(T_)], -1)
     want = (ne * tw).sum(-1).mean() + (ue * tw).sum(-1).mean()
     np.testing.assert_allclose(loss.item(), want, rtol=1e-4)
-    scale = np.full((rows,), 1.0 / (rows - 1), np.float32)
-    scale[-1] = 1.0
+    bidx = np.concatenate([np.repeat(np.arange(B), U), np.repeat(np.arange(B), C), np.arange(B)])
+    scale = np.concatenate([np.full(nn, 1.0 / (U + C), np.float32), np.ones(B, np.float32)])
     dSr = np.zeros_like(S)
     for i in range(T_):
-        ci = tw[:, i][:, None, None] * scale[None, :, None] * 2.0 / (D * B)
+        ci = (tw[bidx, i] * scale * 2.0 / (D * B))[:, None]
         dSr += ci * (S - P[i])
         np.testing.assert_allclose(dP[i].cpu().numpy(), -ci * (S - P[i]), rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(dS.cpu().numpy(), dSr, rtol=1e-4, atol=1e-8)

@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
     const float* __restrict__ vec, int64_t R, const int32_t* __restrict__ hidx, const int32_t* __restrict__ cidx,
     const float* __restrict__ mask, const float* __restrict__ pad, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int user_log_mask,
-    float* __restrict__ user, float* __restrict__ score, float* __restrict__ e_out, float* __restrict__ alpha,
-    float* __restrict__ den, int B, int U, int C, int D, int Q) {
+    float* __restrict__ user, int64_t user_stride, float* __restrict__ score, float* __restrict__ e_out,
+    float* __restrict__ alpha, float* __restrict__ den, int B, int U, int C, int D, int Q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hv = (float*)smem;                 // [U][D]
     float* es = hv + U * D;                   // [U][Q]
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
         float s = 0.f;
         for (int u = 0; u < U; ++u) s += (al[u] / dsum) * hv[u * D + d];
         us[d] = s;
-        user[((int64_t)z * B + b) * D + d] = s;
+        user[(int64_t)z * user_stride + (int64_t)b * D + d] = s;
     }
     __syncthreads();
     for (int c = w; c < C; c += 4) {
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256) void user_bwd_kernel(
     float* p_w1 = part + b * pstride;
     float* p_b1 = p_w1 + (int64_t)Q * D;
     float* p_w2 = p_b1 + Q;
-    float* p_b2 = p_w2 + Q;
-    float* p_pad = p_b2 + 1;
+    float* p_pad = p_w2 + Q;
+    float* p_b2 = p_pad + D;
     load_hv<false>(hv, vec, hidx, mask, pad, user_log_mask, U, D, tid);
     __syncthreads();
     for (int u = w; u < U; u += 4) {
@@ -432,16 +432,21 @@ __global__ __launch_bounds__(256) void kd_score_loss_kernel(const float* __restr
     }
 }
 
-// embedding-level KD (model_bert.py:277-284, 300-303): one wave per (impression, row)
+// embedding-level KD (model_bert.py:277-284, 300-303): one wave per row of the stacked layout
+// [B*U history rows | B*C candidate rows | B user rows]; news rows are averaged over U+C, user rows not.
 __global__ __launch_bounds__(256) void kd_embed_loss_kernel(const float* __restrict__ S, const float* __restrict__ P,
                                                             const float* __restrict__ tw, float* __restrict__ dS,
                                                             float* __restrict__ dP, float* __restrict__ part, int B,
-                                                            int rows, int D, int T) {
+                                                            int U, int C, int D, int T) {
     const int lane = threadIdx.x & 63;
     const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= (int64_t)B * rows) return;
-    const int b = (int)(wv / rows), r = (int)(wv - (int64_t)b * rows);
-    const float rowscale = r < rows - 1 ? 1.f / (float)(rows - 1) : 1.f;     // news rows are averaged, user row not
+    const int64_t nh = (int64_t)B * U, nn = (int64_t)B * (U + C), rtot = nn + B;
+    if (wv >= rtot) return;
+    int b;
+    float rowscale;
+    if (wv < nh) { b = (int)(wv / U); rowscale = 1.f / (float)(U + C); }
+    else if (wv < nn) { b = (int)((wv - nh) / C); rowscale = 1.f / (float)(U + C); }
+    else { b = (int)(wv - nn); rowscale = 1.f; }
     float loss = 0.f;
     for (int c = lane * 4; c < D; c += 256) {
         f32x4 s = *(const f32x4*)(S + wv * D + c);
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256) void kd_embed_loss_kernel(const float* __restr
         for (int i = 0; i < T; ++i) {
             float wi = tw[(int64_t)b * T + i];
             float ci = wi * rowscale * 2.f / ((float)D * (float)B);
-            int64_t off = (((int64_t)i * B + b) * rows + r) * D + c;
+            int64_t off = ((int64_t)i * rtot + wv) * D + c;
             f32x4 df = s - *(const f32x4*)(P + off);
             loss += wi * rowscale * (df[0] * df[0] + df[1] * df[1] + df[2] * df[2] + df[3] * df[3]);
             g += ci * df;
@@ -528,26 +533,28 @@ extern "C" int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, 
 }
 
 static int user_shape_ok(int B, int U, int C, int D, int Q) {
-    return B >= 1 && U >= 1 && U <= MAXU && C >= 0 && (D % 4) == 0 && D >= 4 && Q >= 1;
+    return B >= 1 && U >= 1 && U <= MAXU && C >= 0 && (D % 4) == 0 && D >= 4 && Q >= 4 && (Q % 4) == 0;
 }
 
 extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const int32_t* cidx,
                                   const float* mask, const float* pad, const float* w1, const float* b1, const float* w2,
-                                  const float* b2, int user_log_mask, float* user, float* score, float* e, float* alpha,
-                                  float* den, int n_model, int B, int U, int C, int D, int Q, void* stream) {
+                                  const float* b2, int user_log_mask, float* user, int64_t user_stride, float* score,
+                                  float* e, float* alpha, float* den, int n_model, int B, int U, int C, int D, int Q,
+                                  void* stream) {
     TNR_CHECK_ARG(vec && hidx && cidx && mask && pad && w1 && b1 && w2 && b2 && user && score && e && alpha && den,
                   "tnr_user_score_fwd: null pointer");
-    TNR_CHECK_ARG(user_shape_ok(B, U, C, D, Q) && n_model >= 1, "tnr_user_score_fwd: bad shape (U <= %d)", MAXU);
+    TNR_CHECK_ARG(user_shape_ok(B, U, C, D, Q) && n_model >= 1 && user_stride >= (int64_t)B * D,
+                  "tnr_user_score_fwd: bad shape (U <= %d)", MAXU);
     size_t lds = sizeof(float) * ((size_t)U * D + (size_t)U * Q + MAXU + D);
     TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_score_fwd: U*D + U*Q too large for LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)user_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)user_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(user_score_fwd_kernel, dim3((unsigned)B, (unsigned)n_model), dim3(256), lds, (hipStream_t)stream,
-                       vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, user, score, e, alpha, den, B, U, C,
-                       D, Q);
+                       vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, user, user_stride, score, e, alpha, den,
+                       B, U, C, D, Q);
     TNR_CHECK_LAUNCH("tnr_user_score_fwd");
     return TNR_OK;
 }
@@ -564,7 +571,7 @@ extern "C" int tnr_user_bwd(const float* vec, const int32_t* hidx, const float* 
     TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_bwd: too large for LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)user_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)user_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(user_bwd_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, vec, hidx, mask, pad, w1,
@@ -587,12 +594,12 @@ extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, 
                                void* stream);
 
 extern "C" int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* loss, float* dS, float* dP,
-                                 float* part, int B, int rows, int D, int T, void* stream) {
+                                 float* part, int B, int U, int C, int D, int T, void* stream) {
     TNR_CHECK_ARG(S && P && tw && loss && dS && dP && part, "tnr_kd_embed_loss: null pointer");
-    TNR_CHECK_ARG(B >= 1 && rows >= 2 && (D % 4) == 0 && T >= 1, "tnr_kd_embed_loss: bad shape");
-    int64_t waves = (int64_t)B * rows;
+    TNR_CHECK_ARG(B >= 1 && U >= 1 && C >= 1 && (D % 4) == 0 && T >= 1, "tnr_kd_embed_loss: bad shape");
+    int64_t waves = (int64_t)B * (U + C + 1);
     hipLaunchKernelGGL(kd_embed_loss_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, P, tw,
-                       dS, dP, part, B, rows, D, T);
+                       dS, dP, part, B, U, C, D, T);
     TNR_CHECK_LAUNCH("tnr_kd_embed_loss");
     return tnr_reduce_rows(part, waves, 1, 1, loss, 0, stream);
 }

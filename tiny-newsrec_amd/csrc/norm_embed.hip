@@ -25,8 +25,9 @@ __device__ __forceinline__ void row_stats(const float (&x)[V][4], int H, float& 
 }
 
 // tnlrv3/modeling.py:153-178 (word + pos + type0 -> LN) fused with the mask of :446-454
-template <int V>
-__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict__ tok, int64_t n_tok, int L,
+template <int V, typename TokT>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const TokT* __restrict__ tok, const int32_t* __restrict__ nidx,
+                                                       int64_t n_tok, int L,
                                                        const float* __restrict__ word, const float* __restrict__ pos,
                                                        const float* __restrict__ type0, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, bf16* __restrict__ out,
@@ -37,9 +38,10 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
     if (t >= n_tok) return;
     int64_t n = t / L;
     int i = (int)(t - n * L);
-    int64_t id = tok[n * 2 * L + i];
+    const int64_t trow = nidx ? (int64_t)nidx[n] : n;       // news index -> row of the resident token table
+    int64_t id = (int64_t)tok[trow * 2 * L + i];
     if (lane == 0) {
-        int64_t mk = tok[n * 2 * L + L + i];
+        int64_t mk = (int64_t)tok[trow * 2 * L + L + i];
         mask_add[n * 32 + i] = (1.0f - (float)mk) * -10000.0f;
         if (i == 0)
             for (int j = L; j < 32; ++j) mask_add[n * 32 + j] = -1e30f;
@@ -267,10 +269,27 @@ extern "C" int tnr_embed_ln_fwd(const int64_t* tok, int64_t n_seq, int L, int H,
     int64_t n_tok = n_seq * L;
     dim3 grid((unsigned)((n_tok + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(V) hipLaunchKernelGGL(embed_ln_kernel<V>, grid, blk, 0, st, tok, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add)
+#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int64_t>), grid, blk, 0, st, tok, (const int32_t*)nullptr, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     TNR_CHECK_LAUNCH("tnr_embed_ln_fwd");
+    return TNR_OK;
+}
+
+extern "C" int tnr_embed_ln_fwd_indexed(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
+                                        const float* word, const float* pos, const float* type0, const float* gamma,
+                                        const float* beta, float eps, void* out, float* mask_add, void* stream) {
+    TNR_CHECK_ARG(news_combined && nidx && word && pos && type0 && gamma && beta && out && mask_add,
+                  "tnr_embed_ln_fwd_indexed: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 32 && n_seq >= 1, "tnr_embed_ln_fwd_indexed: need 1<=L<=32");
+    TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_embed_ln_fwd_indexed: H must be 256/512/768/1024");
+    int64_t n_tok = n_seq * L;
+    dim3 grid((unsigned)((n_tok + 3) / 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int32_t>), grid, blk, 0, st, news_combined, nidx, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add)
+    switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+    TNR_CHECK_LAUNCH("tnr_embed_ln_fwd_indexed");
     return TNR_OK;
 }
 

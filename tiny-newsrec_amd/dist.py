@@ -1,0 +1,63 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI)
+replacing horovod (run.py:141-149, utils.py:43-60): flat parameter broadcast from rank 0, and a
+gradient AVERAGE (hvd.Average, Compression.none, fp32) done as a few large contiguous all-reduces
+(one per gradient bucket, heads first then one per trainable layer) launched as soon as backward
+has produced the bucket, so they overlap the remaining backward GEMMs; the 1/world scale is folded
+into the AMSGrad kernel.  xGMI is point-to-point, so few large messages beat many small ones."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """-> (world, rank, local_rank); env from the launcher (torch.distributed.run sets RANK/WORLD_SIZE/LOCAL_RANK)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+    return world, rank, local
+
+
+class GradSync:
+    """Bucketed all-reduce of a flat gradient buffer. ranges: [(start, end)] in completion order."""
+
+    def __init__(self, flat_g, ranges, world):
+        self.flat_g, self.ranges, self.world = flat_g, list(ranges), world
+        self.pending = []
+
+    def launch(self, bucket):
+        if self.world == 1:
+            return
+        s, e = self.ranges[bucket]
+        self.pending.append(dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    @property
+    def scale(self):
+        return 1.0 / self.world
+
+
+def broadcast_flat(tensors, src=0):
+    """hvd.broadcast_parameters (run.py:142): every flat buffer from rank 0."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce_max(x):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    return x

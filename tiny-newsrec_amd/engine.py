@@ -1,0 +1,564 @@
+"""Training-step engine: chains the libtnr_hip.so kernels into forward / backward / AMSGrad.
+
+Host-side mirror of the reference's hot loop body (run.py:178-195): Model.forward
+(model_bert.py:262-305) -> total_loss.backward() -> optimizer.step(), for one worker's batch.
+torch is used for device memory, streams and (in dist.py) the RCCL all-reduce only; every
+arithmetic op on the path is a HIP kernel behind the C ABI, and there is no fallback.
+
+Memory plan (sized for 288 GB HBM3E): parameters live in two flat fp32 buffers (trainable /
+frozen) whose slices ARE the nn.Parameters of model_bert.py, gradients and AMSGrad state are flat
+buffers of the trainable size, bf16 (and transposed bf16) weight copies are refreshed by one
+kernel after each update, activations of the trainable layers stay resident for backward.
+"""
+import math
+
+import torch
+
+import tnr_hip as T
+
+PFX = "student.news_encoder."
+BERT = PFX + "bert_model.bert."
+QPAD = 256          # news pooling query dim (200) padded to the GEMM tile
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class EngineConfig:
+    def __init__(self, n_layers=4, trainable_layers=(2, 3), hidden=768, heads=12, inter=3072, news_dim=256,
+                 news_query=200, user_query=200, num_teachers=4, user_log_length=50, npratio=4, num_words=30,
+                 user_log_mask=False, temperature=1.0, coef=0.2, vocab=30522, max_pos=512, type_vocab=2,
+                 ln_eps=1e-12):
+        self.n_layers, self.trainable_layers = n_layers, tuple(sorted(trainable_layers))
+        self.H, self.A, self.I, self.D = hidden, heads, inter, news_dim
+        self.Qn, self.Qu, self.T = news_query, user_query, num_teachers
+        self.U, self.C, self.L = user_log_length, npratio + 1, num_words
+        self.user_log_mask, self.temperature, self.coef = bool(user_log_mask), float(temperature), float(coef)
+        self.vocab, self.max_pos, self.type_vocab, self.ln_eps = vocab, max_pos, type_vocab, ln_eps
+        assert hidden == heads * 64, "attention kernel is built for head size 64"
+        assert hidden % 256 == 0 and inter % 128 == 0 and news_dim % 4 == 0 and news_query <= QPAD
+        assert 1 <= num_words <= 32, "fused attention kernel covers titles of up to 32 tokens"
+        assert all(0 <= l < n_layers for l in self.trainable_layers)
+
+
+def layer_param_order(l):
+    p = BERT + "encoder.layer.%d." % l
+    return [p + "attention.self.query.weight", p + "attention.self.key.weight", p + "attention.self.value.weight",
+            p + "attention.self.query.bias", p + "attention.self.key.bias", p + "attention.self.value.bias",
+            p + "attention.output.dense.weight", p + "attention.output.dense.bias",
+            p + "attention.output.LayerNorm.weight", p + "attention.output.LayerNorm.bias",
+            p + "intermediate.dense.weight", p + "intermediate.dense.bias",
+            p + "output.dense.weight", p + "output.dense.bias",
+            p + "output.LayerNorm.weight", p + "output.LayerNorm.bias"]
+
+
+def param_shapes(cfg):
+    """state_dict schema of model_bert.Model, in the engine's storage order."""
+    H, I, D, T_ = cfg.H, cfg.I, cfg.D, cfg.T
+    s = {}
+    for i in range(T_):
+        s["teachers.%d.attn.att_fc1.weight" % i] = (cfg.Qu, D)
+    for i in range(T_):
+        s["teachers.%d.attn.att_fc1.bias" % i] = (cfg.Qu,)
+    for i in range(T_):
+        s["teachers.%d.attn.att_fc2.weight" % i] = (1, cfg.Qu)
+    for i in range(T_):
+        s["teachers.%d.pad_doc" % i] = (1, D)
+    for i in range(T_):
+        s["teachers.%d.attn.att_fc2.bias" % i] = (1,)
+    s[BERT + "embeddings.word_embeddings.weight"] = (cfg.vocab, H)
+    s[BERT + "embeddings.position_embeddings.weight"] = (cfg.max_pos, H)
+    s[BERT + "embeddings.token_type_embeddings.weight"] = (cfg.type_vocab, H)
+    s[BERT + "embeddings.LayerNorm.weight"] = (H,)
+    s[BERT + "embeddings.LayerNorm.bias"] = (H,)
+    for l in range(cfg.n_layers):
+        for k in layer_param_order(l):
+            if k.endswith("intermediate.dense.weight"):
+                s[k] = (I, H)
+            elif k.endswith("intermediate.dense.bias"):
+                s[k] = (I,)
+            elif k.endswith(".output.dense.weight") and "attention" not in k:
+                s[k] = (H, I)
+            elif k.endswith("weight") and "LayerNorm" not in k:
+                s[k] = (H, H)
+            else:
+                s[k] = (H,)
+    s[BERT + "pooler.dense.weight"] = (H, H)
+    s[BERT + "pooler.dense.bias"] = (H,)
+    s[BERT + "rel_pos_bias.weight"] = (cfg.A, 32)
+    s[PFX + "bert_model.classifier.weight"] = (2, H)
+    s[PFX + "bert_model.classifier.bias"] = (2,)
+    # heads: order = order in which their gradients complete / are laid out by the kernels
+    s[PFX + "attn.att_fc1.weight"] = (cfg.Qn, H)
+    s[PFX + "attn.att_fc1.bias"] = (cfg.Qn,)
+    s[PFX + "attn.att_fc2.weight"] = (1, cfg.Qn)
+    s[PFX + "attn.att_fc2.bias"] = (1,)
+    s[PFX + "dense.weight"] = (D, H)
+    s[PFX + "dense.bias"] = (D,)
+    s["student.user_encoder.attn.att_fc1.weight"] = (cfg.Qu, D)
+    s["student.user_encoder.attn.att_fc1.bias"] = (cfg.Qu,)
+    s["student.user_encoder.attn.att_fc2.weight"] = (1, cfg.Qu)
+    s["student.user_encoder.pad_doc"] = (1, D)
+    s["student.user_encoder.attn.att_fc2.bias"] = (1,)
+    for i in range(T_):
+        s["transform_matrix.%d.weight" % i] = (D, D)
+    for i in range(T_):
+        s["transform_matrix.%d.bias" % i] = (D,)
+    return s
+
+
+def is_trainable(cfg, name):
+    """run.py:101-112: teachers frozen; bert_model frozen except encoder.layer[i], i in trainable_layers."""
+    if name.startswith("teachers."):
+        return False
+    if name.startswith(PFX + "bert_model."):
+        for l in cfg.trainable_layers:
+            if name.startswith(BERT + "encoder.layer.%d." % l):
+                return True
+        return False
+    return True
+
+
+class Engine:
+    def __init__(self, cfg, device="cuda:0", max_batch=32):
+        T.lib()                      # fail loudly if the HIP library is missing
+        self.cfg, self.dev = cfg, torch.device(device)
+        self.step_count = 0
+        self._n_alloc = 0
+        self._build_params()
+        self._build_shadows()
+        self.max_batch = max_batch
+        self._alloc_workspace(max_batch)
+        self.comm = None             # set by dist.attach()
+
+    # ------------------------------------------------------------------ parameters
+    def _groups(self):
+        """Storage groups: members are contiguous (no padding inside), every group starts 64-float aligned.
+        Stacks that kernels read as one array: per-teacher params, q/k/v weights and biases, the student
+        user-encoder block (= tnr_user_bwd's partial layout [w1|b1|w2|pad|b2]), transform matrices."""
+        cfg = self.cfg
+        T_ = cfg.T
+        tstack = lambda suffix: ["teachers.%d.%s" % (i, suffix) for i in range(T_)]
+        groups = []
+        if T_:
+            for suffix in ("attn.att_fc1.weight", "attn.att_fc1.bias", "attn.att_fc2.weight", "pad_doc", "attn.att_fc2.bias"):
+                groups.append((tstack(suffix), None))
+        for k in ("word_embeddings.weight", "position_embeddings.weight", "token_type_embeddings.weight",
+                  "LayerNorm.weight", "LayerNorm.bias"):
+            groups.append(([BERT + "embeddings." + k], None))
+        for l in range(cfg.n_layers):
+            n = layer_param_order(l)
+            groups.append((n[0:3], None))
+            groups.append((n[3:6], None))
+            for k in n[6:]:
+                groups.append(([k], None))
+        for k in (BERT + "pooler.dense.weight", BERT + "pooler.dense.bias", BERT + "rel_pos_bias.weight",
+                  PFX + "bert_model.classifier.weight", PFX + "bert_model.classifier.bias"):
+            groups.append(([k], None))
+        groups.append(([PFX + "attn.att_fc1.weight"], QPAD * cfg.H))     # rows Qn..QPAD stay zero
+        groups.append(([PFX + "attn.att_fc1.bias"], QPAD))
+        for k in ("attn.att_fc2.weight", "attn.att_fc2.bias", "dense.weight", "dense.bias"):
+            groups.append(([PFX + k], None))
+        ue = "student.user_encoder."
+        groups.append(([ue + "attn.att_fc1.weight", ue + "attn.att_fc1.bias", ue + "attn.att_fc2.weight", ue + "pad_doc",
+                        ue + "attn.att_fc2.bias"], None))
+        if T_:
+            groups.append((["transform_matrix.%d.weight" % i for i in range(T_)], None))
+            groups.append((["transform_matrix.%d.bias" % i for i in range(T_)], None))
+        return groups
+
+    def _build_params(self):
+        cfg = self.cfg
+        shapes = param_shapes(cfg)
+        self.shapes = shapes
+        off = {True: 0, False: 0}
+        self.slot = {}
+        seen = set()
+        for names, reserve in self._groups():
+            tr = is_trainable(cfg, names[0])
+            o = off[tr]
+            for name in names:
+                shp = shapes[name]
+                n = int(math.prod(shp))
+                self.slot[name] = (tr, o, n, shp)
+                o += n
+                seen.add(name)
+            off[tr] = _rup(max(o, off[tr] + (reserve or 0)), 64)
+        assert seen == set(shapes), set(shapes) ^ seen
+        self.n_train, self.n_frozen = max(off[True], 64), max(off[False], 64)
+        dev = self.dev
+        self.flat = {True: torch.zeros(self.n_train, device=dev), False: torch.zeros(self.n_frozen, device=dev)}
+        self.flat_g = torch.zeros(self.n_train, device=dev)
+        self.adam_m = torch.zeros(self.n_train, device=dev)
+        self.adam_v = torch.zeros(self.n_train, device=dev)
+        self.adam_vmax = torch.zeros(self.n_train, device=dev)
+        self.params, self.grads = {}, {}
+        for name in shapes:
+            tr, o, n, shp = self.slot[name]
+            self.params[name] = self.flat[tr][o:o + n].view(shp)
+            if tr:
+                self.grads[name] = self.flat_g[o:o + n].view(shp)
+
+    def p(self, name):
+        return self.params[name]
+
+    def off(self, name):
+        return self.slot[name][1]
+
+    def _view(self, first, numel, shape, grad=False):
+        tr, o, _, _ = self.slot[first]
+        buf = self.flat_g if grad else self.flat[tr]
+        return buf[o:o + numel].view(shape)
+
+    def load_state_dict(self, sd):
+        """sd: {key: array-like fp32}; every key of the reference schema must be present."""
+        missing = [k for k in self.shapes if k not in sd]
+        if missing:
+            raise KeyError("missing keys: %s" % missing[:5])
+        for k, shp in self.shapes.items():
+            v = sd[k]
+            v = v if isinstance(v, torch.Tensor) else torch.as_tensor(v)
+            if tuple(v.shape) != tuple(shp):
+                raise ValueError("%s: shape %s != %s" % (k, tuple(v.shape), shp))
+            self.params[k].copy_(v.to(self.dev, torch.float32))
+        self.refresh_shadows(all_layers=True)
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.params.items()}
+
+    # ------------------------------------------------------------------ bf16 weight copies
+    def _build_shadows(self):
+        cfg, dev, bf = self.cfg, self.dev, torch.bfloat16
+        H, I = cfg.H, cfg.I
+        lo = min(cfg.trainable_layers) if cfg.trainable_layers else cfg.n_layers
+        self.lo = lo
+        self.sh = []
+        for l in range(cfg.n_layers):
+            d = dict(qkv=torch.zeros((3 * H, H), device=dev, dtype=bf), o=torch.zeros((H, H), device=dev, dtype=bf),
+                     w1=torch.zeros((I, H), device=dev, dtype=bf), w2=torch.zeros((H, I), device=dev, dtype=bf))
+            if l >= lo:      # dgrad needs the transposed copies
+                d.update(qkvT=torch.zeros((H, 3 * H), device=dev, dtype=bf), oT=torch.zeros((H, H), device=dev, dtype=bf),
+                         w1T=torch.zeros((H, I), device=dev, dtype=bf), w2T=torch.zeros((I, H), device=dev, dtype=bf))
+            self.sh.append(d)
+        self.sh_a1 = torch.zeros((QPAD, H), device=dev, dtype=bf)
+        self.sh_a1T = torch.zeros((H, QPAD), device=dev, dtype=bf)
+        self.b_a1 = self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,))
+        self.rel = torch.zeros((cfg.A, 32, 32), device=dev)
+
+        def table(layers, with_heads):
+            rows = []
+            for l in layers:
+                d, names = self.sh[l], layer_param_order(l)
+                for i in range(3):
+                    rows.append((self.p(names[i]), H, H, d["qkv"][i * H:], H, d["qkvT"][:, i * H:] if "qkvT" in d else None, 3 * H))
+                rows.append((self.p(names[6]), H, H, d["o"], H, d.get("oT"), H))
+                rows.append((self.p(names[10]), I, H, d["w1"], H, d.get("w1T"), I))
+                rows.append((self.p(names[12]), H, I, d["w2"], I, d.get("w2T"), H))
+            if with_heads:
+                rows.append((self.p(PFX + "attn.att_fc1.weight"), cfg.Qn, H, self.sh_a1, H, self.sh_a1T, QPAD))
+            desc, start, tot = [], [0], 0
+            for src, r, c, dst, ld, dstT, ldT in rows:
+                desc.append([src.data_ptr(), r, c, dst.data_ptr(), ld, dstT.data_ptr() if dstT is not None else 0, ldT, 0])
+                tot += ((r + 31) // 32) * ((c + 31) // 32)
+                start.append(tot)
+            return (torch.tensor(desc, dtype=torch.int64, device=dev), len(desc), tot,
+                    torch.tensor(start, dtype=torch.int64, device=dev))
+
+        self.desc_all = table(range(cfg.n_layers), True)
+        self.desc_train = table(cfg.trainable_layers, True)
+
+    def refresh_shadows(self, all_layers=False):
+        d = self.desc_all if all_layers else self.desc_train
+        T.call("tnr_refresh_shadows", d[0], d[1], d[2], d[3])
+        if all_layers:
+            T.call("tnr_relpos_table", self.p(BERT + "rel_pos_bias.weight"), self.cfg.A, self.cfg.L, self.rel)
+
+    # ------------------------------------------------------------------ workspaces
+    def _alloc_workspace(self, B):
+        cfg, dev, bf = self.cfg, self.dev, torch.bfloat16
+        H, I, D, L = cfg.H, cfg.I, cfg.D, cfg.L
+        N = B * (cfg.U + cfg.C)
+        Mp = _rup(N * L, 128)
+        self.B_alloc, self.N_alloc, self.Mp = B, N, Mp
+        z = lambda *s, dt=bf: torch.zeros(s, device=dev, dtype=dt)
+        f = lambda *s: torch.zeros(s, device=dev, dtype=torch.float32)
+        self.tok = torch.zeros((N, 2 * L), device=dev, dtype=torch.int64)
+        self.mask_add = f(N, 32)
+        self.x0 = z(Mp, H)
+        n_keep = cfg.n_layers - self.lo
+        mk = lambda: dict(qkv=z(Mp, 3 * H), ctx=z(Mp, H), h1pre=z(Mp, H), st1=f(Mp, 2), h1=z(Mp, H), u=z(Mp, I),
+                          g=z(Mp, I), ypre=z(Mp, H), st2=f(Mp, 2), y=z(Mp, H))
+        self.act = [mk() for _ in range(n_keep)]          # resident activations of layers >= lo
+        self.scr = mk() if self.lo > 0 else None           # scratch for frozen layers below lo
+        self.scr_y = [z(Mp, H), z(Mp, H)] if self.lo > 0 else None
+        self.e = f(Mp, QPAD)
+        self.nv, self.alpha, self.den = f(N, H), f(N, 32), f(N)
+        Rt = N + B
+        self.Rt = Rt
+        self.S = f(Rt, D)                 # student rows: [B*U history | B*C candidate | B user]
+        self.dS = f(Rt, D)
+        T_ = max(cfg.T, 1)
+        self.X = f(T_, Rt, D)             # teacher rows, same layout
+        self.Pm = f(T_, Rt, D)
+        self.dP = f(T_, Rt, D)
+        self.ones = torch.ones(Rt, device=dev)
+        self.hidx = torch.arange(B * cfg.U, device=dev, dtype=torch.int32).view(B, cfg.U)
+        self.cidx = (B * cfg.U + torch.arange(B * cfg.C, device=dev, dtype=torch.int32)).view(B, cfg.C)
+        self.score, self.dscore = f(B, cfg.C), f(B, cfg.C)
+        self.e_u, self.alpha_u, self.den_u = f(B, cfg.U, cfg.Qu), f(B, cfg.U), f(B)
+        self.t_score = f(T_, B, cfg.C)
+        self.e_t, self.alpha_t, self.den_t = f(T_, B, cfg.U, cfg.Qu), f(T_, B, cfg.U), f(T_, B)
+        self.tw = f(B, T_)
+        self.losses = f(4)
+        self.kd_part = f(Rt)
+        self.user_part = f(B, T.query("tnr_user_bwd_part_stride", D, cfg.Qu))
+        # backward buffers
+        self.dnv = f(N, H)
+        self.dy, self.dy2 = z(Mp, H), z(Mp, H)
+        self.dpre = z(Mp, QPAD)
+        self.dw2p, self.db2p = f(N, cfg.Qn), f(N)
+        self.dypre, self.dh1, self.dh1pre, self.dctx = z(Mp, H), z(Mp, H), z(Mp, H), z(Mp, H)
+        self.du = z(Mp, I)
+        self.dqkv = z(Mp, 3 * H)
+        self.ln_part = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
+        self.cs_part = f(T.query("tnr_colsum_part_elems", Mp, max(I, 3 * H)))
+        self.splits = 8
+        self.ws = f(T.query("tnr_gemm_tn_ws_elems", max(3 * H, I), H, self.splits))
+
+    # ------------------------------------------------------------------ kernel wrappers
+    def _gemm(self, a, w, c, M, bias=None, res=None, aux=None, flags=0):
+        N, K = w.shape
+        T.call("tnr_gemm_nt", a, a.stride(0), w, w.stride(0), c, c.stride(0), M, N, K, bias, res,
+               res.stride(0) if res is not None else 0, aux, aux.stride(0) if aux is not None else 0, flags)
+
+    def _wgrad(self, dy, x, dw, M):
+        N, K = dw.shape
+        T.call("tnr_gemm_tn_wgrad", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws, self.splits, 0)
+
+    def _colsum(self, x, out, M, dtype=T.BF16):
+        T.call("tnr_colsum", x, x.stride(0), dtype, M, x.shape[1], out, self.cs_part, 0)
+
+    def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, beta=0.0):
+        T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, 1.0, beta)
+
+    # ------------------------------------------------------------------ forward
+    def encode(self, tok, n_seq, nidx=None):
+        """NewsEncoder.forward model_bert.py:119-137 -> news vectors S[:n_seq] (fp32).
+        tok (n_seq, 2L) int64 on device, or (nidx given) tok = resident news_combined (n+1, 2L) int32 and
+        nidx (n_seq,) int32 news indices."""
+        cfg = self.cfg
+        H, L = cfg.H, cfg.L
+        M = n_seq * L
+        g = self.p
+        emb = (g(BERT + "embeddings.word_embeddings.weight"), g(BERT + "embeddings.position_embeddings.weight"),
+               g(BERT + "embeddings.token_type_embeddings.weight"), g(BERT + "embeddings.LayerNorm.weight"),
+               g(BERT + "embeddings.LayerNorm.bias"), cfg.ln_eps, self.x0, self.mask_add)
+        if nidx is None:
+            T.call("tnr_embed_ln_fwd", tok, n_seq, L, H, *emb)
+        else:
+            T.call("tnr_embed_ln_fwd_indexed", tok, nidx, n_seq, L, H, *emb)
+        x = self.x0
+        self.x_in = {}
+        for l in range(cfg.n_layers):
+            names = layer_param_order(l)
+            sh = self.sh[l]
+            kept = l >= self.lo
+            a = self.act[l - self.lo] if kept else self.scr
+            y = a["y"] if kept else self.scr_y[l & 1]
+            bqkv = self._view(names[3], 3 * H, (3 * H,))
+            self.x_in[l] = x
+            self._gemm(x, sh["qkv"], a["qkv"], M, bias=bqkv, flags=T.EPI_BIAS)
+            T.call("tnr_attn_l32_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A)
+            self._gemm(a["ctx"], sh["o"], a["h1pre"], M, bias=g(names[7]), res=x, flags=T.EPI_BIAS | T.EPI_RES)
+            T.call("tnr_ln_fwd", a["h1pre"], g(names[8]), g(names[9]), cfg.ln_eps, a["h1"], a["st1"], M, H)
+            fl = T.EPI_BIAS | T.EPI_GELU | (T.EPI_AUXOUT if kept else 0)
+            self._gemm(a["h1"], sh["w1"], a["g"], M, bias=g(names[11]), aux=a["u"] if kept else None, flags=fl)
+            self._gemm(a["g"], sh["w2"], a["ypre"], M, bias=g(names[13]), res=a["h1"], flags=T.EPI_BIAS | T.EPI_RES)
+            T.call("tnr_ln_fwd", a["ypre"], g(names[14]), g(names[15]), cfg.ln_eps, y, a["st2"], M, H)
+            x = y
+        self.y_last = x
+        # AttentionPooling (no mask) + dense  model_bert.py:133-136
+        self._gemm(x, self.sh_a1, self.e, M, bias=self.b_a1, flags=T.EPI_BIAS | T.EPI_TANH | T.EPI_OUTF32)
+        T.call("tnr_attpool_fwd", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
+               self.nv, self.alpha, self.den, n_seq, L, H)
+        wd = g(PFX + "dense.weight")
+        self._sgemm(self.nv, H, 1, 0, wd, H, 1, 0, self.S, cfg.D, 0, g(PFX + "dense.bias"), 0, n_seq, cfg.D, H)
+        return self.S[:n_seq]
+
+    def _prepare(self, B):
+        # buffers are sized for the exact batch: row strides of the stacked (T, Rt, D) arrays and the
+        # zero rows the wgrad kernels rely on (rows [M, roundup(M,64))) both depend on it.  Only the last,
+        # short batch of an epoch (streaming.py:76, no drop_remainder) ever changes B.
+        if B != self.B_alloc:
+            self._alloc_workspace(B)
+
+    def forward_indexed(self, news_combined, hist_idx, history_mask, cand_idx, label, teacher_tables):
+        """The same step fed the way the resident-table loader feeds it: news_combined (n+1, 2L) int32 and
+        teacher_tables (T, n+1, D) fp32 stay in HBM; per step only hist_idx (B,U), cand_idx (B,C) int32 news
+        indices, the mask and the labels arrive (dataloader.py:129-149 at index level)."""
+        return self.forward(None, history_mask, None, label, teacher_tables=teacher_tables, t_hidx=hist_idx,
+                            t_cidx=cand_idx, news_combined=news_combined)
+
+    def forward(self, history, history_mask, candidate, label, teacher_hist=None, teacher_cand=None,
+                teacher_tables=None, t_hidx=None, t_cidx=None, news_combined=None):
+        """Model.forward model_bert.py:262-305.  Teacher embeddings either as the reference's lists of
+        (B,U,D)/(B,C,D) tensors, or as resident tables (T,R,D) + int32 row ids (B,U)/(B,C).
+        Returns the device tensor [distill, target, emb, -] and student_score (B,C)."""
+        cfg = self.cfg
+        B = history_mask.shape[0]
+        U, C, L, D, T_ = cfg.U, cfg.C, cfg.L, cfg.D, cfg.T
+        self._prepare(B)
+        N = B * (U + C)
+        Rt = N + B
+        self.cur = (B, N, Rt)
+        self.mask = history_mask.to(torch.float32).contiguous()
+        self.label = label.to(torch.int64).contiguous()
+        if news_combined is not None:
+            self.nidx = torch.cat([t_hidx.reshape(-1), t_cidx.reshape(-1)]).to(torch.int32)
+            self.encode(news_combined, N, nidx=self.nidx)
+        else:
+            assert history.shape[1:] == (U, 2 * L) and candidate.shape[1:] == (C, 2 * L)
+            tok = self.tok[:N]
+            tok[:B * U].copy_(history.reshape(B * U, 2 * L))
+            tok[B * U:].copy_(candidate.reshape(B * C, 2 * L))
+            self.encode(tok, N)
+        S = self.S[:Rt]
+        hidx, cidx = self._idx(B)
+        ue = "student.user_encoder."
+        g = self.p
+        T.call("tnr_user_score_fwd", S, Rt, hidx, cidx, self.mask, g(ue + "pad_doc"), g(ue + "attn.att_fc1.weight"),
+               g(ue + "attn.att_fc1.bias"), g(ue + "attn.att_fc2.weight"), g(ue + "attn.att_fc2.bias"),
+               int(cfg.user_log_mask), S[N:], B * D, self.score, self.e_u, self.alpha_u, self.den_u, 1, B, U, C, D, cfg.Qu)
+        if T_ > 0:
+            X = self.X[:, :Rt]
+            if teacher_tables is not None:
+                idx = self.nidx if news_combined is not None else torch.cat([t_hidx.reshape(-1), t_cidx.reshape(-1)]).to(torch.int32)
+                T.call("tnr_gather_rows", teacher_tables, teacher_tables.shape[1], idx, N, D, T_, self.X, self.X.shape[1], 0)
+            else:
+                for i in range(T_):
+                    self.X[i, :B * U].copy_(teacher_hist[i].reshape(B * U, D))
+                    self.X[i, B * U:N].copy_(teacher_cand[i].reshape(B * C, D))
+            w1 = self._view("teachers.0.attn.att_fc1.weight", T_ * cfg.Qu * D, (T_, cfg.Qu, D))
+            T.call("tnr_user_score_fwd", self.X, self.X.shape[1], hidx, cidx, self.mask,
+                   self._view("teachers.0.pad_doc", T_ * D, (T_, D)), w1,
+                   self._view("teachers.0.attn.att_fc1.bias", T_ * cfg.Qu, (T_, cfg.Qu)),
+                   self._view("teachers.0.attn.att_fc2.weight", T_ * cfg.Qu, (T_, cfg.Qu)),
+                   self._view("teachers.0.attn.att_fc2.bias", T_, (T_,)), int(cfg.user_log_mask),
+                   self.X[0, N:], self.X.stride(0), self.t_score, self.e_t, self.alpha_t, self.den_t, T_, B, U, C, D, cfg.Qu)
+        T.call("tnr_kd_score_loss", self.score, self.t_score if T_ else None, self.label, cfg.temperature, cfg.coef,
+               self.tw if T_ else None, self.dscore, self.losses, B, C, T_)
+        if T_ > 0:
+            Wt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
+            bt = self._view("transform_matrix.0.bias", T_ * D, (T_, D))
+            self._sgemm(self.X, D, 1, self.X.stride(0), Wt, D, 1, D * D, self.Pm, D, self.Pm.stride(0), bt, D, Rt, D, D,
+                        batch=T_)
+            T.call("tnr_kd_embed_loss", S, self.Pm, self.tw, self.losses[2:], self.dS, self.dP, self.kd_part, B, U, C, D, T_)
+        else:
+            self.dS[:Rt].zero_()
+            self.losses[2:3].zero_()
+        return self.losses, self.score[:B]
+
+    def _idx(self, B):
+        assert B == self.B_alloc
+        return self.hidx, self.cidx
+
+    def total_loss(self):
+        """distill + coef*target + emb  (model_bert.py:305) as a device scalar."""
+        l = self.losses
+        return l[0] + self.cfg.coef * l[1] + l[2]
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, after_bucket=None):
+        """d total_loss / d trainable parameters -> self.flat_g.  after_bucket(i) is called when gradient
+        bucket i (0 = heads, then one per layer from the top) is complete (dist.py overlaps its all-reduce)."""
+        cfg = self.cfg
+        B, N, Rt = self.cur
+        U, C, L, D, H, I, T_ = cfg.U, cfg.C, cfg.L, cfg.D, cfg.H, cfg.I, cfg.T
+        M = N * L
+        g, gr = self.p, self.grads
+        S, dS = self.S[:Rt], self.dS
+        hidx, cidx = self._idx(B)
+        if T_ > 0:
+            # dW_i = dP_i^T X_i ; db_i = colsum(dP_i)   (transform_matrix, model_bert.py:278,283)
+            dWt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D), grad=True)
+            dbt = self._view("transform_matrix.0.bias", T_ * D, (T_, D), grad=True)
+            self._sgemm(self.dP, 1, D, Rt * D, self.X, 1, D, self.X.stride(0), dWt, D, D * D, None, 0, D, D, Rt, batch=T_)
+            self._sgemm(self.dP, 1, D, Rt * D, self.ones, 0, 1, 0, dbt, 1, D, None, 0, D, 1, Rt, batch=T_)
+        # scorer + user encoder
+        T.call("tnr_score_bwd", S, cidx, S[N:], self.dscore, dS, dS[N:], B, C, D)
+        ue = "student.user_encoder."
+        T.call("tnr_user_bwd", S, hidx, self.mask, g(ue + "pad_doc"), g(ue + "attn.att_fc1.weight"),
+               g(ue + "attn.att_fc2.weight"), int(cfg.user_log_mask), dS[N:], self.e_u, self.alpha_u, self.den_u, dS,
+               self.user_part, B, U, D, cfg.Qu)
+        ps = self.user_part.shape[1]
+        T.call("tnr_reduce_rows", self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.weight", ps, (ps,), grad=True), 0)
+        # dense + pooling of the news encoder
+        dvec = dS[:N]
+        wd = g(PFX + "dense.weight")
+        self._sgemm(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N)
+        self._sgemm(dvec, 1, D, 0, self.ones, 0, 1, 0, gr[PFX + "dense.bias"], 1, 0, None, 0, D, 1, N)
+        self._sgemm(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D)
+        y = self.y_last
+        T.call("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
+               self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, N, L, H)
+        T.call("tnr_reduce_rows", self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], 0)
+        T.call("tnr_reduce_rows", self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], 0)
+        self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M)
+        self._colsum(self.dpre, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), M)
+        if after_bucket:
+            after_bucket(0)
+        if not cfg.trainable_layers:
+            return
+        self._gemm(self.dpre, self.sh_a1T, self.dy, M, res=self.dy2, flags=T.EPI_RES)
+        dy = self.dy
+        bucket = 1
+        for l in range(cfg.n_layers - 1, self.lo - 1, -1):
+            names, sh, a = layer_param_order(l), self.sh[l], self.act[l - self.lo]
+            tr = l in cfg.trainable_layers
+            x_in = self.x_in[l]
+            T.call("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, gr[names[14]] if tr else None,
+                   gr[names[15]] if tr else None, self.ln_part, M, H)
+            if tr:
+                self._wgrad(self.dypre, a["g"], gr[names[12]], M)
+                self._colsum(self.dypre, gr[names[13]], M)
+            self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU)
+            if tr:
+                self._wgrad(self.du, a["h1"], gr[names[10]], M)
+                self._colsum(self.du, gr[names[11]], M)
+            self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
+            T.call("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, gr[names[8]] if tr else None,
+                   gr[names[9]] if tr else None, self.ln_part, M, H)
+            if tr:
+                self._wgrad(self.dh1pre, a["ctx"], gr[names[6]], M)
+                self._colsum(self.dh1pre, gr[names[7]], M)
+            self._gemm(self.dh1pre, sh["oT"], self.dctx, M)
+            T.call("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv, N, L, cfg.A)
+            if tr:
+                self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M)
+                self._colsum(self.dqkv, self._view(names[3], 3 * H, (3 * H,), grad=True), M)
+            if l > self.lo:
+                nxt = self.dy2 if dy is self.dy else self.dy
+                self._gemm(self.dqkv, sh["qkvT"], nxt, M, res=self.dh1pre, flags=T.EPI_RES)
+                dy = nxt
+            if tr and after_bucket:
+                after_bucket(bucket)
+                bucket += 1
+
+    def bucket_ranges(self):
+        """Contiguous [start, end) slices of flat_g in the order their gradients complete."""
+        out = [(self.off(PFX + "attn.att_fc1.weight"), self.n_train)]
+        for l in sorted(self.cfg.trainable_layers, reverse=True):
+            names = layer_param_order(l)
+            s = self.off(names[0])
+            e = self.off(names[-1]) + self.slot[names[-1]][2]
+            out.append((s, _rup(e, 64)))
+        return out
+
+    # ------------------------------------------------------------------ optimiser
+    def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """torch.optim.Adam(amsgrad=True).step() (run.py:134,195) + refresh of the bf16 weight copies."""
+        self.step_count += 1
+        T.call("tnr_amsgrad_step", self.flat[True], self.flat_g, self.adam_m, self.adam_v, self.adam_vmax, self.n_train,
+               self.step_count, lr, beta1, beta2, eps, grad_scale)
+        self.refresh_shadows(all_layers=False)

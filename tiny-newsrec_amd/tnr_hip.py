@@ -19,6 +19,7 @@ _SIG = {
     "tnr_version": [],
     "tnr_relpos_table": [_P, _I, _I, _P, _P],
     "tnr_embed_ln_fwd": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "tnr_embed_ln_fwd_indexed": [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "tnr_gemm_nt": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P, _L, _I, _P],
     "tnr_gemm_tn_wgrad": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _P],
     "tnr_gemm_tn_ws_elems": [_L, _L, _I],
@@ -33,12 +34,12 @@ _SIG = {
     "tnr_attpool_bwd": [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P],
     "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _P],
     "tnr_gather_rows": [_P, _L, _P, _L, _I, _I, _P, _L, _L, _P],
-    "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tnr_user_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tnr_user_bwd_part_stride": [_I, _I],
     "tnr_score_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "tnr_kd_score_loss": [_P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _P],
-    "tnr_kd_embed_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "tnr_kd_embed_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "tnr_reduce_rows": [_P, _L, _L, _L, _P, _I, _P],
     "tnr_amsgrad_step": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "tnr_refresh_shadows": [_P, _I, _L, _P, _P],
@@ -84,11 +85,31 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# name -> list of (start_event, end_event, work) filled while a name is in TIMED (bench.py's roofline leg):
+# events are recorded on torch's current stream, which is the stream the kernel is launched on.
+TIMED = {}
+
+
+def _work(name, conv):
+    if name == "tnr_gemm_nt":
+        return 2.0 * conv[6] * conv[7] * conv[8]
+    if name == "tnr_gemm_tn_wgrad":
+        return 2.0 * conv[6] * conv[7] * conv[8]
+    return 0.0
+
+
 def call(name, *args):
     """Invoke an int-status entry point on torch's current stream (appended automatically)."""
     L = lib()
     conv = [_ptr(a) if (isinstance(a, torch.Tensor) or a is None) else a for a in args]
+    rec = TIMED.get(name)
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = getattr(L, name)(*conv, stream())
+    if rec is not None:
+        e1.record()
+        rec.append((e0, e1, _work(name, conv)))
     if rc != 0:
         raise TnrError("%s failed (%d): %s" % (name, rc, L.tnr_last_error().decode()))
 
