@@ -9,6 +9,8 @@
 // address and again on the read address (cdna_hip_programming.md section 5.4 rule 21).  Two LDS buffers,
 // next tile's loads issued before the current tile's MFMAs, one barrier per K tile; 64 KB LDS per
 // workgroup -> 2 workgroups per CU overlap each other's barrier stalls.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -34,6 +36,69 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
+// Tile order inside the (XCD-contiguous) id space: groups of GM row-tiles x all column tiles, row-tile
+// fastest, so the 32 workgroups an XCD runs at once form a GM x (32/GM) patch: each A row-tile is shared by
+// 32/GM of them and each B column slice by GM (measured before: bn-fastest order, 71% L2 hit rate, every
+// workgroup streaming its own B slice from beyond L2).
+__device__ __forceinline__ void tile_coords(int wg, int nbm, int nbn, int GM, int& bm, int& bn) {
+    int per = GM * nbn;
+    int grp = wg / per;
+    int first = grp * GM;
+    int gsz = nbm - first < GM ? nbm - first : GM;
+    int local = wg - grp * per;
+    bm = first + local % gsz;
+    bn = local / gsz;
+}
+
+// epilogue shared by the NT kernels: lane holds C[m_base + 16 i][n_base + 16 j + r], r = 0..3
+__device__ __forceinline__ void nt_epilogue(const NTArgs& g, f32x4 (&acc)[4][4], int m_base, int n_base) {
+    const int flags = g.flags;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n_base + j * 16;
+        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (flags & TNR_EPI_BIAS) bv = *(const f32x4*)(g.bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + i * 16;
+            if (m >= g.M) continue;
+            f32x4 v = acc[i][j] + bv;
+            if (flags & TNR_EPI_AUXOUT) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+                *(bf16x4*)(g.aux + (int64_t)m * g.ldaux + n) = o;
+            }
+            if (flags & TNR_EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (flags & TNR_EPI_TANH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            }
+            if (flags & TNR_EPI_MULDGELU) {
+                bf16x4 u = *(const bf16x4*)(g.aux + (int64_t)m * g.ldaux + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+            }
+            if (flags & TNR_EPI_RES) {
+                bf16x4 rr = *(const bf16x4*)(g.res + (int64_t)m * g.ldres + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (flags & TNR_EPI_OUTF32) {
+                *(f32x4*)((float*)g.C + (int64_t)m * g.ldc + n) = v;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+                *(bf16x4*)((bf16*)g.C + (int64_t)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -41,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs g) {
     const int nbn = g.N >> 7;
     const int nbm = (g.M + 127) >> 7;
     const int wg = xcd_remap(blockIdx.x, nbm * nbn);
-    const int bm = wg / nbn, bn = wg - bm * nbn;
+    int bm, bn;
+    tile_coords(wg, nbm, nbn, 8, bm, bn);
 
     // ---- staging: 4 A pieces + 4 B pieces of 1 KiB (8 rows x 128 B) per wave and K tile
     const bf16* asrc[4];
@@ -102,54 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: 4 consecutive n per lane and tile
-    const int flags = g.flags;
-    const int m_base = bm * 128 + wm * 64 + (lane & 15);
-    const int n_base = bn * 128 + wn * 64 + (lane >> 4) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n_base + j * 16;
-        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (flags & TNR_EPI_BIAS) bv = *(const f32x4*)(g.bias + n);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m_base + i * 16;
-            if (m >= g.M) continue;
-            f32x4 v = acc[i][j] + bv;
-            if (flags & TNR_EPI_AUXOUT) {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-                *(bf16x4*)(g.aux + (int64_t)m * g.ldaux + n) = o;
-            }
-            if (flags & TNR_EPI_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if (flags & TNR_EPI_TANH) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-            }
-            if (flags & TNR_EPI_MULDGELU) {
-                bf16x4 u = *(const bf16x4*)(g.aux + (int64_t)m * g.ldaux + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
-            }
-            if (flags & TNR_EPI_RES) {
-                bf16x4 rr = *(const bf16x4*)(g.res + (int64_t)m * g.ldres + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
-            if (flags & TNR_EPI_OUTF32) {
-                *(f32x4*)((float*)g.C + (int64_t)m * g.ldc + n) = v;
-            } else {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-                *(bf16x4*)((bf16*)g.C + (int64_t)m * g.ldc + n) = o;
-            }
-        }
-    }
+    nt_epilogue(g, acc, bm * 128 + wm * 64 + (lane & 15), bn * 128 + wn * 64 + (lane >> 4) * 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -163,6 +182,7 @@ struct TNArgs {
     int Mt;                    // number of 64-row m tiles (Mpad / 64)
     int N, K;
     int tiles_per_split;
+    int splits;
 };
 
 __device__ __forceinline__ int tn_swz(int row) { return (((row & 3) | (((row >> 3) & 1) << 2)) << 1); }
@@ -172,8 +192,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wn = w >> 1, wk = w & 1;          // wave tile: 64 n x 64 k
     const int nbk = g.K >> 7;
-    const int bn = blockIdx.x / nbk, bk = blockIdx.x - bn * nbk;
-    const int z = blockIdx.y;
+    const int ntile = (g.N >> 7) * nbk;
+    const int wg = xcd_remap(blockIdx.x, ntile * g.splits);   // same split (same rows of dY / X) on one XCD
+    const int z = wg / ntile, tile = wg - z * ntile;
+    const int bn = tile / nbk, bk = tile - bn * nbk;
     const int mt0 = z * g.tiles_per_split;
     int mt1 = mt0 + g.tiles_per_split;
     if (mt1 > g.Mt) mt1 = g.Mt;
@@ -263,6 +285,371 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs g) {
     }
 }
 
+
+// ================================================================================================
+// v2: 256x128 output tile, 8 waves (2 per SIMD, each 64x64 as above), 3-stage LDS ring of 48 KB stages
+// ([sub-tile 0 | sub-tile 1 | other operand], 16 KB each).  Loads of K tile t+2 are issued while tile t
+// is computed and stay in flight across the single barrier per K tile (counted s_waitcnt vmcnt, raw
+// s_barrier).  Arithmetic intensity 85 FLOP per staged byte instead of 64: the 128x128 kernel above is
+// bound by the ~70 GB/s one CU can pull from L2 (MI355X_MICROARCH.md, indexed-rows table).
+constexpr int STAGE2 = 3 * TILE_BYTES;
+constexpr int RING2 = 3 * STAGE2;
+
+#define TNR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int PROBE>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int nbn = g.N >> 7;
+    const int nbm = (g.M + 255) >> 8;
+    const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+    int bm, bn;
+    tile_coords(wg, nbm, nbn, 4, bm, bn);
+
+    // 48 pieces of 1 KiB per stage, 6 per wave: piece p -> sub-tile p>>4 (0,1 = A rows 0-127 / 128-255, 2 = B)
+    const bf16* src[6];
+    int dst[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        int p = w * 6 + q, sub = p >> 4, pp = p & 15;
+        int row = pp * 8 + (lane >> 3);
+        int chunk = (lane & 7) ^ (row & 7);
+        if (sub < 2) {
+            int gm = bm * 256 + sub * 128 + row;
+            gm = gm < g.M ? gm : g.M - 1;
+            src[q] = g.A + (int64_t)gm * g.lda + chunk * 8;
+        } else {
+            src[q] = g.B + (int64_t)(bn * 128 + row) * g.ldb + chunk * 8;
+        }
+        dst[q] = sub * TILE_BYTES + pp * 1024;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE2;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) glds16(src[q] + kt * 64, base + dst[q]);
+    };
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K >> 6;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    int cur = 0, nxt = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) TNR_WAIT_VMCNT(6); else TNR_WAIT_VMCNT(0);     // tile kt landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();                                    // ... and everybody else's; tile kt-1 fully read
+        if (kt + 2 < nk) stage(nxt, kt + 2);
+        const char* sa = smem + cur * STAGE2 + (wm >> 1) * TILE_BYTES + ((wm & 1) * 64) * 128;
+        const char* sb = smem + cur * STAGE2 + 2 * TILE_BYTES + (wn * 64) * 128;
+#pragma unroll
+        for (int s = 0; s < (PROBE == 1 ? 0 : 2); ++s) {      // PROBE 1: load pipeline only (timing experiment)
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt = nxt == 2 ? 0 : nxt + 1;
+    }
+    nt_epilogue(g, acc, bm * 256 + wm * 64 + (lane & 15), bn * 128 + wn * 64 + (lane >> 4) * 4);
+}
+
+// wgrad v2: output tile 256 (n) x 128 (k); stage = [dY cols 0-127 | dY cols 128-255 | X], each [64 m][256 B]
+__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wn = w >> 1, wk = w & 1;          // wave tile: 64 n x 64 k
+    const int nbk = g.K >> 7;
+    const int ntile = (g.N >> 8) * nbk;
+    const int wg = xcd_remap(blockIdx.x, ntile * g.splits);
+    const int z = wg / ntile, tile = wg - z * ntile;
+    const int bn = tile / nbk, bk = tile - bn * nbk;
+    const int mt0 = z * g.tiles_per_split;
+    int mt1 = mt0 + g.tiles_per_split;
+    if (mt1 > g.Mt) mt1 = g.Mt;
+    const int nt = mt1 - mt0;
+
+    const bf16* src[6];
+    int64_t ldsrc[6];
+    int dst[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        int p = w * 6 + q, sub = p >> 4, pp = p & 15;
+        int row = pp * 4 + (lane >> 4);
+        int chunk = (lane & 15) ^ tn_swz(row);
+        if (sub < 2) {
+            src[q] = g.dY + (int64_t)(mt0 * 64 + row) * g.lddy + bn * 256 + sub * 128 + chunk * 8;
+            ldsrc[q] = 64 * g.lddy;
+        } else {
+            src[q] = g.X + (int64_t)(mt0 * 64 + row) * g.ldx + bk * 128 + chunk * 8;
+            ldsrc[q] = 64 * g.ldx;
+        }
+        dst[q] = sub * TILE_BYTES + pp * 1024;
+    }
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * STAGE2;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) glds16(src[q] + (int64_t)t * ldsrc[q], base + dst[q]);
+    };
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    int roff[2][2], rswz[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = 32 * s + 8 * g16 + q4 + 4 * h;
+            roff[s][h] = row * 256 + (p4 & 1) * 8;
+            rswz[s][h] = tn_swz(row);
+        }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nt > 0) {
+        stage(0, 0);
+        if (nt > 1) stage(1, 1);
+        int cur = 0, nxt = 2;
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) TNR_WAIT_VMCNT(6); else TNR_WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            if (t + 2 < nt) stage(nxt, t + 2);
+            const char* sy = smem + cur * STAGE2 + (wn >> 1) * TILE_BYTES;
+            const char* sx = smem + cur * STAGE2 + 2 * TILE_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 yf[4], xf[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    int cy = 2 * ((wn & 1) * 4 + tt) + (p4 >> 1);
+                    int cx = 2 * (wk * 4 + tt) + (p4 >> 1);
+                    bf16x4 y0 = ds_read_tr16(sy + roff[s][0] + ((cy ^ rswz[s][0]) << 4));
+                    bf16x4 y1 = ds_read_tr16(sy + roff[s][1] + ((cy ^ rswz[s][1]) << 4));
+                    bf16x4 x0 = ds_read_tr16(sx + roff[s][0] + ((cx ^ rswz[s][0]) << 4));
+                    bf16x4 x1 = ds_read_tr16(sx + roff[s][1] + ((cx ^ rswz[s][1]) << 4));
+                    yf[tt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    xf[tt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], yf[i], acc[i][j], 0, 0, 0);
+            }
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt = nxt == 2 ? 0 : nxt + 1;
+        }
+    }
+    float* slab = g.ws + (int64_t)z * g.N * g.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int n = bn * 256 + wn * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k = bk * 128 + wk * 64 + j * 16 + (lane >> 4) * 4;
+            *(f32x4*)(slab + (int64_t)n * g.K + k) = acc[i][j];
+        }
+    }
+}
+
+// ================================================================================================
+// v3: 256x256 output tile, 8 waves (2 x 4, each 128 x 64), two 64 KB LDS stages
+// ([A rows 0-127 | A rows 128-255 | B rows 0-127 | B rows 128-255], 16 KB each).  128 FLOP per staged byte:
+// measured on MI355X the v2 load pipeline alone (no MFMA) took 80% of the kernel time, i.e. these GEMMs are
+// bound by the ~10-12 TB/s the CUs can stream from L2 into LDS, so the tile has to grow, not the schedule.
+constexpr int STAGE3 = 4 * TILE_BYTES;
+constexpr int RING3 = 2 * STAGE3;
+
+template <int PROBE>
+__global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int nbn = g.N >> 8;
+    const int nbm = (g.M + 255) >> 8;
+    const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+    int bm, bn;
+    tile_coords(wg, nbm, nbn, 8, bm, bn);
+
+    const bf16* src[8];
+    int dst[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int p = w * 8 + q, sub = p >> 4, pp = p & 15;
+        int row = pp * 8 + (lane >> 3);
+        int chunk = (lane & 7) ^ (row & 7);
+        if (sub < 2) {
+            int gm = bm * 256 + sub * 128 + row;
+            gm = gm < g.M ? gm : g.M - 1;
+            src[q] = g.A + (int64_t)gm * g.lda + chunk * 8;
+        } else {
+            src[q] = g.B + (int64_t)(bn * 256 + (sub - 2) * 128 + row) * g.ldb + chunk * 8;
+        }
+        dst[q] = sub * TILE_BYTES + pp * 1024;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE3;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) glds16(src[q] + kt * 64, base + dst[q]);
+    };
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K >> 6;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        TNR_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();            // tile kt landed everywhere; tile kt-1 fully consumed
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sa = smem + cur * STAGE3 + wm * TILE_BYTES;
+        const char* sb = smem + cur * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
+#pragma unroll
+        for (int s = 0; s < (PROBE == 1 ? 0 : 2); ++s) {
+            bf16x8 af[8], bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue in two halves of 64 rows (reuses the shared 4x4 routine)
+    const int n_base = bn * 256 + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        f32x4 (&a4)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[hh * 4]);
+        nt_epilogue(g, a4, bm * 256 + wm * 128 + hh * 64 + (lane & 15), n_base);
+    }
+}
+
+// wgrad v3: output tile 256 (n) x 256 (k); stage = [dY cols 0-127 | dY cols 128-255 | X cols 0-127 | X cols 128-255]
+template <int PROBE>
+__global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wn = w >> 2, wk = w & 3;          // wave tile: 128 n x 64 k
+    const int nbk = g.K >> 8;
+    const int ntile = (g.N >> 8) * nbk;
+    const int wg = xcd_remap(blockIdx.x, ntile * g.splits);
+    const int z = wg / ntile, tile = wg - z * ntile;
+    const int bn = tile / nbk, bk = tile - bn * nbk;
+    const int mt0 = z * g.tiles_per_split;
+    int mt1 = mt0 + g.tiles_per_split;
+    if (mt1 > g.Mt) mt1 = g.Mt;
+    const int nt = mt1 - mt0;
+
+    const bf16* src[8];
+    int64_t ldsrc[8];
+    int dst[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int p = w * 8 + q, sub = p >> 4, pp = p & 15;
+        int row = pp * 4 + (lane >> 4);
+        int chunk = (lane & 15) ^ tn_swz(row);
+        if (sub < 2) {
+            src[q] = g.dY + (int64_t)(mt0 * 64 + row) * g.lddy + bn * 256 + sub * 128 + chunk * 8;
+            ldsrc[q] = 64 * g.lddy;
+        } else {
+            src[q] = g.X + (int64_t)(mt0 * 64 + row) * g.ldx + bk * 256 + (sub - 2) * 128 + chunk * 8;
+            ldsrc[q] = 64 * g.ldx;
+        }
+        dst[q] = sub * TILE_BYTES + pp * 1024;
+    }
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * STAGE3;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) glds16(src[q] + (int64_t)t * ldsrc[q], base + dst[q]);
+    };
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    int roff[2][2], rswz[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = 32 * s + 8 * g16 + q4 + 4 * h;
+            roff[s][h] = row * 256 + (p4 & 1) * 8;
+            rswz[s][h] = tn_swz(row);
+        }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nt > 0) {
+        stage(0, 0);
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            TNR_WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < nt) stage(cur ^ 1, t + 1);
+            const char* sy = smem + cur * STAGE3 + wn * TILE_BYTES;
+            const char* sx = smem + cur * STAGE3 + (2 + (wk >> 1)) * TILE_BYTES;
+#pragma unroll
+            for (int s = 0; s < (PROBE == 1 ? 0 : 2); ++s) {
+                bf16x8 yf[8], xf[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    int cx = 2 * ((wk & 1) * 4 + tt) + (p4 >> 1);
+                    bf16x4 x0 = ds_read_tr16(sx + roff[s][0] + ((cx ^ rswz[s][0]) << 4));
+                    bf16x4 x1 = ds_read_tr16(sx + roff[s][1] + ((cx ^ rswz[s][1]) << 4));
+                    xf[tt] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) {
+                    int cy = 2 * tt + (p4 >> 1);
+                    bf16x4 y0 = ds_read_tr16(sy + roff[s][0] + ((cy ^ rswz[s][0]) << 4));
+                    bf16x4 y1 = ds_read_tr16(sy + roff[s][1] + ((cy ^ rswz[s][1]) << 4));
+                    yf[tt] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], yf[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    float* slab = g.ws + (int64_t)z * g.N * g.K;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int n = bn * 256 + wn * 128 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k = bk * 256 + wk * 64 + j * 16 + (lane >> 4) * 4;
+            *(f32x4*)(slab + (int64_t)n * g.K + k) = acc[i][j];
+        }
+    }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t NK, int K, float* out,
                                    int64_t ldo, int accumulate) {
     int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -294,8 +681,31 @@ extern "C" int tnr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
     TNR_CHECK_ARG(M < (1 << 24), "tnr_gemm_nt: M too large");
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
              (const bf16*)res, ldres, (bf16*)aux, ldaux, flags};
-    int nwg = (int)(((M + 127) / 128) * (N / 128));
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(nwg), dim3(256), 2 * BUF_BYTES, (hipStream_t)stream, g);
+    static const char* ver_s = getenv("TNR_GEMM_VER");
+    static const int ver = ver_s ? atoi(ver_s) : 3;
+    static const char* probe_s = getenv("TNR_GEMM_PROBE");
+    static const bool probe = probe_s && probe_s[0] == '1';
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (ver == 1 || M <= 128) {
+        int nwg = (int)(((M + 127) / 128) * (N / 128));
+        hipLaunchKernelGGL(gemm_nt_kernel, dim3(nwg), dim3(256), 2 * BUF_BYTES, st, g);
+    } else if (ver == 2 || (N % 256) != 0) {
+        int nwg = (int)(((M + 255) / 256) * (N / 128));
+        if (probe) hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), RING2, st, g);
+        else hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), RING2, st, g);
+    } else {
+        int nwg = (int)(((M + 255) / 256) * (N / 256));
+        if (probe) hipLaunchKernelGGL(gemm_nt256x256_kernel<1>, dim3(nwg), dim3(512), RING3, st, g);
+        else hipLaunchKernelGGL(gemm_nt256x256_kernel<0>, dim3(nwg), dim3(512), RING3, st, g);
+    }
     TNR_CHECK_LAUNCH("tnr_gemm_nt");
     return TNR_OK;
 }
@@ -317,9 +727,25 @@ extern "C" int tnr_gemm_tn_wgrad(const void* dY, int64_t lddy, const void* X, in
     if (splits > Mt) splits = Mt;
     int tps = (Mt + splits - 1) / splits;
     splits = (Mt + tps - 1) / tps;
-    TNArgs g{(const bf16*)dY, lddy, (const bf16*)X, ldx, ws, Mt, (int)N, (int)K, tps};
-    dim3 grid((unsigned)((N / 128) * (K / 128)), (unsigned)splits);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 2 * BUF_BYTES, (hipStream_t)stream, g);
+    TNArgs g{(const bf16*)dY, lddy, (const bf16*)X, ldx, ws, Mt, (int)N, (int)K, tps, splits};
+    static const char* ver_s = getenv("TNR_GEMM_VER");
+    static const int ver = ver_s ? atoi(ver_s) : 3;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256x256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        attr_set = true;
+    }
+    if (ver == 1 || (N % 256) != 0) {
+        dim3 grid((unsigned)((N / 128) * (K / 128) * splits));
+        hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 2 * BUF_BYTES, (hipStream_t)stream, g);
+    } else if (ver == 2 || (K % 256) != 0) {
+        dim3 grid((unsigned)((N / 256) * (K / 128) * splits));
+        hipLaunchKernelGGL(gemm_tn256_kernel, grid, dim3(512), RING2, (hipStream_t)stream, g);
+    } else {
+        dim3 grid((unsigned)((N / 256) * (K / 256) * splits));
+        hipLaunchKernelGGL(gemm_tn256x256_kernel<0>, grid, dim3(512), RING3, (hipStream_t)stream, g);
+    }
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad");
     int64_t NK = N * K;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((NK / 4 + 255) / 256)), dim3(256), 0,
