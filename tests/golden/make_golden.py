@@ -210,6 +210,7 @@ def golden_amsgrad():
 
 
 def main():
+    golden_interface()
     R = ref_shim.load_reference()
     golden_relpos(R)
     golden_datapath(R)
@@ -231,6 +232,41 @@ def main():
                            trainable, seed=seed, B=2, T=T, full_grads=False)
         np.savez_compressed(os.path.join(HERE, "full_model_%d.npz" % k), **rec)
         print("full", k, rec["total"], rec["distill"], rec["emb"], rec["target"])
+
+
+
+def golden_interface():
+    """Flag surface (parameters.py) and state_dict schema (model_bert.Model) of the reference, as JSON."""
+    import json
+    import importlib
+    R = ref_shim.load_reference()
+    sys.path.insert(0, R.path)
+    try:
+        sys.modules.pop("parameters", None)
+        P = importlib.import_module("parameters")
+        argv, sys.argv = sys.argv, ["x"]
+        try:
+            a = P.parse_args()
+        finally:
+            sys.argv = argv
+    finally:
+        sys.path.remove(R.path)
+        sys.modules.pop("parameters", None)
+    flags = {k: (v if not isinstance(v, float) else float(v)) for k, v in vars(a).items()}
+    m = R.model_bert.Model(ref_shim.make_args(num_student_layers=4, num_teachers=4))
+    schema = {k: list(v.shape) for k, v in m.state_dict().items()}
+    n_train = 0
+    for p in m.teachers.parameters():
+        p.requires_grad = False
+    for p in m.student.news_encoder.bert_model.parameters():
+        p.requires_grad = False
+    for i, layer in enumerate(m.student.news_encoder.bert_model.bert.encoder.layer):
+        if i in (2, 3):
+            for p in layer.parameters():
+                p.requires_grad = True
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    with open(os.path.join(HERE, "interface.json"), "w") as f:
+        json.dump({"flags": flags, "state_dict": schema, "trainable_4layer_23": trainable}, f, indent=0, sort_keys=True)
 
 
 if __name__ == "__main__":

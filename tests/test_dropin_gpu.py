@@ -1,0 +1,74 @@
+"""GPU: the reference's Python surface on the HIP engine -- model_bert.Model(args).forward(...) 5-tuple,
+total_loss.backward() filling .grad, optimizer.step(), state_dict schema, and `python run.py --mode train`."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import GOLDEN, load_case   # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+IFACE = json.load(open(os.path.join(GOLDEN, "interface.json")))
+
+
+def _args(z, cfg, T_):
+    seed, B, _, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
+    return types.SimpleNamespace(
+        config_name=None, pooling="att", model="NAML", num_teacher_layers=12, num_student_layers=nl,
+        bert_trainable_layer=list(cfg["trainable_layers"]), news_dim=D, news_query_vector_dim=200,
+        user_query_vector_dim=200, num_teachers=T_, user_log_length=U, npratio=C - 1, num_words_title=L,
+        user_log_mask=cfg["user_log_mask"], temperature=cfg["temperature"], coef=cfg["coef"], batch_size=B)
+
+
+def test_model_module_is_a_drop_in():
+    import model_bert
+    z, P, cfg, inp = load_case("full_model_1.npz")
+    T_ = len(inp[4])
+    torch.cuda.set_device(0)
+    model = model_bert.Model(_args(z, cfg, T_))
+    sd = model.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == IFACE["state_dict"]
+    assert sorted(k for k, p in model.named_parameters() if p.requires_grad) == sorted(IFACE["trainable_4layer_23"])
+    assert hasattr(model, "student") and hasattr(model.student, "news_encoder") and len(model.teachers._modules) == T_
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    out = model(t(inp[0]), t(inp[1]), t(inp[2]), t(inp[3]), [t(x) for x in inp[4]], [t(x) for x in inp[5]])
+    total, distill, emb, target, score = out
+    for got, key in ((total, "total"), (distill, "distill"), (emb, "emb"), (target, "target")):
+        assert abs(got.item() - float(z[key])) < 1.6e-2 * max(1.0, abs(float(z[key]))), key
+    assert score.shape == (inp[0].shape[0], inp[2].shape[1])
+    opt = model_bert.TnrAdam(model, 1e-4)
+    opt.zero_grad()
+    total.backward()
+    w = dict(model.named_parameters())
+    k = "student.news_encoder.bert_model.bert.encoder.layer.3.output.dense.weight"
+    assert w[k].grad is not None and abs(float(w[k].grad.norm()) - float(z["gnorm." + k])) < 6e-2 * float(z["gnorm." + k])
+    assert w["student.news_encoder.bert_model.bert.embeddings.word_embeddings.weight"].grad is None
+    assert w["teachers.0.pad_doc"].grad is None
+    before = w[k].detach().clone()
+    opt.step()
+    assert not torch.equal(before, w[k].detach())
+    # checkpoint round trip in the reference's dict layout (run.py:205-214)
+    model.load_state_dict({k_: v.cpu() for k_, v in model.state_dict().items()})
+
+
+def test_run_py_train_entry_point(tmp_path):
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tiny-newsrec_amd"))
+    cmd = [sys.executable, "-u", os.path.join(ROOT, "tiny-newsrec_amd", "run.py"), "--mode", "train", "--synthetic", "True",
+           "--enable_hvd", "False", "--batch_size", "8", "--epochs", "1", "--max_steps_per_epoch", "4", "--log_steps", "2",
+           "--num_words_title", "30", "--news_dim", "256", "--num_student_layers", "2", "--bert_trainable_layer", "0", "1",
+           "--num_teachers", "2", "--user_log_mask", "False", "--coef", "0.2", "--model", "NAML", "--model_type", "tnlrv3",
+           "--model_dir", str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=os.path.join(ROOT, "tiny-newsrec_amd"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "train_loss" in r.stdout and "Model saved to" in r.stdout
+    ck = torch.load(os.path.join(str(tmp_path), "epoch-1.pt"), map_location="cpu")
+    assert set(ck) == {"model_state_dict", "category_dict", "word_dict", "subcategory_dict"}
+    assert "student.user_encoder.pad_doc" in ck["model_state_dict"]

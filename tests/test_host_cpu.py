@@ -1,0 +1,160 @@
+"""CPU: host side of the boundary -- flag surface, state_dict schema, file sharding, sample decoding (bit-exact
+against vectors captured from the reference), TF-free line streaming, and the data-parallel gradient
+sync on a 2-rank gloo group."""
+import json
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+IFACE = json.load(open(os.path.join(GOLDEN, "interface.json")))
+DATA = os.path.join(GOLDEN, "data")
+
+
+def test_every_reference_flag_with_its_default():
+    import parameters
+    a = vars(parameters.parse_args([]))
+    for k, v in IFACE["flags"].items():
+        assert k in a, "flag --%s missing" % k
+        assert a[k] == v, "--%s default %r != reference %r" % (k, a[k], v)
+    b = parameters.parse_args("--mode train --bert_trainable_layer 2 3 --user_log_mask False --coef 0.2 "
+                              "--teacher_ckpts a b --num_teachers 2".split())
+    assert b.bert_trainable_layer == [2, 3] and b.user_log_mask is False and b.teacher_ckpts == ["a", "b"]
+    with pytest.raises(SystemExit):
+        parameters.parse_args(["--mode", "bogus"])
+
+
+def test_state_dict_schema_and_trainable_set_match_reference():
+    import engine as E
+    cfg = E.EngineConfig(n_layers=4, trainable_layers=(2, 3), num_teachers=4)
+    shapes = E.param_shapes(cfg)
+    assert {k: list(v) for k, v in shapes.items()} == IFACE["state_dict"]
+    assert sorted(k for k in shapes if E.is_trainable(cfg, k)) == sorted(IFACE["trainable_4layer_23"])
+    eng = E.Engine(cfg, device="cpu", max_batch=1)        # storage layout only; no kernel is launched
+    assert sum(v.numel() for v in eng.params.values()) == 53654504
+    assert sum(v.numel() for k, v in eng.params.items() if E.is_trainable(cfg, k)) == 14841634
+    # parameters are views of the flat buffers, 16-byte aligned, non-overlapping
+    spans = sorted((eng.slot[k][1], eng.slot[k][1] + eng.slot[k][2]) for k in shapes if eng.slot[k][0])
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    assert all(v.data_ptr() % 16 == 0 for k, v in eng.params.items() if v.numel() >= 4)
+    # gradient buckets tile the trainable buffer exactly once
+    br = sorted(eng.bucket_ranges())
+    assert br[0][0] == 0 and br[-1][1] == eng.n_train and all(a[1] == b[0] for a, b in zip(br, br[1:]))
+    # stacked groups the kernels read as one array
+    q, k_ = (E.layer_param_order(3)[0], E.layer_param_order(3)[1])
+    assert eng.off(k_) == eng.off(q) + 768 * 768
+    assert eng.off("teachers.1.attn.att_fc1.weight") == eng.off("teachers.0.attn.att_fc1.weight") + 200 * 256
+
+
+def test_worker_file_sharding_matches_reference():
+    import streaming
+    z = np.load(os.path.join(GOLDEN, "datapath.npz"))
+    for w in (1, 2, 3):
+        seen = []
+        for r in range(w):
+            for sh in (0, 1):
+                got = [os.path.basename(x) for x in streaming.get_worker_files(DATA, r, w, "behaviors_np4_*.tsv", bool(sh), 3)]
+                assert got == [str(x) for x in z["files_w%d_r%d_s%d" % (w, r, sh)]]
+            seen += [os.path.basename(x) for x in streaming.get_worker_files(DATA, r, w, "behaviors_np4_*.tsv")]
+        assert sorted(seen) == ["behaviors_np4_%d.tsv" % i for i in range(3)]       # disjoint and complete
+    stat = streaming.get_stat(DATA, "behaviors_np4_*.tsv")
+    assert sorted(stat.values()) == [4, 4, 4]
+
+
+def _loader(resident=False, batch_size=5, world=1, rank=0, shuffle=False):
+    import dataloader
+    import hashinit
+    z = np.load(os.path.join(GOLDEN, "datapath.npz"))
+    news_index = {str(k): int(v) for k, v in zip(z["news_ids"], z["news_index"])}
+    comb = z["news_combined"]
+    temb = [hashinit.hash_normal(11, "dp_temb%d" % i, (comb.shape[0], 8)) for i in range(2)]
+    args = types.SimpleNamespace(npratio=4, user_log_length=50, batch_size=batch_size, shuffle_buffer_size=7, num_teachers=2)
+    dl = dataloader.DataLoaderTrain(DATA, "behaviors_np4_*.tsv", args, world, rank, 0, news_index, comb, temb,
+                                    enable_prefetch=True, enable_shuffle=shuffle, enable_gpu=False, resident=resident)
+    return dl, z
+
+
+def test_sample_decoding_is_bit_exact_with_reference():
+    dl, z = _loader()
+    lines = [str(x).encode() for x in z["lines"]]
+    random.seed(7)
+    out = dl._process(lines)
+    assert out[0].dtype == torch.int64 and np.array_equal(out[0].numpy(), z["log_ids"])
+    assert out[1].dtype == torch.float32 and np.array_equal(out[1].numpy(), z["log_mask"])
+    assert np.array_equal(out[2].numpy(), z["input_ids"]) and np.array_equal(out[3].numpy(), z["targets"])
+    assert np.array_equal(out[4][0].numpy(), z["th0"]) and np.array_equal(out[5][1].numpy(), z["tc1"])
+    # edge cases of the golden lines: empty history, >50 clicks, unknown ids
+    h, m, c, y = dl.decode([b"9\tU\tt\t\tN1\tN2 N3 N4 N5"])
+    assert h.sum() == 0 and m.sum() == 0
+
+
+def test_stream_covers_every_line_once_with_short_last_batch():
+    dl, z = _loader(batch_size=5)
+    got = []
+    sizes = []
+    for b in dl:
+        sizes.append(b[0].shape[0])
+        got.append(b[3])
+    assert sizes == [5, 5, 2] and sum(sizes) == len(z["lines"])
+    # second epoch restarts cleanly; shuffled epoch still covers all lines
+    assert sum(b[0].shape[0] for b in dl) == 12
+    dl2, _ = _loader(batch_size=4, shuffle=True)
+    assert sum(b[0].shape[0] for b in dl2) == 12
+    dl2.join()
+    # two workers see disjoint files: 2 + 1 files -> 8 + 4 lines
+    n = [sum(b[0].shape[0] for b in _loader(world=2, rank=r)[0]) for r in range(2)]
+    assert sorted(n) == [4, 8]
+
+
+def test_news_table_layout_with_stub_tokenizer():
+    import preprocess
+    L = 6
+
+    def tok(text, max_length, padding, truncation):
+        ids = [101] + [1000 + len(w) for w in text.split()][:max_length - 2] + [102]
+        am = [1] * len(ids) + [0] * (max_length - len(ids))
+        return {"input_ids": ids + [0] * (max_length - len(ids)), "attention_mask": am}
+
+    args = types.SimpleNamespace(num_words_title=L, tokenizer_name=None)
+    news, idx, cat, sub = preprocess.read_news_bert(os.path.join(DATA, "news.tsv"), args, "train", tokenizer=tok)
+    t, m, _, _ = preprocess.get_doc_input_bert(news, idx, cat, sub, args)
+    assert list(idx.values()) == list(range(1, 41)) and t.shape == (41, L) and t.dtype == np.int32
+    assert (t[0] == 0).all() and (m[0] == 0).all() and (t[1:, 0] == 101).all()
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import dist
+    w, r, _ = dist.init("gloo")
+    flat = torch.arange(1000, dtype=torch.float32) * (r + 1)
+    ranges = [(600, 1000), (300, 600), (0, 300)]
+    gs = dist.GradSync(flat, ranges, w)
+    for b in range(3):
+        gs.launch(b)
+    gs.wait()
+    p = torch.full((10,), float(r))
+    dist.broadcast_flat([p])
+    dist.barrier()
+    q.put((r, flat.numpy().copy(), gs.scale, p.numpy().copy()))      # by value: the child exits right after
+
+
+def test_gradient_average_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    ps = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+    want = torch.arange(1000, dtype=torch.float32) * 3          # rank0 * 1 + rank1 * 2
+    for r, flat, scale, p in res:
+        assert np.array_equal(flat, want.numpy()) and scale == 0.5   # sum on the wire, 1/world folded into AMSGrad
+        assert np.array_equal(p, np.zeros(10, np.float32))            # parameters broadcast from rank 0

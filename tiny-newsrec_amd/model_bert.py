@@ -1,0 +1,135 @@
+"""Module surface of Tiny-NewsRec/model_bert.py on the HIP engine: same class names, constructor and forward
+signatures, return tuples and state_dict key schema, so run.py / checkpoints interchange.
+
+    Model(args).forward(history, history_mask, candidate, label, teacher_history_embs, teacher_candidate_embs)
+        -> (total_loss, distill_loss, emb_loss, target_loss, student_score)        model_bert.py:262-305
+
+Every nn.Parameter is a view into the engine's flat fp32 buffers; total_loss.backward() runs the hand-written
+HIP backward and leaves gradients in the parameters' .grad (views of the flat gradient buffer).  The module is
+a thin shell: no arithmetic happens in torch, and construction fails if libtnr_hip.so is missing."""
+import json
+
+import torch
+from torch import nn
+
+import engine as E
+
+
+def engine_config_from_args(args, num_teachers=None, is_teacher=False):
+    """parameters.py flags -> EngineConfig.  Model sizes come from the tnlrv3 config json like
+    config_class.from_pretrained(args.config_name, num_hidden_layers=...) at model_bert.py:110-113."""
+    cfg = {}
+    try:
+        with open(args.config_name) as f:
+            cfg = json.load(f)
+    except (OSError, TypeError, ValueError):
+        pass
+    if getattr(args, "pooling", "att") != "att" or getattr(args, "model", "NAML") == "NRMS":
+        raise NotImplementedError("HIP path covers pooling='att' and the NAML user encoder (demo.sh); "
+                                  "cls/mean pooling and NRMS are SURVEY section 8-f N4")
+    nl = args.num_teacher_layers if is_teacher else args.num_student_layers
+    T_ = args.num_teachers if num_teachers is None else num_teachers
+    return E.EngineConfig(
+        n_layers=nl, trainable_layers=tuple(l for l in args.bert_trainable_layer if l < nl),
+        hidden=cfg.get("hidden_size", 768), heads=cfg.get("num_attention_heads", 12), inter=cfg.get("intermediate_size", 3072),
+        news_dim=args.news_dim, news_query=args.news_query_vector_dim, user_query=args.user_query_vector_dim,
+        num_teachers=T_, user_log_length=args.user_log_length, npratio=args.npratio, num_words=args.num_words_title,
+        user_log_mask=args.user_log_mask, temperature=args.temperature, coef=args.coef, vocab=cfg.get("vocab_size", 30522),
+        max_pos=cfg.get("max_position_embeddings", 512), type_vocab=cfg.get("type_vocab_size", 2),
+        ln_eps=cfg.get("layer_norm_eps", 1e-12))
+
+
+class _Backward(torch.autograd.Function):
+    """Bridges total_loss.backward() (run.py:194) to Engine.backward()."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, total):
+        ctx.model = model
+        return total.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        m = ctx.model
+        m.engine.backward(after_bucket=m._after_bucket)
+        if m.strict_grad_scale:
+            m.engine.flat_g.mul_(gout)          # honour a non-unit upstream gradient (costs one pass)
+        m._bind_grads()
+        return torch.zeros_like(m._anchor), None, None
+
+
+class _Shell(nn.Module):
+    """nn.Module tree whose leaves are parameters aliased to engine storage; built from dotted key names."""
+
+    def _adopt(self, engine, prefix):
+        for key, tensor in engine.params.items():
+            if not key.startswith(prefix):
+                continue
+            parts = key[len(prefix):].split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Shell())
+                mod = mod._modules[p]
+            prm = nn.Parameter(tensor, requires_grad=E.is_trainable(engine.cfg, key))
+            mod.register_parameter(parts[-1], prm)
+
+
+class Model(_Shell):
+    def __init__(self, args, device=None, max_batch=None):
+        super().__init__()
+        self.args = args
+        dev = device or ("cuda:%d" % torch.cuda.current_device())
+        self.engine = E.Engine(engine_config_from_args(args), dev, max_batch=max_batch or args.batch_size)
+        self._adopt(self.engine, "")
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._after_bucket = None
+        self.strict_grad_scale = False
+        self._name_of = {id(p): k for k, p in self.named_parameters()}
+
+    # reference-compatible views --------------------------------------------------------------------
+    def named_trainable(self):
+        return [(k, p) for k, p in self.named_parameters() if p.requires_grad]
+
+    def _bind_grads(self):
+        for k, p in self.named_parameters():
+            if p.requires_grad and p.grad is None:
+                p.grad = self.engine.grads[k]
+
+    def load_state_dict(self, sd, strict=True):
+        out = super().load_state_dict(sd, strict=strict)
+        self.engine.refresh_shadows(all_layers=True)       # bf16 copies + rel-pos table follow the fp32 weights
+        return out
+
+    def forward(self, history, history_mask, candidate, label, teacher_history_embs, teacher_candidate_embs):
+        eng = self.engine
+        if isinstance(history, tuple) and len(history) == 4:      # resident-mode IndexBatch
+            raise TypeError("use forward_indexed for resident-mode batches")
+        losses, score = eng.forward(history, history_mask, candidate, label, list(teacher_history_embs),
+                                    list(teacher_candidate_embs))
+        return self._pack(losses, score)
+
+    def forward_indexed(self, news_combined, hist_idx, history_mask, cand_idx, label, teacher_tables):
+        losses, score = self.engine.forward_indexed(news_combined, hist_idx, history_mask, cand_idx, label, teacher_tables)
+        return self._pack(losses, score)
+
+    def _pack(self, losses, score):
+        total = _Backward.apply(self._anchor, self, self.engine.total_loss())
+        return total, losses[0], losses[2], losses[1], score
+
+
+class TnrAdam:
+    """optim.Adam(model.parameters(), lr, amsgrad=True) of run.py:134 on the engine's flat buffers
+    (one fused kernel + bf16-copy refresh); zero_grad / step keep the reference's call order (run.py:193-195)."""
+
+    def __init__(self, model, lr, grad_sync=None):
+        self.model, self.lr, self.grad_sync = model, lr, grad_sync
+
+    def zero_grad(self):
+        pass                      # every backward overwrites the whole flat gradient buffer
+
+    def step(self):
+        scale = 1.0
+        if self.grad_sync is not None:
+            self.grad_sync.wait()
+            scale = self.grad_sync.scale
+        self.model.engine.step(self.lr, grad_scale=scale)

@@ -1,0 +1,135 @@
+"""Entry point with the reference's interface (Tiny-NewsRec/run.py:463-472): python run.py --mode train ...
+Training loop = run.py:20-216 (step order fwd -> acc -> zero_grad -> backward -> step, log line format,
+epoch-end checkpoint dict and file name, max_steps_per_epoch break), on the HIP engine with RCCL replacing
+horovod.  --mode test / get_teacher_emb are the forward-only paths of SURVEY.md section 8-f N2."""
+import logging
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+
+import utils
+from parameters import parse_args
+
+
+def _load_inputs(args):
+    """news table + teacher embeddings (run.py:46-53, 73-74) or their synthetic stand-ins."""
+    if args.synthetic:
+        import synth
+        n = 51282
+        comb = synth.news_table(1234, n, args.num_words_title)
+        tables = list(synth.teacher_tables(1234, args.num_teachers, n, args.news_dim)) if args.num_teachers else []
+        return {"N%d" % i: i for i in range(1, n + 1)}, comb, tables, {}, {}
+    from preprocess import get_doc_input_bert, read_news_bert
+    news, news_index, cat, sub = read_news_bert(os.path.join(args.train_data_dir, "news.tsv"), args, mode="train")
+    title, mask, _, _ = get_doc_input_bert(news, news_index, cat, sub, args)
+    tables = []
+    for p in args.teacher_emb_paths[:args.num_teachers]:
+        with open(p, "rb") as f:
+            tables.append(np.asarray(pickle.load(f), dtype=np.float32))
+    return news_index, np.concatenate([title, mask], axis=-1), tables, cat, sub
+
+
+def train(args):
+    import dist
+    from dataloader import DataLoaderTrain, IndexBatch
+    from model_bert import Model, TnrAdam
+    from streaming import get_stat, get_worker_files
+    size, rank, local = utils.init_hvd_cuda(args.enable_hvd, args.enable_gpu)
+    assert args.enable_gpu, "the HIP path needs a GPU (there is no CPU fallback)"
+    news_index, news_combined, teacher_embs, category_dict, subcategory_dict = _load_inputs(args)
+    model = Model(args)
+    eng = model.engine
+    sd = model.state_dict()
+    if args.synthetic:
+        import hashinit
+        sd = {k: torch.from_numpy(hashinit.init_tensor(1234, k, tuple(v.shape))) for k, v in sd.items()}
+    else:
+        for i, ck in enumerate(args.teacher_ckpts[:args.num_teachers]):      # run.py:61-70
+            for k, v in torch.load(ck, map_location="cpu")["model_state_dict"].items():
+                if k.startswith("user_encoder"):
+                    sd[".".join(["teachers", str(i)] + k.split(".")[1:])] = v
+        if args.use_pretrain_model:                                          # run.py:76-85
+            for k, v in torch.load(args.pretrain_model_path, map_location="cpu")["model_state_dict"].items():
+                if k.startswith("student"):
+                    sd[k] = v
+    model.load_state_dict(sd)
+    if args.load_ckpt_name is not None:                                      # run.py:125-129
+        ck = utils.get_checkpoint(args.model_dir, args.load_ckpt_name)
+        model.load_state_dict(torch.load(ck, map_location="cpu")["model_state_dict"])
+        logging.info(f"Model loaded from {ck}")
+    dist.broadcast_flat([eng.flat[True], eng.flat[False]])                   # hvd.broadcast_parameters, run.py:142
+    eng.refresh_shadows(all_layers=True)
+    sync = dist.GradSync(eng.flat_g, eng.bucket_ranges(), size)             # hvd.DistributedOptimizer(Average), :145-149
+    model._after_bucket = sync.launch if size > 1 else None
+    optimizer = TnrAdam(model, args.lr, sync if size > 1 else None)
+
+    if args.synthetic:
+        import synth
+        steps = min(args.max_steps_per_epoch, 200)
+        hidx, mask, cidx, label = [torch.from_numpy(x).cuda() for x in
+                                   synth.impressions(77 + rank, steps * args.batch_size, len(news_index), args.user_log_length, args.npratio + 1)]
+        B = args.batch_size
+        dev_news = torch.from_numpy(news_combined).cuda()
+        dev_tab = torch.from_numpy(np.stack(teacher_embs, 0)).cuda() if teacher_embs else None
+        batches = lambda: (IndexBatch((hidx[i * B:(i + 1) * B], mask[i * B:(i + 1) * B], cidx[i * B:(i + 1) * B],
+                                       label[i * B:(i + 1) * B])) for i in range(steps))
+    else:
+        stat = get_stat(args.train_data_dir, args.filename_pat)
+        paths = get_worker_files(args.train_data_dir, rank, size, args.filename_pat, args.enable_shuffle, 0)
+        n = sum(stat[f] for f in paths)
+        logging.info("[{}] contains {} samples {} steps".format(rank, n, n // args.batch_size))
+        loader = DataLoaderTrain(teacher_embs=teacher_embs, news_index=news_index, news_combined=news_combined, word_dict=None,
+                                 data_dir=args.train_data_dir, filename_pat=args.filename_pat, args=args, world_size=size,
+                                 worker_rank=rank, cuda_device_idx=local, enable_prefetch=True, enable_shuffle=True,
+                                 enable_gpu=True, resident=args.resident_tables)
+        dev_news, dev_tab = getattr(loader, "dev_news", None), loader.dev_tables
+        batches = lambda: iter(loader)
+
+    logging.info("Training...")
+    for ep in range(args.start_epoch, args.epochs):
+        loss_sum, acc_sum, t0 = torch.zeros((), device="cuda"), torch.zeros((), device="cuda"), time.time()
+        for cnt, batch in enumerate(batches()):
+            if cnt > args.max_steps_per_epoch:
+                break
+            if isinstance(batch, IndexBatch):
+                h, m, c, y = batch
+                total, distill, emb, target, y_student = model.forward_indexed(dev_news, h, m, c, y, dev_tab)
+            else:
+                h, m, c, y, th, tc = batch
+                total, distill, emb, target, y_student = model(h, m, c, y, th, tc)
+            loss_sum += total.detach()
+            acc_sum += utils.acc(y, y_student)
+            optimizer.zero_grad()
+            total.backward()
+            optimizer.step()
+            if cnt % args.log_steps == 0:
+                d = max(cnt, 1)
+                logging.info("[{}] Ed: {}, train_loss: {:.5f}, acc: {:.5f}, {:.1f} impressions/s".format(
+                    rank, cnt * args.batch_size, loss_sum.item() / d, acc_sum.item() / d,
+                    size * cnt * args.batch_size / max(time.time() - t0, 1e-9)))
+        print(ep + 1)
+        if rank == 0:                                                        # run.py:205-214
+            os.makedirs(args.model_dir, exist_ok=True)
+            ckpt_path = os.path.join(args.model_dir, f"epoch-{ep + 1}.pt")
+            torch.save({"model_state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
+                        "category_dict": category_dict, "word_dict": None, "subcategory_dict": subcategory_dict}, ckpt_path)
+            logging.info(f"Model saved to {ckpt_path}")
+    if not args.synthetic:
+        loader.join()
+
+
+def get_teacher_emb(args):
+    raise NotImplementedError("get_teacher_emb (run.py:382-460) is SURVEY section 8-f N2; Engine.encode() is its forward path")
+
+
+def test(args):
+    raise NotImplementedError("test (run.py:219-379) is SURVEY section 8-f N2; Engine.encode() is its forward path")
+
+
+if __name__ == "__main__":
+    utils.setuplogger()
+    args = parse_args()
+    {"train": train, "test": test, "get_teacher_emb": get_teacher_emb}[args.mode](args)

@@ -1,0 +1,129 @@
+"""TF-free restatement of Tiny-NewsRec/streaming.py: the data-parallel file-sharding rule (get_worker_files
+:40-58, bit-exact incl. the seeded shuffle) and a line reader with the semantics the reference asks tf.data for
+(:61-96): round-robin interleave over this worker's files in blocks of 128 lines, optional shuffle buffer,
+batches of `batch_size` raw byte lines, last batch may be short (no drop_remainder, :76)."""
+import fnmatch
+import logging
+import os
+import random
+
+import numpy as np
+
+
+def get_stat(dirname, filename_pat="*"):
+    """{path: line count} for matching files (streaming.py:10-22 shells out to `wc -l`)."""
+    if not os.path.exists(dirname):
+        logging.warning(f"{dirname} does not exist!")
+        return None
+    stat = {}
+    for x in os.listdir(dirname):
+        if fnmatch.fnmatch(x, filename_pat):
+            path = os.path.join(dirname, x)
+            with open(path, "rb") as f:
+                stat[path] = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 20), b""))
+    return stat
+
+
+def get_files(dirname, filename_pat="*", recursive=False):
+    if not os.path.exists(dirname):
+        logging.warning(f"{dirname} does not exist!")
+        return None
+    out = []
+    for x in os.listdir(dirname):
+        path = os.path.join(dirname, x)
+        if os.path.isdir(path):
+            if recursive:
+                out.extend(get_files(path, filename_pat))
+        elif fnmatch.fnmatch(x, filename_pat):
+            out.append(path)
+    return out
+
+
+def get_worker_files(dirname, worker_rank, world_size, filename_pat="*", shuffle=False, seed=0):
+    """sorted matches -> optional random.seed(seed); random.shuffle -> files[rank::world]"""
+    all_files = get_files(dirname, filename_pat)
+    all_files.sort()
+    if shuffle:
+        random.seed(seed)          # NB: also seeds the label draw of dataloader.py:136, as in the reference
+        random.shuffle(all_files)
+    files = all_files[worker_rank::world_size]
+    logging.info(f"worker_rank:{worker_rank}, world_size:{world_size}, shuffle:{shuffle}, seed:{seed}, "
+                 f"directory:{dirname}, files:{files}")
+    return files
+
+
+class StreamReader:
+    BLOCK = 128
+
+    def __init__(self, data_paths, batch_size, shuffle=False, shuffle_buffer_size=1000, seed=None):
+        self.paths, self.batch_size = list(data_paths), batch_size
+        self.shuffle, self.buf_size = shuffle, shuffle_buffer_size
+        self.rng = random.Random(seed)
+        self.endofstream = True
+        self._it = None
+
+    def _lines(self):
+        files = [open(p, "rb") for p in self.paths]
+        try:
+            live = list(files)
+            while live:
+                for f in list(live):
+                    for _ in range(self.BLOCK):
+                        line = f.readline()
+                        if not line:
+                            live.remove(f)
+                            break
+                        yield line.rstrip(b"\n")
+        finally:
+            for f in files:
+                f.close()
+
+    def _shuffled(self):
+        buf = []
+        for line in self._lines():
+            if len(buf) < self.buf_size:
+                buf.append(line)
+                continue
+            i = self.rng.randrange(len(buf))
+            buf[i], line = line, buf[i]
+            yield line
+        self.rng.shuffle(buf)
+        yield from buf
+
+    def reset(self):
+        self._it = self._shuffled() if self.shuffle else self._lines()
+        self.endofstream = False
+
+    def get_next(self):
+        batch = []
+        for line in self._it:
+            batch.append(line)
+            if len(batch) == self.batch_size:
+                break
+        if not batch:
+            self.endofstream = True
+            return None
+        return np.array(batch, dtype=object)
+
+    def reach_end(self):
+        return self.endofstream
+
+
+class StreamSampler:
+    def __init__(self, data_dir, filename_pat, batch_size, worker_rank, world_size, enable_shuffle=False,
+                 shuffle_buffer_size=1000, shuffle_seed=0):
+        paths = get_worker_files(data_dir, worker_rank, world_size, filename_pat, shuffle=enable_shuffle, seed=shuffle_seed)
+        self.stream_reader = StreamReader(paths, batch_size, enable_shuffle, shuffle_buffer_size)
+
+    def __iter__(self):
+        self.stream_reader.reset()
+        return self
+
+    def __next__(self):
+        nb = self.stream_reader.get_next()
+        if nb is None:
+            raise StopIteration
+        return nb
+
+    def reach_end(self):
+        return self.stream_reader.reach_end()
