@@ -40,6 +40,7 @@ extern "C" {
 #define TNR_EPI_MULDGELU 16  /* * gelu'(aux[m,n])  : backward of TNR_EPI_GELU */
 #define TNR_EPI_OUTF32 32    /* C is fp32 instead of bf16 */
 #define TNR_EPI_AUXOUT 64    /* also store the pre-activation (acc+bias) to aux (bf16) */
+#define TNR_EPI_COLSUM 128   /* tnr_gemm_nt_ex: also emit per-64-row-strip column sums of the bf16 output (bias grads) */
 
 int tnr_version(void);
 const char* tnr_last_error(void);
@@ -71,6 +72,13 @@ int tnr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                 int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                 void* aux, int64_t ldaux, int flags, void* stream);
 
+/* Same with an extra output for TNR_EPI_COLSUM: colsum_part (tnr_gemm_colsum_rows(M), N) fp32 whose rows sum
+ * (tnr_reduce_rows) to the column sums of C -- the bias gradient of the Linear whose dgrad this GEMM is. */
+int tnr_gemm_nt_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                   void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream);
+int64_t tnr_gemm_colsum_rows(int64_t M);
+
 /* dW[N,K] (fp32) = dY[M,N]^T . X[M,K] : weight gradient of a Linear.  Reduction over M is split into
  * `splits` slabs in `ws` (fp32, splits*N*K elements) and summed in fixed order (deterministic).
  * Rows [M, Mpad) of dY and X must be zero, Mpad = roundup(M, 64) ; N % 128 == 0, K % 128 == 0.
@@ -83,10 +91,10 @@ int64_t tnr_gemm_tn_ws_elems(int64_t N, int64_t K, int splits);
  * fwd: y = LN(x) ; stats (M,2) fp32 = (mean, rstd) kept for backward. */
 int tnr_ln_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* stats,
                int64_t M, int H, void* stream);
-/* bwd: dx = LN'(dy) ; dgamma/dbeta partial sums go to part (nblk,2,H) fp32 then are reduced into
- * dgamma, dbeta (may be null when the layer is frozen). */
+/* bwd: dx = LN'(dy) ; partial sums go to part (nblk,3,H) fp32 then are reduced into dgamma, dbeta and
+ * dxsum = column sums of dx (the bias gradient of the Linear in front of this LayerNorm); each may be null. */
 int tnr_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
-               float* dgamma, float* dbeta, float* part, int64_t M, int H, void* stream);
+               float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream);
 int64_t tnr_ln_bwd_part_elems(int64_t M, int H);
 
 /* BertSelfAttention.multi_head_attention (tnlrv3/modeling.py:205-231) for L <= 32, head size 64:
@@ -94,13 +102,17 @@ int64_t tnr_ln_bwd_part_elems(int64_t M, int H);
  * rel (A,32,32) fp32 from tnr_relpos_table ; ctx (N*L, A*64) bf16. */
 int tnr_attn_l32_fwd(const void* qkv, const float* mask_add, const float* rel, void* ctx,
                      int64_t n_seq, int L, int A, void* stream);
-/* backward: recomputes the probabilities ; dqkv (N*L, 3*A*64) bf16. */
+/* backward: recomputes the probabilities ; dqkv (N*L, 3*A*64) bf16 ; bias_part (N, 3*A*64) fp32 (nullable) =
+ * per-sequence column sums of dqkv (rows sum to the q/k/v bias gradient). */
 int tnr_attn_l32_bwd(const void* qkv, const float* mask_add, const float* rel, const void* dctx,
-                     void* dqkv, int64_t n_seq, int L, int A, void* stream);
+                     void* dqkv, float* bias_part, int64_t n_seq, int L, int A, void* stream);
 
 /* column sums (bias gradients): out[n] (+)= sum_m X[m,n] ; X bf16 or fp32 (dtype) ; part (nblk,N) fp32 */
 int tnr_colsum(const void* X, int64_t ldx, int dtype, int64_t M, int64_t N, float* out, float* part,
                int accumulate, void* stream);
+/* batch of matrices X + z*sX -> out (batch, N) ; part needs batch * tnr_colsum_part_elems(M, N) */
+int tnr_colsum_batched(const void* X, int64_t ldx, int64_t sX, int dtype, int64_t M, int64_t N, int batch,
+                       float* out, float* part, int accumulate, void* stream);
 int64_t tnr_colsum_part_elems(int64_t M, int64_t N);
 
 /* ---- heads ----------------------------------------------------------------------------------- */
@@ -111,18 +123,21 @@ int64_t tnr_colsum_part_elems(int64_t M, int64_t N);
 int tnr_attpool_fwd(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
                     float* nv, float* alpha, float* den, int64_t n_seq, int L, int H, void* stream);
 /* backward: dnv (N,H) fp32 -> dy_direct (N*L,H) bf16 = alpha*dnv ; dpre (N*L, lddpre) bf16 =
- * d tanh-preactivation (padded cols 0) ; dw2_part (N,Q) ; db2_part (N). */
+ * d tanh-preactivation (padded cols 0) ; dw2_part (N,Q) ; db2_part (N) ; db1_part (N, lddpre) nullable = per-title
+ * column sums of dpre (fc1 bias gradient partials). */
 int tnr_attpool_bwd(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
                     const float* alpha, const float* den, void* dy_direct, void* dpre, int64_t lddpre,
-                    float* dw2_part, float* db2_part, int64_t n_seq, int L, int H, void* stream);
+                    float* dw2_part, float* db2_part, float* db1_part, int64_t n_seq, int L, int H, void* stream);
 
 /* small fp32 GEMM on the f32 MFMA (exact fp32):  for z in [0,batch):
  *   C_z[m,n] = alpha * sum_k A_z(m,k) B_z(n,k) + bias_z[n] + beta * C_z[m,n]
- * A_z(m,k) = A[z*sA + row(m)*a_rs + k*a_cs], row(m) = a_idx ? a_idx[m] : m ; likewise B (no gather). */
+ * A_z(m,k) = A[z*sA + m*a_rs + k*a_cs] (a_idx must be NULL), likewise B.  ksplit > 1 splits K over workgroups
+ * into part (ksplit, batch, M, N) fp32 and sums them in fixed order (needs dense C, no bias/alpha/beta). */
 int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA, const int32_t* a_idx,
               const float* B, int64_t b_rs, int64_t b_cs, int64_t sB,
               float* C, int64_t ldc, int64_t sC, const float* bias, int64_t sBias,
-              int64_t M, int64_t N, int64_t K, int batch, float alpha, float beta, void* stream);
+              int64_t M, int64_t N, int64_t K, int batch, float alpha, float beta,
+              int ksplit, float* part, void* stream);
 
 /* out[z, out_row0 + r, :] = tbl[z, idx[r], :]  (dataloader.py:140-144 teacher-embedding gather, done on
  * device from resident tables instead of on the host) */
@@ -133,11 +148,12 @@ int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, int64_t n_i
  * `n_model` encoders at once (student and/or frozen teachers), one workgroup per (impression, model).
  * vec: (n_model, R, D) fp32 row tables ; hidx (B,U) / cidx (B,C) int32 row ids ; mask (B,U) fp32.
  * params are stacked per model: pad (n_model,D), w1 (n_model,Q,D), b1 (n_model,Q), w2 (n_model,Q), b2 (n_model).
- * out: user (model z at user + z*user_stride, (B,D)), score (n_model,B,C), saved e (n_model,B,U,Q), alpha (n_model,B,U), den (n_model,B). */
+ * epre (n_model, B*U, Q) = fc1 pre-activations v W1^T + b1 of every history slot in position order (one batched
+ * tnr_sgemm) ; out: user (model z at user + z*user_stride, (B,D)), score (n_model,B,C), saved e (n_model,B,U,Q), alpha (n_model,B,U), den (n_model,B). */
 int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const int32_t* cidx, const float* mask,
                        const float* pad, const float* w1, const float* b1, const float* w2, const float* b2,
-                       int user_log_mask, float* user, int64_t user_stride, float* score, float* e, float* alpha,
-                       float* den, int n_model, int B, int U, int C, int D, int Q, void* stream);
+                       int user_log_mask, const float* epre, float* user, int64_t user_stride, float* score,
+                       float* e, float* alpha, float* den, int n_model, int B, int U, int C, int D, int Q, void* stream);
 /* backward of the student's user encoder: duser (B,D) -> dvec rows hidx (+=), and per-impression
  * partial parameter gradients part (B, Q*D + Q + Q + D + 1) laid out [w1|b1|w2|pad|b2]. */
 int tnr_user_bwd(const float* vec, const int32_t* hidx, const float* mask, const float* pad, const float* w1,

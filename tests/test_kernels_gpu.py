@@ -171,12 +171,14 @@ def test_layernorm_fwd_bwd(M):
     dx = torch.zeros((M, H), device=DEV, dtype=torch.bfloat16)
     dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
     part = torch.zeros(T.query("tnr_ln_bwd_part_elems", M, H), device=DEV)
-    T.call("tnr_ln_bwd", dev(dy, torch.bfloat16), dev(x, torch.bfloat16), st, dev(g), dx, dg, db, part, M, H)
+    dxs = torch.zeros(H, device=DEV)
+    T.call("tnr_ln_bwd", dev(dy, torch.bfloat16), dev(x, torch.bfloat16), st, dev(g), dx, dg, db, dxs, part, M, H)
     torch.cuda.synchronize()
     dxr, dgr, dbr = O.layer_norm_bwd(dy, cache, g)
     np.testing.assert_allclose(dx.float().cpu().numpy(), dxr, rtol=1e-2, atol=1e-2)
     np.testing.assert_allclose(dg.cpu().numpy(), dgr, rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(db.cpu().numpy(), dbr, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(dxs.cpu().numpy(), dx.float().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)   # fused bias grad
 
 
 def test_colsum_and_reduce():
@@ -232,7 +234,8 @@ def test_attention_fwd_bwd(N, L, A):
     # backward
     dctx = bf(rnd((N * L, A * d), 3))
     dqkv = torch.zeros((N * L, 3 * A * d), device=DEV, dtype=torch.bfloat16)
-    T.call("tnr_attn_l32_bwd", dev(qkv, torch.bfloat16), madd, relt, dev(dctx, torch.bfloat16), dqkv, N, L, A)
+    bpart = torch.zeros((N, 3 * A * d), device=DEV)
+    T.call("tnr_attn_l32_bwd", dev(qkv, torch.bfloat16), madd, relt, dev(dctx, torch.bfloat16), dqkv, bpart, N, L, A)
     torch.cuda.synchronize()
     dch = dctx.reshape(N, L, A, d).transpose(0, 2, 1, 3)
     dp = dch @ v.transpose(0, 1, 3, 2)
@@ -245,6 +248,7 @@ def test_attention_fwd_bwd(N, L, A):
     got = dqkv.float().cpu().numpy()
     scale = np.abs(want_d).max()
     np.testing.assert_allclose(got, want_d, rtol=3e-2, atol=3e-2 * scale)
+    np.testing.assert_allclose(bpart.sum(0).cpu().numpy(), got.sum(0), rtol=1e-3, atol=1e-3 * scale * N * L)   # fused bias grad
 
 
 # ------------------------------------------------------------------------------------------------ heads
@@ -269,7 +273,8 @@ def test_attpool_fwd_bwd():
     dyd = torch.zeros((N * L, H), device=DEV, dtype=torch.bfloat16)
     dpre = torch.ones((N * L, QP), device=DEV, dtype=torch.bfloat16)
     dw2p, db2p = torch.zeros((N, Q), device=DEV), torch.zeros(N, device=DEV)
-    T.call("tnr_attpool_bwd", yd, ed, QP, dev(w2[0]), Q, dev(dnv), alpha, den, dyd, dpre, QP, dw2p, db2p, N, L, H)
+    db1p = torch.zeros((N, QP), device=DEV)
+    T.call("tnr_attpool_bwd", yd, ed, QP, dev(w2[0]), Q, dev(dnv), alpha, den, dyd, dpre, QP, dw2p, db2p, db1p, N, L, H)
     torch.cuda.synchronize()
     direct = c["w"][..., None] * dnv[:, None, :]
     np.testing.assert_allclose(dyd.float().cpu().numpy(), direct.reshape(N * L, H), rtol=1e-2, atol=1e-3)
@@ -278,6 +283,7 @@ def test_attpool_fwd_bwd():
     got = dpre.float().cpu().numpy()
     np.testing.assert_allclose(got[:, :Q], dpre_ref.reshape(N * L, Q), rtol=1e-2, atol=1e-2 * np.abs(dpre_ref).max())
     assert (got[:, Q:] == 0).all()
+    np.testing.assert_allclose(db1p.sum(0).cpu().numpy(), got.sum(0), rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(dw2p.sum(0).cpu().numpy(), g2[0], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(db2p.sum().cpu().numpy(), gb2[0], rtol=1e-3, atol=1e-4)
 
@@ -286,16 +292,24 @@ def test_sgemm_variants():
     M, N, K, Z = 150, 200, 77, 3
     A, B, bias, C0 = rnd((Z, M, K), 1), rnd((Z, N, K), 2), rnd((Z, N), 3), rnd((Z, M, N), 4)
     c = dev(C0.copy())
-    T.call("tnr_sgemm", dev(A), K, 1, M * K, None, dev(B), K, 1, N * K, c, N, M * N, dev(bias), N, M, N, K, Z, 0.5, 2.0)
+    T.call("tnr_sgemm", dev(A), K, 1, M * K, None, dev(B), K, 1, N * K, c, N, M * N, dev(bias), N, M, N, K, Z, 0.5, 2.0, 1, None)
     torch.cuda.synchronize()
     want = 0.5 * np.einsum("zmk,znk->zmn", A, B) + bias[:, None, :] + 2.0 * C0
     np.testing.assert_allclose(c.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
     # transposed A (dW = dY^T X) : A(m,k) = dY[k, m]
     dY, X = rnd((300, 64), 5), rnd((300, 48), 6)
     c2 = torch.zeros((64, 48), device=DEV)
-    T.call("tnr_sgemm", dev(dY), 1, 64, 0, None, dev(X), 1, 48, 0, c2, 48, 0, None, 0, 64, 48, 300, 1, 1.0, 0.0)
+    T.call("tnr_sgemm", dev(dY), 1, 64, 0, None, dev(X), 1, 48, 0, c2, 48, 0, None, 0, 64, 48, 300, 1, 1.0, 0.0, 1, None)
     torch.cuda.synchronize()
     np.testing.assert_allclose(c2.cpu().numpy(), dY.T @ X, rtol=1e-4, atol=1e-4)
+    # split-K, batched (ragged last chunk)
+    dYb, Xb = rnd((3, 1000, 64), 7), rnd((3, 1000, 48), 8)
+    c3 = torch.zeros((3, 64, 48), device=DEV)
+    part = torch.zeros(8 * 3 * 64 * 48, device=DEV)
+    T.call("tnr_sgemm", dev(dYb), 1, 64, 1000 * 64, None, dev(Xb), 1, 48, 1000 * 48, c3, 48, 64 * 48, None, 0, 64, 48, 1000, 3,
+           1.0, 0.0, 8, part)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(c3.cpu().numpy(), np.einsum("zkm,zkn->zmn", dYb, Xb), rtol=1e-4, atol=1e-3)
 
 
 def _user_params(nm, D, Q, seed):
@@ -317,8 +331,9 @@ def test_user_score_fwd_bwd(ulm):
     user, score = torch.zeros((nm, B, D), device=DEV), torch.zeros((nm, B, C), device=DEV)
     e, alpha, den = torch.zeros((nm, B, U, Q), device=DEV), torch.zeros((nm, B, U), device=DEV), torch.zeros((nm, B), device=DEV)
     dv = {k: dev(v) for k, v in pr.items()}
+    epre = np.einsum("zrd,zqd->zrq", np.stack([vec[z][hidx.reshape(-1)] for z in range(nm)], 0), pr["w1"]) + pr["b1"][:, None, :]
     T.call("tnr_user_score_fwd", dev(vec), R, dev(hidx), dev(cidx), dev(mask), dv["pad"], dv["w1"], dv["b1"], dv["w2"],
-           dv["b2"], ulm, user, B * D, score, e, alpha, den, nm, B, U, C, D, Q)
+           dv["b2"], ulm, dev(epre.astype(np.float32)), user, B * D, score, e, alpha, den, nm, B, U, C, D, Q)
     torch.cuda.synchronize()
     caches = []
     for z in range(nm):
@@ -454,3 +469,33 @@ def test_refresh_shadows():
     assert np.array_equal(d1.float().cpu().numpy()[:200], bf(w1)) and (d1[200:] == 0).all()
     assert np.array_equal(d1t.float().cpu().numpy()[:, :200], bf(w1).T)
     assert np.array_equal(d2t.float().cpu().numpy()[:, :768], bf(w2).T)
+
+
+def test_gemm_colsum_epilogue_and_batched_colsum():
+    M, N, K = 700, 512, 128
+    A, B = bf(rnd((M, K), 1)), bf(rnd((N, K), 2, 0.1))
+    aux = bf(rnd((M, N), 3))
+    c = torch.zeros((M, N), device=DEV, dtype=torch.bfloat16)
+    rows = T.query("tnr_gemm_colsum_rows", M)
+    part = torch.full((rows, N), 7.0, device=DEV)
+    T.call("tnr_gemm_nt_ex", dev(A, torch.bfloat16), K, dev(B, torch.bfloat16), K, c, N, M, N, K, None, None, 0,
+           dev(aux, torch.bfloat16), N, T.EPI_MULDGELU | T.EPI_COLSUM, part)
+    out = torch.zeros(N, device=DEV)
+    T.call("tnr_reduce_rows", part, rows, N, N, out, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), c.float().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    X = rnd((3, 900, 256), 4)
+    o = torch.zeros((3, 256), device=DEV)
+    p2 = torch.zeros(3 * T.query("tnr_colsum_part_elems", 900, 256), device=DEV)
+    T.call("tnr_colsum_batched", dev(X), 256, 900 * 256, T.F32, 900, 256, 3, o, p2, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o.cpu().numpy(), X.sum(1), rtol=1e-4, atol=1e-3)
+
+
+def test_reduce_rows_shapes():
+    for rows, n in ((825, 1536), (1792, 1), (33, 200), (3, 70)):
+        x = rnd((rows, n), rows)
+        o = torch.ones(n, device=DEV)
+        T.call("tnr_reduce_rows", dev(x), rows, n, n, o, 1)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(o.cpu().numpy(), 1 + x.sum(0), rtol=1e-4, atol=1e-3)

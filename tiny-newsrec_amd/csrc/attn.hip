@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 // dQ = dS K / 8, dK = dS^T Q / 8.
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                        const float* __restrict__ rel, const bf16* __restrict__ dctx,
-                                                       bf16* __restrict__ dqkv, int64_t n_pairs, int L, int A) {
+                                                       bf16* __restrict__ dqkv, float* __restrict__ bias_part,
+                                                       int64_t n_pairs, int L, int A) {
     // per wave: K tile, dO tile, Q tile (each 4 KB, row-major [32][64]) + 256 B of row statistics
     __shared__ __attribute__((aligned(16))) char lds[4][3 * 4096 + 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -263,6 +264,29 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
             dk[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[s], tr_frag(tQ, s, ct, lane), dk[ct], 0, 0, 0);
         }
     }
+    // ---- bias gradient partials: column sums over the 32 token rows (rows >= L are exactly zero: padded
+    // queries have dO = 0 and padded keys have P = 0), summed from the bf16-rounded values
+    if (bias_part != nullptr && valid) {
+        float* bp = bias_part + n * ldq + a * 64 + (lane & 31);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            float sq = 0.f, sk = 0.f, sv = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sq += (float)(bf16)(dq[ct][r] * 0.125f);
+                sk += (float)(bf16)(dk[ct][r] * 0.125f);
+                sv += (float)(bf16)dv[ct][r];
+            }
+            sq += __shfl_xor(sq, 32, 64);
+            sk += __shfl_xor(sk, 32, 64);
+            sv += __shfl_xor(sv, 32, 64);
+            if (h == 0) {
+                bp[ct * 32] = sq;
+                bp[HD + ct * 32] = sk;
+                bp[2 * HD + ct * 32] = sv;
+            }
+        }
+    }
     // ---- stage the three gradient tiles (rows = token, cols = head dim) and store coalesced
     acc_to_lds(tK, dq[0], 0, lane, 0.125f);
     acc_to_lds(tK, dq[1], 1, lane, 0.125f);
@@ -297,14 +321,14 @@ extern "C" int tnr_attn_l32_fwd(const void* qkv, const float* mask_add, const fl
 }
 
 extern "C" int tnr_attn_l32_bwd(const void* qkv, const float* mask_add, const float* rel, const void* dctx, void* dqkv,
-                                int64_t n_seq, int L, int A, void* stream) {
+                                float* bias_part, int64_t n_seq, int L, int A, void* stream) {
     TNR_CHECK_ARG(qkv && mask_add && rel && dctx && dqkv, "tnr_attn_l32_bwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 32 && A >= 1 && n_seq >= 1, "tnr_attn_l32_bwd: need 1<=L<=32");
     TNR_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)dctx % 16) == 0 && ((uintptr_t)dqkv % 16) == 0,
                   "tnr_attn_l32_bwd: 16-byte alignment");
     int64_t pairs = n_seq * A;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)qkv, mask_add, rel, (const bf16*)dctx, (bf16*)dqkv, pairs, L, A);
+                       (const bf16*)qkv, mask_add, rel, (const bf16*)dctx, (bf16*)dqkv, bias_part, pairs, L, A);
     TNR_CHECK_LAUNCH("tnr_attn_l32_bwd");
     return TNR_OK;
 }

@@ -24,6 +24,7 @@ struct NTArgs {
     const bf16* res; int64_t ldres;
     bf16* aux; int64_t ldaux;
     int flags;
+    float* colsum_part;        // TNR_EPI_COLSUM: (rows_of_partials, N) fp32, one row per 64-row strip of C
 };
 
 constexpr int TILE_BYTES = 128 * 128;   // one operand tile: 128 rows x 64 bf16
@@ -57,6 +58,7 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& g, f32x4 (&acc)[4][4],
     for (int j = 0; j < 4; ++j) {
         const int n = n_base + j * 16;
         f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 cs = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (flags & TNR_EPI_BIAS) bv = *(const f32x4*)(g.bias + n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -92,9 +94,25 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& g, f32x4 (&acc)[4][4],
             } else {
                 bf16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = (bf16)v[r];
+                    cs[r] += (float)o[r];
+                }
                 *(bf16x4*)((bf16*)g.C + (int64_t)m * g.ldc + n) = o;
             }
+        }
+        if (flags & TNR_EPI_COLSUM) {
+            // column sums of this wave's 64-row strip: 16 lanes (lane & 15) hold the 16 rows of each tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = cs[r];
+                t += __shfl_xor(t, 1, 64);
+                t += __shfl_xor(t, 2, 64);
+                t += __shfl_xor(t, 4, 64);
+                t += __shfl_xor(t, 8, 64);
+                cs[r] = t;
+            }
+            if ((threadIdx.x & 15) == 0) *(f32x4*)(g.colsum_part + (int64_t)(m_base >> 6) * g.N + n) = cs;
         }
     }
 }
@@ -664,9 +682,21 @@ __global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int
 
 }  // namespace
 
+extern "C" int tnr_gemm_nt_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                              int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                              void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream);
+
 extern "C" int tnr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                            int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                            void* aux, int64_t ldaux, int flags, void* stream) {
+    return tnr_gemm_nt_ex(A, lda, B, ldb, C, ldc, M, N, K, bias, res, ldres, aux, ldaux, flags, nullptr, stream);
+}
+
+extern "C" int64_t tnr_gemm_colsum_rows(int64_t M) { return ((M + 255) / 256) * 4; }
+
+extern "C" int tnr_gemm_nt_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                              int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                              void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream) {
     TNR_CHECK_ARG(A && B && C, "tnr_gemm_nt: null operand");
     TNR_CHECK_ARG(M >= 1 && N >= 128 && (N % 128) == 0 && K >= 64 && (K % 64) == 0,
                   "tnr_gemm_nt: need N%%128==0, K%%64==0 (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
@@ -679,8 +709,10 @@ extern "C" int tnr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
     TNR_CHECK_ARG(!(flags & (TNR_EPI_MULDGELU | TNR_EPI_AUXOUT)) || (aux && (ldaux % 4) == 0),
                   "tnr_gemm_nt: aux required");
     TNR_CHECK_ARG(M < (1 << 24), "tnr_gemm_nt: M too large");
+    TNR_CHECK_ARG(!(flags & TNR_EPI_COLSUM) || (colsum_part && !(flags & TNR_EPI_OUTF32) && M > 128),
+                  "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags};
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part};
     static const char* ver_s = getenv("TNR_GEMM_VER");
     static const int ver = ver_s ? atoi(ver_s) : 3;
     static const char* probe_s = getenv("TNR_GEMM_PROBE");

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const bf16* __restrict
                                                           const float* __restrict__ dnv, const float* __restrict__ alpha,
                                                           bf16* __restrict__ dy, bf16* __restrict__ dpre, int64_t lddpre,
                                                           float* __restrict__ dw2_part, float* __restrict__ db2_part,
-                                                          int L, int H) {
+                                                          float* __restrict__ db1_part, int L, int H) {
     __shared__ float dw[32], da[32];
     const int64_t n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -75,14 +75,17 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const bf16* __restrict
         }
     }
     for (int q = tid; q < lddpre; q += 256) {
-        float sw2 = 0.f;
+        float sw2 = 0.f, sb1 = 0.f;
         float wq = q < Q ? w2[q] : 0.f;
         for (int i = 0; i < L; ++i) {
             float ev = q < Q ? e[(n * L + i) * lde + q] : 0.f;
-            dpre[(n * L + i) * lddpre + q] = (bf16)(da[i] * wq * (1.f - ev * ev));
+            bf16 dv = (bf16)(da[i] * wq * (1.f - ev * ev));
+            dpre[(n * L + i) * lddpre + q] = dv;
+            sb1 += (float)dv;
             sw2 += da[i] * ev;
         }
         if (q < Q) dw2_part[n * Q + q] = sw2;
+        if (db1_part) db1_part[n * lddpre + q] = sb1;
     }
     if (tid == 0) {
         float s = 0.f;
@@ -100,33 +103,48 @@ struct SgemmArgs {
     const float* bias; int64_t sBias;
     int M, N, K;
     float alpha, beta;
+    int ksplit, kchunk, batch;      // ksplit > 1: C = partials (ksplit, batch, M, N), no bias / beta
 };
 
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
     __shared__ float As[64][17], Bs[64][17];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    const int z = blockIdx.z;
-    const float* A = g.A + z * g.sA;
-    const float* B = g.B + z * g.sB;
-    float* C = g.C + z * g.sC;
+    const int zb = blockIdx.z / g.ksplit, zk = blockIdx.z - zb * g.ksplit;
+    const float* A = g.A + zb * g.sA;
+    const float* B = g.B + zb * g.sB;
+    float* C = g.ksplit > 1 ? g.C + ((int64_t)zk * g.batch + zb) * g.M * g.N : g.C + zb * g.sC;
+    const int64_t ldc = g.ksplit > 1 ? g.N : g.ldc;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = zk * g.kchunk;
+    const int kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool a_kfast = g.a_cs == 1, b_kfast = g.b_cs == 1;
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
+    int ra[4], ka[4], rb[4], kb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int idx = tid + 256 * q;
+        ra[q] = a_kfast ? idx >> 4 : idx & 63; ka[q] = a_kfast ? idx & 15 : idx >> 6;
+        rb[q] = b_kfast ? idx >> 4 : idx & 63; kb[q] = b_kfast ? idx & 15 : idx >> 6;
+    }
+    float av[4], bv[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int idx = tid + 256 * q;
-            int ra = a_kfast ? idx >> 4 : idx & 63, ka = a_kfast ? idx & 15 : idx >> 6;
-            int rb = b_kfast ? idx >> 4 : idx & 63, kb = b_kfast ? idx & 15 : idx >> 6;
-            float av = 0.f, bv = 0.f;
-            if (m0 + ra < g.M && k0 + ka < g.K) av = A[(int64_t)(m0 + ra) * g.a_rs + (int64_t)(k0 + ka) * g.a_cs];
-            if (n0 + rb < g.N && k0 + kb < g.K) bv = B[(int64_t)(n0 + rb) * g.b_rs + (int64_t)(k0 + kb) * g.b_cs];
-            As[ra][ka] = av;
-            Bs[rb][kb] = bv;
+            av[q] = (m0 + ra[q] < g.M && k0 + ka[q] < kend) ? A[(int64_t)(m0 + ra[q]) * g.a_rs + (int64_t)(k0 + ka[q]) * g.a_cs] : 0.f;
+            bv[q] = (n0 + rb[q] < g.N && k0 + kb[q] < kend) ? B[(int64_t)(n0 + rb[q]) * g.b_rs + (int64_t)(k0 + kb[q]) * g.b_cs] : 0.f;
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            As[ra[q]][ka[q]] = av[q];
+            Bs[rb[q]][kb[q]] = bv[q];
         }
         __syncthreads();
+        if (k0 + 16 < kend) fetch(k0 + 16);          // next tile's global loads fly under the MFMAs
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
             float a = As[wm * 32 + (lane & 31)][kk + (lane >> 5)];
@@ -137,15 +155,19 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
     }
     const int n = n0 + wn * 32 + (lane & 31);
     if (n >= g.N) return;
-    const float bv = g.bias ? g.bias[z * g.sBias + n] : 0.f;
+    const float bias = (g.bias && g.ksplit == 1) ? g.bias[zb * g.sBias + n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < g.M) {
-            float v = g.alpha * acc[r] + bv;
-            float* c = C + (int64_t)m * g.ldc + n;
-            if (g.beta != 0.f) v += g.beta * *c;
-            *c = v;
+            float* c = C + (int64_t)m * ldc + n;
+            if (g.ksplit > 1) {
+                *c = acc[r];
+            } else {
+                float v = g.alpha * acc[r] + bias;
+                if (g.beta != 0.f) v += g.beta * *c;
+                *c = v;
+            }
         }
     }
 }
@@ -184,17 +206,21 @@ __device__ __forceinline__ void load_hv(float* hv, const float* vec, const int32
     }
 }
 
+// fc1 of the additive attention is done beforehand as one batched GEMM over all (impression, slot) rows
+// (epre = v W1^T + b1, position order b*U+u); slots replaced by pad_doc (user_log_mask False) take fc1(pad).
 __global__ __launch_bounds__(256) void user_score_fwd_kernel(
     const float* __restrict__ vec, int64_t R, const int32_t* __restrict__ hidx, const int32_t* __restrict__ cidx,
     const float* __restrict__ mask, const float* __restrict__ pad, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int user_log_mask,
-    float* __restrict__ user, int64_t user_stride, float* __restrict__ score, float* __restrict__ e_out,
-    float* __restrict__ alpha, float* __restrict__ den, int B, int U, int C, int D, int Q) {
+    const float* __restrict__ epre, float* __restrict__ user, int64_t user_stride, float* __restrict__ score,
+    float* __restrict__ e_out, float* __restrict__ alpha, float* __restrict__ den, int B, int U, int C, int D, int Q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hv = (float*)smem;                 // [U][D]
     float* es = hv + U * D;                   // [U][Q]
     float* al = es + U * Q;                   // [MAXU]
     float* us = al + MAXU;                    // [D]
+    float* epad = us + D;                     // [Q]
+    int& any_pad = *(int*)(epad + Q);         // all LDS in the dynamic region (static LDS would eat into the 160 KB cap)
     const int b = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     vec += (int64_t)z * R * D;
     pad += (int64_t)z * D;
@@ -204,31 +230,33 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
     hidx += (int64_t)b * U;
     cidx += (int64_t)b * C;
     mask += (int64_t)b * U;
+    epre += ((int64_t)z * B + b) * U * Q;
+    if (tid == 0) {
+        int a = 0;
+        if (!user_log_mask)
+            for (int u = 0; u < U; ++u) a |= (mask[u] == 0.f);
+        any_pad = a;
+    }
     load_hv<true>(hv, vec, hidx, mask, pad, user_log_mask, U, D, tid);
     __syncthreads();
-    // fc1 + tanh: thread q keeps U accumulators; hv rows are LDS broadcasts
-    for (int q = tid; q < Q; q += 256) {
-        float acc[MAXU];
-#pragma unroll
-        for (int u = 0; u < MAXU; ++u) acc[u] = 0.f;
-        const float* wr = w1 + (int64_t)q * D;
-        for (int d = 0; d < D; d += 4) {
-            f32x4 wv = *(const f32x4*)(wr + d);
-#pragma unroll
-            for (int u = 0; u < MAXU; ++u)
-                if (u < U) {
-                    f32x4 h = *(const f32x4*)(hv + u * D + d);
-                    acc[u] += h[0] * wv[0] + h[1] * wv[1] + h[2] * wv[2] + h[3] * wv[3];
-                }
-        }
-        float bq = b1[q];
-#pragma unroll
-        for (int u = 0; u < MAXU; ++u)
-            if (u < U) {
-                float ev = tanhf(acc[u] + bq);
-                es[u * Q + q] = ev;
-                e_out[(((int64_t)z * B + b) * U + u) * Q + q] = ev;
+    if (any_pad) {
+        for (int q = tid; q < Q; q += 256) {
+            const float* wr = w1 + (int64_t)q * D;
+            float s = 0.f;
+            for (int d = 0; d < D; d += 4) {
+                f32x4 wv = *(const f32x4*)(wr + d), pv = *(const f32x4*)(pad + d);
+                s += wv[0] * pv[0] + wv[1] * pv[1] + wv[2] * pv[2] + wv[3] * pv[3];
             }
+            epad[q] = s + b1[q];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < U * Q; idx += 256) {
+        int u = idx / Q, q = idx - u * Q;
+        float pre = (user_log_mask || mask[u] != 0.f) ? epre[idx] : epad[q];
+        float ev = tanhf(pre);
+        es[idx] = ev;
+        e_out[(((int64_t)z * B + b) * U) * Q + idx] = ev;
     }
     __syncthreads();
     for (int u = w; u < U; u += 4) {
@@ -497,27 +525,40 @@ extern "C" int tnr_attpool_fwd(const void* y, const float* e, int64_t lde, const
 
 extern "C" int tnr_attpool_bwd(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
                                const float* alpha, const float* den, void* dy_direct, void* dpre, int64_t lddpre,
-                               float* dw2_part, float* db2_part, int64_t n_seq, int L, int H, void* stream) {
+                               float* dw2_part, float* db2_part, float* db1_part, int64_t n_seq, int L, int H, void* stream) {
     (void)den;
     TNR_CHECK_ARG(y && e && w2 && dnv && alpha && dy_direct && dpre && dw2_part && db2_part, "tnr_attpool_bwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 32 && (H % 4) == 0 && Q >= 1 && lde >= Q && lddpre >= Q && n_seq >= 1,
                   "tnr_attpool_bwd: bad shape");
     hipLaunchKernelGGL(attpool_bwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, e,
-                       lde, w2, Q, dnv, alpha, (bf16*)dy_direct, (bf16*)dpre, lddpre, dw2_part, db2_part, L, H);
+                       lde, w2, Q, dnv, alpha, (bf16*)dy_direct, (bf16*)dpre, lddpre, dw2_part, db2_part, db1_part, L, H);
     TNR_CHECK_LAUNCH("tnr_attpool_bwd");
     return TNR_OK;
 }
 
+extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
+                               void* stream);
+
 extern "C" int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA, const int32_t* a_idx, const float* B,
                          int64_t b_rs, int64_t b_cs, int64_t sB, float* C, int64_t ldc, int64_t sC, const float* bias,
                          int64_t sBias, int64_t M, int64_t N, int64_t K, int batch, float alpha, float beta,
-                         void* stream) {
+                         int ksplit, float* part, void* stream) {
     TNR_CHECK_ARG(A && B && C && M >= 1 && N >= 1 && K >= 1 && batch >= 1, "tnr_sgemm: bad argument");
     TNR_CHECK_ARG(a_idx == nullptr, "tnr_sgemm: row gather is done by tnr_gather_rows");
-    SgemmArgs g{A, a_rs, a_cs, sA, B, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, (int)M, (int)N, (int)K, alpha, beta};
-    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)batch);
+    if (ksplit < 1) ksplit = 1;
+    int kchunk = (int)K;
+    if (ksplit > 1) {
+        TNR_CHECK_ARG(part && bias == nullptr && alpha == 1.0f && beta == 0.0f && ldc == N && (batch == 1 || sC == M * N),
+                      "tnr_sgemm: split-K needs a partial buffer, dense C, no bias/alpha/beta");
+        kchunk = (int)(((K + ksplit - 1) / ksplit + 15) / 16 * 16);
+        ksplit = (int)((K + kchunk - 1) / kchunk);
+    }
+    SgemmArgs g{A, a_rs, a_cs, sA, B, b_rs, b_cs, sB, ksplit > 1 ? part : C, ldc, sC, bias, sBias, (int)M, (int)N, (int)K,
+                alpha, beta, ksplit, kchunk, batch};
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(batch * ksplit));
     hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     TNR_CHECK_LAUNCH("tnr_sgemm");
+    if (ksplit > 1) return tnr_reduce_rows(part, ksplit, (int64_t)batch * M * N, (int64_t)batch * M * N, C, 0, stream);
     return TNR_OK;
 }
 
@@ -538,14 +579,14 @@ static int user_shape_ok(int B, int U, int C, int D, int Q) {
 
 extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const int32_t* cidx,
                                   const float* mask, const float* pad, const float* w1, const float* b1, const float* w2,
-                                  const float* b2, int user_log_mask, float* user, int64_t user_stride, float* score,
-                                  float* e, float* alpha, float* den, int n_model, int B, int U, int C, int D, int Q,
-                                  void* stream) {
-    TNR_CHECK_ARG(vec && hidx && cidx && mask && pad && w1 && b1 && w2 && b2 && user && score && e && alpha && den,
+                                  const float* b2, int user_log_mask, const float* epre, float* user, int64_t user_stride,
+                                  float* score, float* e, float* alpha, float* den, int n_model, int B, int U, int C, int D,
+                                  int Q, void* stream) {
+    TNR_CHECK_ARG(vec && hidx && cidx && mask && pad && w1 && b1 && w2 && b2 && epre && user && score && e && alpha && den,
                   "tnr_user_score_fwd: null pointer");
     TNR_CHECK_ARG(user_shape_ok(B, U, C, D, Q) && n_model >= 1 && user_stride >= (int64_t)B * D,
                   "tnr_user_score_fwd: bad shape (U <= %d)", MAXU);
-    size_t lds = sizeof(float) * ((size_t)U * D + (size_t)U * Q + MAXU + D);
+    size_t lds = sizeof(float) * ((size_t)U * D + (size_t)U * Q + MAXU + D + Q + 4);
     TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_score_fwd: U*D + U*Q too large for LDS");
     static bool attr_set = false;
     if (!attr_set) {
@@ -553,8 +594,8 @@ extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hi
         attr_set = true;
     }
     hipLaunchKernelGGL(user_score_fwd_kernel, dim3((unsigned)B, (unsigned)n_model), dim3(256), lds, (hipStream_t)stream,
-                       vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, user, user_stride, score, e, alpha, den,
-                       B, U, C, D, Q);
+                       vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, epre, user, user_stride, score, e, alpha,
+                       den, B, U, C, D, Q);
     TNR_CHECK_LAUNCH("tnr_user_score_fwd");
     return TNR_OK;
 }
@@ -590,8 +631,7 @@ extern "C" int tnr_kd_score_loss(const float* s_score, const float* t_score, con
     return TNR_OK;
 }
 
-extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
-                               void* stream);
+
 
 extern "C" int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* loss, float* dS, float* dP,
                                  float* part, int B, int U, int C, int D, int T, void* stream) {

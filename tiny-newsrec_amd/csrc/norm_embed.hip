@@ -104,15 +104,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ xi
 }
 
 // dx = rstd * (dxh - mean(dxh) - xh * mean(dxh*xh)), dxh = dy*gamma ; per-block partial dgamma/dbeta
-constexpr int LNB_ROWS = 64;   // rows per block (4 waves x 16 rows)
+constexpr int LNB_ROWS = 128;  // rows per block (4 waves x 32 rows)
 template <int V>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ xin,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      bf16* __restrict__ dx, float* __restrict__ part, int64_t M) {
     const int H = 256 * V;
-    __shared__ float red[4][2][256 * V];
+    __shared__ float red[4][3][256 * V];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float gm[V][4], dg[V][4], db[V][4];
+    float gm[V][4], dg[V][4], db[V][4], dxs[V][4];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         f32x4 t = *(const f32x4*)(gamma + v * 256 + lane * 4);
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             gm[v][r] = t[r];
             dg[v][r] = 0.f;
             db[v][r] = 0.f;
+            dxs[v][r] = 0.f;
         }
     }
     for (int it = 0; it < LNB_ROWS / 4; ++it) {
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         for (int v = 0; v < V; ++v) {
             bf16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16)(rstd * (g[v][r] - s1 - xh[v][r] * s2));
+            for (int r = 0; r < 4; ++r) {
+                o[r] = (bf16)(rstd * (g[v][r] - s1 - xh[v][r] * s2));
+                dxs[v][r] += (float)o[r];          // the rounded value the wgrad kernels will see
+            }
             *(bf16x4*)(dx + m * H + v * 256 + lane * 4) = o;
         }
     }
@@ -161,37 +165,54 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         for (int r = 0; r < 4; ++r) {
             red[w][0][v * 256 + lane * 4 + r] = dg[v][r];
             red[w][1][v * 256 + lane * 4 + r] = db[v][r];
+            red[w][2][v * 256 + lane * 4 + r] = dxs[v][r];
         }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * H; c += 256) {
+    for (int c = threadIdx.x; c < 3 * H; c += 256) {
         int k = c / H, h = c - k * H;
-        part[(int64_t)blockIdx.x * 2 * H + c] = red[0][k][h] + red[1][k][h] + red[2][k][h] + red[3][k][h];
+        part[(int64_t)blockIdx.x * 3 * H + c] = red[0][k][h] + red[1][k][h] + red[2][k][h] + red[3][k][h];
     }
 }
 
-// fixed-order sum over rows of a (rows, stride) fp32 matrix
-__global__ void reduce_rows_kernel(const float* __restrict__ part, int64_t rows, int64_t stride, int64_t n,
-                                   float* __restrict__ out, int accumulate) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int64_t r = 0;
-    for (; r + 4 <= rows; r += 4) {
-        s0 += part[r * stride + i];
-        s1 += part[(r + 1) * stride + i];
-        s2 += part[(r + 2) * stride + i];
-        s3 += part[(r + 3) * stride + i];
+// fixed-order sum over rows of a (rows, stride) fp32 matrix.  Wide outputs: block = 64 columns x 4 row lanes
+// (each lane a strided subsequence, combined in a fixed order).  Narrow outputs (n < 64): one block per column.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int64_t rows, int64_t stride,
+                                                          int64_t n, float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (i < n)
+        for (int64_t r = rl; r < rows; r += 4) s += part[r * stride + i];
+    red[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && i < n) {
+        float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        out[i] = accumulate ? out[i] + t : t;
     }
-    for (; r < rows; ++r) s0 += part[r * stride + i];
-    float s = (s0 + s1) + (s2 + s3);
-    out[i] = accumulate ? out[i] + s : s;
+}
+__global__ __launch_bounds__(256) void reduce_rows_narrow_kernel(const float* __restrict__ part, int64_t rows,
+                                                                 int64_t stride, float* __restrict__ out, int accumulate) {
+    __shared__ float red[256];
+    const int64_t i = blockIdx.x;
+    float s = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) s += part[r * stride + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = accumulate ? out[i] + red[0] : red[0];
 }
 
 // column sums: block (256 threads) owns 256 columns? no: 64 columns x 4 row-lanes, CS_ROWS rows per block
 constexpr int CS_ROWS = 512;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
-                                                     float* __restrict__ part) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Xb, int64_t ldx, int64_t M, int64_t N,
+                                                     float* __restrict__ partb, int64_t sX, int64_t sPart) {
+    const T* X = Xb + (int64_t)blockIdx.z * sX;
+    float* part = partb + (int64_t)blockIdx.z * sPart;
     // thread handles 4 consecutive columns; 64 threads across 256 columns, 4 row groups
     __shared__ float red[4][256];
     const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
     __syncthreads();
     int t = threadIdx.x;
     int64_t col = (int64_t)blockIdx.x * 256 + t;
-    if (col < N) part[(int64_t)blockIdx.y * N + col] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    if (col < N) part[(int64_t)blockIdx.y * gridDim.z * N + col] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
 
 // tnlrv3/modeling.py:345-373 bucket (integer edges, see oracle) + the Linear(32->A) lookup of :462-463
@@ -306,49 +327,64 @@ extern "C" int tnr_ln_fwd(const void* x, const float* gamma, const float* beta, 
     return TNR_OK;
 }
 
-extern "C" int64_t tnr_ln_bwd_part_elems(int64_t M, int H) { return ((M + LNB_ROWS - 1) / LNB_ROWS) * 2 * H; }
+extern "C" int64_t tnr_ln_bwd_part_elems(int64_t M, int H) { return ((M + LNB_ROWS - 1) / LNB_ROWS) * 3 * H; }
 
 extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
                                void* stream) {
     TNR_CHECK_ARG(part && out && rows >= 1 && n >= 1, "tnr_reduce_rows: bad argument");
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
-                       rows, stride, n, out, accumulate);
+    if (n < 64 && rows >= 256)
+        hipLaunchKernelGGL(reduce_rows_narrow_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, part, rows,
+                           stride, out, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, part,
+                           rows, stride, n, out, accumulate);
     TNR_CHECK_LAUNCH("tnr_reduce_rows");
     return TNR_OK;
 }
 
 extern "C" int tnr_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
-                          float* dgamma, float* dbeta, float* part, int64_t M, int H, void* stream) {
+                          float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream) {
     TNR_CHECK_ARG(dy && x && stats && gamma && dx && M >= 1, "tnr_ln_bwd: null pointer");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_ln_bwd: H must be 256/512/768/1024");
-    TNR_CHECK_ARG(!(dgamma || dbeta) || part, "tnr_ln_bwd: part workspace required for dgamma/dbeta");
+    TNR_CHECK_ARG(!(dgamma || dbeta || dxsum) || part, "tnr_ln_bwd: part workspace required for dgamma/dbeta/dxsum");
     int64_t nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
     dim3 grid((unsigned)nblk), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    float* p = (dgamma || dbeta) ? part : nullptr;
+    float* p = (dgamma || dbeta || dxsum) ? part : nullptr;
 #define LAUNCH(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, blk, 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, p, M)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     TNR_CHECK_LAUNCH("tnr_ln_bwd");
-    if (dgamma) { int rc = tnr_reduce_rows(part, nblk, 2 * H, H, dgamma, 0, stream); if (rc) return rc; }
-    if (dbeta) { int rc = tnr_reduce_rows(part + H, nblk, 2 * H, H, dbeta, 0, stream); if (rc) return rc; }
+    if (dgamma && dbeta == dgamma + H) {       // adjacent in the flat gradient buffer: one reduction
+        int rc = tnr_reduce_rows(part, nblk, 3 * H, 2 * H, dgamma, 0, stream); if (rc) return rc;
+    } else {
+        if (dgamma) { int rc = tnr_reduce_rows(part, nblk, 3 * H, H, dgamma, 0, stream); if (rc) return rc; }
+        if (dbeta) { int rc = tnr_reduce_rows(part + H, nblk, 3 * H, H, dbeta, 0, stream); if (rc) return rc; }
+    }
+    if (dxsum) { int rc = tnr_reduce_rows(part + 2 * H, nblk, 3 * H, H, dxsum, 0, stream); if (rc) return rc; }
     return TNR_OK;
 }
 
 extern "C" int64_t tnr_colsum_part_elems(int64_t M, int64_t N) { return ((M + CS_ROWS - 1) / CS_ROWS) * N; }
 
-extern "C" int tnr_colsum(const void* X, int64_t ldx, int dtype, int64_t M, int64_t N, float* out, float* part,
-                          int accumulate, void* stream) {
-    TNR_CHECK_ARG(X && out && part && M >= 1 && N >= 4 && (N % 4) == 0 && (ldx % 4) == 0, "tnr_colsum: bad argument");
+extern "C" int tnr_colsum_batched(const void* X, int64_t ldx, int64_t sX, int dtype, int64_t M, int64_t N, int batch,
+                                  float* out, float* part, int accumulate, void* stream) {
+    TNR_CHECK_ARG(X && out && part && M >= 1 && N >= 4 && (N % 4) == 0 && (ldx % 4) == 0 && batch >= 1, "tnr_colsum: bad argument");
     TNR_CHECK_ARG(dtype == TNR_BF16 || dtype == TNR_F32, "tnr_colsum: dtype");
     int64_t nby = (M + CS_ROWS - 1) / CS_ROWS;
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nby), blk(256);
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nby, (unsigned)batch), blk(256);
+    // partials laid out (nby, batch, N) so that ONE row reduction yields out (batch, N)
     if (dtype == TNR_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, blk, 0, (hipStream_t)stream, (const bf16*)X, ldx, M, N, part);
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, blk, 0, (hipStream_t)stream, (const bf16*)X, ldx, M, N, part, sX, N);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)X, ldx, M, N, part);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)X, ldx, M, N, part, sX, N);
     TNR_CHECK_LAUNCH("tnr_colsum");
-    return tnr_reduce_rows(part, nby, N, N, out, accumulate, stream);
+    return tnr_reduce_rows(part, nby, (int64_t)batch * N, (int64_t)batch * N, out, accumulate, stream);
+}
+
+extern "C" int tnr_colsum(const void* X, int64_t ldx, int dtype, int64_t M, int64_t N, float* out, float* part,
+                          int accumulate, void* stream) {
+    return tnr_colsum_batched(X, ldx, 0, dtype, M, N, 1, out, part, accumulate, stream);
 }
 
 extern "C" int tnr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {

@@ -322,25 +322,40 @@ class Engine:
         self.du = z(Mp, I)
         self.dqkv = z(Mp, 3 * H)
         self.ln_part = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
-        self.cs_part = f(T.query("tnr_colsum_part_elems", Mp, max(I, 3 * H)))
-        self.splits = 8
-        self.ws = f(T.query("tnr_gemm_tn_ws_elems", max(3 * H, I), H, self.splits))
+        self.cs_part = f(max(T.query("tnr_colsum_part_elems", Mp, QPAD), T_ * T.query("tnr_colsum_part_elems", Rt, D)))
+        self.gcs_part = f(T.query("tnr_gemm_colsum_rows", Mp), I)        # b1 gradient partials from the dgrad epilogue
+        self.qkvb_part = f(N, 3 * H)                                       # q/k/v bias gradient partials from attention bwd
+        self.db1p = f(N, QPAD)
+        self.epre_u = f(B * cfg.U, cfg.Qu)
+        self.epre_t = f(T_, B * cfg.U, cfg.Qu)
+        self.KS = 8                                                        # split-K of the long-K small GEMMs
+        self.sg_part = f(self.KS * max(T_ * D * D, D * H))
+        self.ws = f(max(self._wgrad_splits(n_, k_)[1] for n_, k_ in ((3 * H, H), (H, H), (I, H), (H, I), (QPAD, H))))
+
+    @staticmethod
+    def _wgrad_splits(N, K):
+        """-> (splits, workspace elems): about two waves of 256-thread... workgroups on the 256 CUs."""
+        tiles = (N // 256) * (K // 256) if (N % 256 == 0 and K % 256 == 0) else (N // 128) * (K // 128)
+        splits = max(1, min(64, 512 // max(tiles, 1)))
+        return splits, T.query("tnr_gemm_tn_ws_elems", N, K, splits)
 
     # ------------------------------------------------------------------ kernel wrappers
-    def _gemm(self, a, w, c, M, bias=None, res=None, aux=None, flags=0):
+    def _gemm(self, a, w, c, M, bias=None, res=None, aux=None, flags=0, colsum=None):
         N, K = w.shape
-        T.call("tnr_gemm_nt", a, a.stride(0), w, w.stride(0), c, c.stride(0), M, N, K, bias, res,
-               res.stride(0) if res is not None else 0, aux, aux.stride(0) if aux is not None else 0, flags)
+        T.call("tnr_gemm_nt_ex", a, a.stride(0), w, w.stride(0), c, c.stride(0), M, N, K, bias, res,
+               res.stride(0) if res is not None else 0, aux, aux.stride(0) if aux is not None else 0, flags, colsum)
 
     def _wgrad(self, dy, x, dw, M):
         N, K = dw.shape
-        T.call("tnr_gemm_tn_wgrad", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws, self.splits, 0)
+        T.call("tnr_gemm_tn_wgrad", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws,
+               self._wgrad_splits(N, K)[0], 0)
 
     def _colsum(self, x, out, M, dtype=T.BF16):
         T.call("tnr_colsum", x, x.stride(0), dtype, M, x.shape[1], out, self.cs_part, 0)
 
-    def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, beta=0.0):
-        T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, 1.0, beta)
+    def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, ksplit=1):
+        T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, 1.0, 0.0,
+               ksplit, self.sg_part if ksplit > 1 else None)
 
     # ------------------------------------------------------------------ forward
     def encode(self, tok, n_seq, nidx=None):
@@ -427,9 +442,13 @@ class Engine:
         hidx, cidx = self._idx(B)
         ue = "student.user_encoder."
         g = self.p
+        Qu = cfg.Qu
+        self._sgemm(S, D, 1, 0, g(ue + "attn.att_fc1.weight"), D, 1, 0, self.epre_u, Qu, 0, g(ue + "attn.att_fc1.bias"), 0,
+                    B * U, Qu, D)
         T.call("tnr_user_score_fwd", S, Rt, hidx, cidx, self.mask, g(ue + "pad_doc"), g(ue + "attn.att_fc1.weight"),
                g(ue + "attn.att_fc1.bias"), g(ue + "attn.att_fc2.weight"), g(ue + "attn.att_fc2.bias"),
-               int(cfg.user_log_mask), S[N:], B * D, self.score, self.e_u, self.alpha_u, self.den_u, 1, B, U, C, D, cfg.Qu)
+               int(cfg.user_log_mask), self.epre_u, S[N:], B * D, self.score, self.e_u, self.alpha_u, self.den_u, 1, B, U, C,
+               D, Qu)
         if T_ > 0:
             X = self.X[:, :Rt]
             if teacher_tables is not None:
@@ -439,13 +458,15 @@ class Engine:
                 for i in range(T_):
                     self.X[i, :B * U].copy_(teacher_hist[i].reshape(B * U, D))
                     self.X[i, B * U:N].copy_(teacher_cand[i].reshape(B * C, D))
-            w1 = self._view("teachers.0.attn.att_fc1.weight", T_ * cfg.Qu * D, (T_, cfg.Qu, D))
+            w1 = self._view("teachers.0.attn.att_fc1.weight", T_ * Qu * D, (T_, Qu, D))
+            b1 = self._view("teachers.0.attn.att_fc1.bias", T_ * Qu, (T_, Qu))
+            self._sgemm(self.X, D, 1, self.X.stride(0), w1, D, 1, Qu * D, self.epre_t, Qu, B * U * Qu, b1, Qu, B * U, Qu, D,
+                        batch=T_)
             T.call("tnr_user_score_fwd", self.X, self.X.shape[1], hidx, cidx, self.mask,
-                   self._view("teachers.0.pad_doc", T_ * D, (T_, D)), w1,
-                   self._view("teachers.0.attn.att_fc1.bias", T_ * cfg.Qu, (T_, cfg.Qu)),
-                   self._view("teachers.0.attn.att_fc2.weight", T_ * cfg.Qu, (T_, cfg.Qu)),
-                   self._view("teachers.0.attn.att_fc2.bias", T_, (T_,)), int(cfg.user_log_mask),
-                   self.X[0, N:], self.X.stride(0), self.t_score, self.e_t, self.alpha_t, self.den_t, T_, B, U, C, D, cfg.Qu)
+                   self._view("teachers.0.pad_doc", T_ * D, (T_, D)), w1, b1,
+                   self._view("teachers.0.attn.att_fc2.weight", T_ * Qu, (T_, Qu)),
+                   self._view("teachers.0.attn.att_fc2.bias", T_, (T_,)), int(cfg.user_log_mask), self.epre_t,
+                   self.X[0, N:], self.X.stride(0), self.t_score, self.e_t, self.alpha_t, self.den_t, T_, B, U, C, D, Qu)
         T.call("tnr_kd_score_loss", self.score, self.t_score if T_ else None, self.label, cfg.temperature, cfg.coef,
                self.tw if T_ else None, self.dscore, self.losses, B, C, T_)
         if T_ > 0:
@@ -483,8 +504,9 @@ class Engine:
             # dW_i = dP_i^T X_i ; db_i = colsum(dP_i)   (transform_matrix, model_bert.py:278,283)
             dWt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D), grad=True)
             dbt = self._view("transform_matrix.0.bias", T_ * D, (T_, D), grad=True)
-            self._sgemm(self.dP, 1, D, Rt * D, self.X, 1, D, self.X.stride(0), dWt, D, D * D, None, 0, D, D, Rt, batch=T_)
-            self._sgemm(self.dP, 1, D, Rt * D, self.ones, 0, 1, 0, dbt, 1, D, None, 0, D, 1, Rt, batch=T_)
+            self._sgemm(self.dP, 1, D, Rt * D, self.X, 1, D, self.X.stride(0), dWt, D, D * D, None, 0, D, D, Rt, batch=T_,
+                        ksplit=self.KS)
+            T.call("tnr_colsum_batched", self.dP, D, Rt * D, T.F32, Rt, D, T_, dbt, self.cs_part, 0)
         # scorer + user encoder
         T.call("tnr_score_bwd", S, cidx, S[N:], self.dscore, dS, dS[N:], B, C, D)
         ue = "student.user_encoder."
@@ -496,16 +518,16 @@ class Engine:
         # dense + pooling of the news encoder
         dvec = dS[:N]
         wd = g(PFX + "dense.weight")
-        self._sgemm(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N)
-        self._sgemm(dvec, 1, D, 0, self.ones, 0, 1, 0, gr[PFX + "dense.bias"], 1, 0, None, 0, D, 1, N)
+        self._sgemm(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N, ksplit=self.KS)
+        T.call("tnr_colsum", dvec, D, T.F32, N, D, gr[PFX + "dense.bias"], self.cs_part, 0)
         self._sgemm(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D)
         y = self.y_last
         T.call("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
-               self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, N, L, H)
+               self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
         T.call("tnr_reduce_rows", self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], 0)
         T.call("tnr_reduce_rows", self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], 0)
+        T.call("tnr_reduce_rows", self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), 0)
         self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M)
-        self._colsum(self.dpre, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), M)
         if after_bucket:
             after_bucket(0)
         if not cfg.trainable_layers:
@@ -517,26 +539,27 @@ class Engine:
             names, sh, a = layer_param_order(l), self.sh[l], self.act[l - self.lo]
             tr = l in cfg.trainable_layers
             x_in = self.x_in[l]
+            # bias gradients ride along: dx column sums from LayerNorm backward, the dgrad epilogue, attention backward
             T.call("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, gr[names[14]] if tr else None,
-                   gr[names[15]] if tr else None, self.ln_part, M, H)
+                   gr[names[15]] if tr else None, gr[names[13]] if tr else None, self.ln_part, M, H)
             if tr:
                 self._wgrad(self.dypre, a["g"], gr[names[12]], M)
-                self._colsum(self.dypre, gr[names[13]], M)
-            self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU)
+            self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if tr else 0),
+                       colsum=self.gcs_part if tr else None)
             if tr:
+                T.call("tnr_reduce_rows", self.gcs_part, self.gcs_part.shape[0], I, I, gr[names[11]], 0)
                 self._wgrad(self.du, a["h1"], gr[names[10]], M)
-                self._colsum(self.du, gr[names[11]], M)
             self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
             T.call("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, gr[names[8]] if tr else None,
-                   gr[names[9]] if tr else None, self.ln_part, M, H)
+                   gr[names[9]] if tr else None, gr[names[7]] if tr else None, self.ln_part, M, H)
             if tr:
                 self._wgrad(self.dh1pre, a["ctx"], gr[names[6]], M)
-                self._colsum(self.dh1pre, gr[names[7]], M)
             self._gemm(self.dh1pre, sh["oT"], self.dctx, M)
-            T.call("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv, N, L, cfg.A)
+            T.call("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv,
+                   self.qkvb_part if tr else None, N, L, cfg.A)
             if tr:
+                T.call("tnr_reduce_rows", self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), 0)
                 self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M)
-                self._colsum(self.dqkv, self._view(names[3], 3 * H, (3 * H,), grad=True), M)
             if l > self.lo:
                 nxt = self.dy2 if dy is self.dy else self.dy
                 self._gemm(self.dqkv, sh["qkvT"], nxt, M, res=self.dh1pre, flags=T.EPI_RES)

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtnr_hip.so")
 
 BF16, F16, F32 = 0, 1, 2
-EPI_BIAS, EPI_GELU, EPI_TANH, EPI_RES, EPI_MULDGELU, EPI_OUTF32, EPI_AUXOUT = 1, 2, 4, 8, 16, 32, 64
+EPI_BIAS, EPI_GELU, EPI_TANH, EPI_RES, EPI_MULDGELU, EPI_OUTF32, EPI_AUXOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64, 128
 
 _c = ctypes
 _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
@@ -21,20 +21,23 @@ _SIG = {
     "tnr_embed_ln_fwd": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "tnr_embed_ln_fwd_indexed": [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "tnr_gemm_nt": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P, _L, _I, _P],
+    "tnr_gemm_nt_ex": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P, _L, _I, _P, _P],
+    "tnr_gemm_colsum_rows": [_L],
     "tnr_gemm_tn_wgrad": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _P],
     "tnr_gemm_tn_ws_elems": [_L, _L, _I],
     "tnr_ln_fwd": [_P, _P, _P, _F, _P, _P, _L, _I, _P],
-    "tnr_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
+    "tnr_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "tnr_ln_bwd_part_elems": [_L, _I],
     "tnr_attn_l32_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
-    "tnr_attn_l32_bwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "tnr_attn_l32_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "tnr_colsum": [_P, _L, _I, _L, _L, _P, _P, _I, _P],
+    "tnr_colsum_batched": [_P, _L, _L, _I, _L, _L, _I, _P, _P, _I, _P],
     "tnr_colsum_part_elems": [_L, _L],
     "tnr_attpool_fwd": [_P, _P, _L, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P],
-    "tnr_attpool_bwd": [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _L, _I, _I, _P],
-    "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _P],
+    "tnr_attpool_bwd": [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _I, _I, _P],
+    "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _I, _P, _P],
     "tnr_gather_rows": [_P, _L, _P, _L, _I, _I, _P, _L, _L, _P],
-    "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tnr_user_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tnr_user_bwd_part_stride": [_I, _I],
     "tnr_score_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
@@ -46,7 +49,7 @@ _SIG = {
     "tnr_cast_f32_to_bf16": [_P, _P, _L, _P],
     "tnr_cast_bf16_to_f32": [_P, _P, _L, _P],
 }
-_RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_ln_bwd_part_elems": _L, "tnr_colsum_part_elems": _L,
+_RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_gemm_colsum_rows": _L, "tnr_ln_bwd_part_elems": _L, "tnr_colsum_part_elems": _L,
         "tnr_user_bwd_part_stride": _L}
 EXPORTS = sorted(_SIG) + ["tnr_last_error"]
 
@@ -91,7 +94,7 @@ TIMED = {}
 
 
 def _work(name, conv):
-    if name == "tnr_gemm_nt":
+    if name in ("tnr_gemm_nt", "tnr_gemm_nt_ex"):
         return 2.0 * conv[6] * conv[7] * conv[8]
     if name == "tnr_gemm_tn_wgrad":
         return 2.0 * conv[6] * conv[7] * conv[8]
