@@ -177,7 +177,8 @@ int tnr_kd_score_loss(const float* s_score, const float* t_score, const int64_t*
 int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* loss, float* dS, float* dP,
                       float* part, int B, int U, int C, int D, int T, void* stream);
 
-/* out[i] (+)= sum_r part[r*stride + i] , i < n  (fixed order) */
+/* out[i] (+)= sum_r part[r*stride + i] , i < n  (fixed order).  `part` is scratch: tall inputs are first summed
+ * in place per row chunk, so its contents are clobbered. */
 int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
                     void* stream);
 

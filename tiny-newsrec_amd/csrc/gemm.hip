@@ -51,20 +51,72 @@ __device__ __forceinline__ void tile_coords(int wg, int nbm, int nbn, int GM, in
     bn = local / gsz;
 }
 
-// epilogue shared by the NT kernels: lane holds C[m_base + 16 i][n_base + 16 j + r], r = 0..3
-__device__ __forceinline__ void nt_epilogue(const NTArgs& g, f32x4 (&acc)[4][4], int m_base, int n_base) {
+// erf-GELU / its derivative by linear interpolation in an LDS table over [-8, 8), step 1/128 (2049 nodes, exact
+// values at the nodes; interpolation error <= max|f''| h^2 / 8 ~ 6e-6, the bf16 output rounding is 4e-3 relative).
+// The closed form costs ~35 VALU issue slots per element and made the FFN epilogues VALU-bound (13 us per
+// 256x256 tile); the table costs ~12 slots + one ds_read2_b32.
+constexpr int LUT_N = 2048;
+__device__ __forceinline__ void lut_build(float* lut, bool grad) {
+    for (int i = threadIdx.x; i <= LUT_N; i += blockDim.x) {
+        float x = (float)(i - LUT_N / 2) * (1.0f / 128.0f);
+        lut[i] = grad ? gelu_erf_grad(x) : gelu_erf(x);
+    }
+}
+template <bool GRAD>
+__device__ __forceinline__ float lut_eval(const float* lut, float x) {
+    float t = fminf(fmaxf(fmaf(x, 128.0f, (float)(LUT_N / 2)), 0.0f), (float)LUT_N - 0.001f);
+    int i = (int)t;
+    float fr = t - (float)i;
+    float a = lut[i], b = lut[i + 1];
+    float y = fmaf(fr, b - a, a);
+    const float hi = GRAD ? 1.0f : x;           // |x| >= 8: Phi is 0 or 1 to fp32 precision
+    return x >= 8.0f ? hi : (x <= -8.0f ? 0.0f : y);
+}
+
+// epilogue shared by the NT kernels: lane holds C[m_base + 16 i][n_base + 16 j + r], r = 0..3.
+// All global reads of a 64-row strip (residual, aux) are issued before any arithmetic and the bias is loaded by
+// the caller at kernel start: with the loads inside the (j, i) loops each one was a dependent L2 round trip
+// (8 per tile, exposed), which cost more than the GELU arithmetic itself.
+struct NTBias { f32x4 v[4]; };
+__device__ __forceinline__ NTBias nt_load_bias(const NTArgs& g, int n_base) {
+    NTBias b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        b.v[j] = (g.flags & TNR_EPI_BIAS) ? *(const f32x4*)(g.bias + n_base + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    return b;
+}
+
+__device__ __forceinline__ void nt_epilogue(const NTArgs& g, f32x4 (&acc)[4][4], int m_base, int n_base,
+                                            const NTBias& bias, const float* lut = nullptr) {
     const int flags = g.flags;
+    bf16x4 rr[4][4], uu[4][4];
+    if (flags & TNR_EPI_RES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = m_base + i * 16;
+            m = m < g.M ? m : g.M - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[i][j] = *(const bf16x4*)(g.res + (int64_t)m * g.ldres + n_base + j * 16);
+        }
+    }
+    if (flags & TNR_EPI_MULDGELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = m_base + i * 16;
+            m = m < g.M ? m : g.M - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) uu[i][j] = *(const bf16x4*)(g.aux + (int64_t)m * g.ldaux + n_base + j * 16);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n_base + j * 16;
-        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 cs = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (flags & TNR_EPI_BIAS) bv = *(const f32x4*)(g.bias + n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m_base + i * 16;
             if (m >= g.M) continue;
-            f32x4 v = acc[i][j] + bv;
+            f32x4 v = acc[i][j] + bias.v[j];
             if (flags & TNR_EPI_AUXOUT) {
                 bf16x4 o;
 #pragma unroll
@@ -72,22 +124,30 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& g, f32x4 (&acc)[4][4],
                 *(bf16x4*)(g.aux + (int64_t)m * g.ldaux + n) = o;
             }
             if (flags & TNR_EPI_GELU) {
+                if (lut) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = lut_eval<false>(lut, v[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
             }
             if (flags & TNR_EPI_TANH) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
             }
             if (flags & TNR_EPI_MULDGELU) {
-                bf16x4 u = *(const bf16x4*)(g.aux + (int64_t)m * g.ldaux + n);
+                if (lut) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+                    for (int r = 0; r < 4; ++r) v[r] *= lut_eval<true>(lut, (float)uu[i][j][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)uu[i][j][r]);
+                }
             }
             if (flags & TNR_EPI_RES) {
-                bf16x4 rr = *(const bf16x4*)(g.res + (int64_t)m * g.ldres + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[i][j][r];
             }
             if (flags & TNR_EPI_OUTF32) {
                 *(f32x4*)((float*)g.C + (int64_t)m * g.ldc + n) = v;
@@ -186,7 +246,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs g) {
         __syncthreads();
     }
 
-    nt_epilogue(g, acc, bm * 128 + wm * 64 + (lane & 15), bn * 128 + wn * 64 + (lane >> 4) * 4);
+    nt_epilogue(g, acc, bm * 128 + wm * 64 + (lane & 15), bn * 128 + wn * 64 + (lane >> 4) * 4,
+                nt_load_bias(g, bn * 128 + wn * 64 + (lane >> 4) * 4));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -384,7 +445,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs g) {
         cur = cur == 2 ? 0 : cur + 1;
         nxt = nxt == 2 ? 0 : nxt + 1;
     }
-    nt_epilogue(g, acc, bm * 256 + wm * 64 + (lane & 15), bn * 128 + wn * 64 + (lane >> 4) * 4);
+    nt_epilogue(g, acc, bm * 256 + wm * 64 + (lane & 15), bn * 128 + wn * 64 + (lane >> 4) * 4,
+                nt_load_bias(g, bn * 128 + wn * 64 + (lane >> 4) * 4));
 }
 
 // wgrad v2: output tile 256 (n) x 128 (k); stage = [dY cols 0-127 | dY cols 128-255 | X], each [64 m][256 B]
@@ -486,6 +548,125 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs g) {
     }
 }
 
+// ---- row-contiguous epilogue of the 256x256 kernels -------------------------------------------------
+// The accumulator layout gives a lane 4 consecutive n of one row: 8-byte bf16 accesses, 16 rows per wave
+// instruction.  Measured: an extra bf16 tensor written/read that way (AUXOUT / RES / MULDGELU) cost +220..290 us
+// per 52800x3072 launch while an fp32 output (16-byte accesses, twice the bytes) cost +40 us -- the epilogue is
+// bound by the number of small memory transactions.  So the fp32 tile goes through LDS in two passes of 128 rows
+// ([128][256] fp32, rows padded by 16 B) and is post-processed with thread -> (row, 8 consecutive columns):
+// 16-byte residual / aux loads and C / aux stores, two full 512-byte row segments per wave instruction.
+constexpr int EPI_LD = 256 * 4 + 16;                 // bytes per staged row
+constexpr int EPI_BYTES = 128 * EPI_LD;              // 133,120 B
+constexpr int LDS3_BYTES = EPI_BYTES + (LUT_N + 4) * 4;
+
+__device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&acc)[8][4], char* smem, const float* lut,
+                                                      int bm, int bn, int wm, int wn, int lane) {
+    const int flags = g.flags;
+    const int tid = threadIdx.x;
+    const int c8 = (tid & 31) * 8, rg = tid >> 5;            // 8 columns, row group 0..15
+    const int n = bn * 256 + c8;
+    f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (flags & TNR_EPI_BIAS) {
+        b0 = *(const f32x4*)(g.bias + n);
+        b1 = *(const f32x4*)(g.bias + n + 4);
+    }
+    float cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();                                       // staging area free (K loop / previous pass done)
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(f32x4*)(smem + (i * 16 + (lane & 15)) * EPI_LD + (wn * 64 + j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+        }
+        __syncthreads();
+        const int m0 = bm * 256 + pass * 128;
+        bf16x8 rr[8], uu[8];
+        if (flags & TNR_EPI_RES) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int m = m0 + rg + 16 * it;
+                m = m < g.M ? m : g.M - 1;
+                rr[it] = *(const bf16x8*)(g.res + (int64_t)m * g.ldres + n);
+            }
+        }
+        if (flags & TNR_EPI_MULDGELU) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int m = m0 + rg + 16 * it;
+                m = m < g.M ? m : g.M - 1;
+                uu[it] = *(const bf16x8*)(g.aux + (int64_t)m * g.ldaux + n);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = rg + 16 * it;
+            const int m = m0 + row;
+            if (m >= g.M) continue;
+            f32x4 v0 = *(const f32x4*)(smem + row * EPI_LD + c8 * 4) + b0;
+            f32x4 v1 = *(const f32x4*)(smem + row * EPI_LD + c8 * 4 + 16) + b1;
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (flags & TNR_EPI_AUXOUT) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)(g.aux + (int64_t)m * g.ldaux + n) = o;
+            }
+            if (flags & TNR_EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = lut_eval<false>(lut, v[e]);
+            }
+            if (flags & TNR_EPI_TANH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+            }
+            if (flags & TNR_EPI_MULDGELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= lut_eval<true>(lut, (float)uu[it][e]);
+            }
+            if (flags & TNR_EPI_RES) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rr[it][e];
+            }
+            if (flags & TNR_EPI_OUTF32) {
+                float* c = (float*)g.C + (int64_t)m * g.ldc + n;
+                *(f32x4*)c = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = (bf16)v[e];
+                    cs[e] += (float)o[e];
+                }
+                *(bf16x8*)((bf16*)g.C + (int64_t)m * g.ldc + n) = o;
+            }
+        }
+    }
+    if (flags & TNR_EPI_COLSUM) {
+        // column sums of the 256-row tile: 16 row groups hold partials for the same 8 columns
+        __syncthreads();
+        float* red = (float*)smem;                             // [16][256]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rg * 256 + c8 + e] = cs[e];
+        __syncthreads();
+        if (tid < 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
+            float* pr = g.colsum_part + (int64_t)(bm * 4) * g.N + bn * 256 + tid;   // 4 partial rows per tile (v2 layout)
+            pr[0] = t;
+            pr[g.N] = 0.f;
+            pr[2 * (int64_t)g.N] = 0.f;
+            pr[3 * (int64_t)g.N] = 0.f;
+        }
+    }
+}
+
 // ================================================================================================
 // v3: 256x256 output tile, 8 waves (2 x 4, each 128 x 64), two 64 KB LDS stages
 // ([A rows 0-127 | A rows 128-255 | B rows 0-127 | B rows 128-255], 16 KB each).  128 FLOP per staged byte:
@@ -536,6 +717,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    float* lut = (float*)(smem + EPI_BYTES);             // own LDS region, built while the first loads fly
+    if (g.flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (g.flags & TNR_EPI_MULDGELU) != 0);
     const int nk = g.K >> 6;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -559,12 +742,121 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    // epilogue in two halves of 64 rows (reuses the shared 4x4 routine)
-    const int n_base = bn * 256 + wn * 64 + (lane >> 4) * 4;
+    nt_epilogue_coalesced(g, acc, smem, lut, bm, bn, wm, wn, lane);
+}
+
+// ================================================================================================
+// v4: the v3 tile as a PERSISTENT kernel: one workgroup per CU walks its XCD's run of tiles; the first two
+// K stages of the next tile are issued before the current tile's epilogue, so the epilogue's VALU work and
+// stores run under the next tile's loads instead of leaving the (binding) L2->LDS pipe idle, and no tile but
+// the first pays the cold-start latency of its first loads.
+__global__ __launch_bounds__(512, 2) void gemm_nt256x256_persistent_kernel(NTArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int nbn = g.N >> 8;
+    const int nbm = (g.M + 255) >> 8;
+    const int ntile = nbm * nbn;
+    // tiles of this workgroup: XCD x (= blockIdx % 8 under round-robin dispatch; locality only) owns a
+    // contiguous run of the grouped tile order, its workgroups sweep it side by side
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per = (G - xcd + 7) >> 3;
+    const int q8 = ntile >> 3, r8 = ntile & 7;
+    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
+    int tile = c0 + slot;
+    if (tile >= c1) return;
+
+    const int nk = g.K >> 6;
+    const bf16* src[8];
+    int dst[8];
+    int prow[8], pchunk[8];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        f32x4 (&a4)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[hh * 4]);
-        nt_epilogue(g, a4, bm * 256 + wm * 128 + hh * 64 + (lane & 15), n_base);
+    for (int q = 0; q < 8; ++q) {
+        int p = w * 8 + q, pp = p & 15;
+        prow[q] = pp * 8 + (lane >> 3);
+        pchunk[q] = ((lane & 7) ^ (prow[q] & 7)) * 8;
+        dst[q] = (p >> 4) * TILE_BYTES + pp * 1024;
+    }
+    auto set_src = [&](int t) {
+        int bm, bn;
+        tile_coords(t, nbm, nbn, 8, bm, bn);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int sub = (w * 8 + q) >> 4;
+            if (sub < 2) {
+                int gm = bm * 256 + sub * 128 + prow[q];
+                gm = gm < g.M ? gm : g.M - 1;
+                src[q] = g.A + (int64_t)gm * g.lda + pchunk[q];
+            } else {
+                src[q] = g.B + (int64_t)(bn * 256 + (sub - 2) * 128 + prow[q]) * g.ldb + pchunk[q];
+            }
+        }
+    };
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE3;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) glds16(src[q] + kt * 64, base + dst[q]);
+    };
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    set_src(tile);
+    stage(0, 0);
+    int cur = 0;
+    int issued = 1;                      // K stages of the current tile already issued
+    while (true) {
+        const int next = tile + per < c1 ? tile + per : -1;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int bm, bn;
+        tile_coords(tile, nbm, nbn, 8, bm, bn);
+        const int n_base = bn * 256 + wn * 64 + (lane >> 4) * 4;
+        const NTBias bias = nt_load_bias(g, n_base);
+        for (int kt = 0; kt < nk; ++kt) {
+            TNR_WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) {
+                if (kt + 1 >= issued) stage(cur ^ 1, kt + 1);
+            } else if (next >= 0) {
+                set_src(next);           // the current tile's pointers are no longer needed
+                stage(cur ^ 1, 0);
+            }
+            const char* sa = smem + cur * STAGE3 + wm * TILE_BYTES;
+            const char* sb = smem + cur * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 af[8], bfr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            cur ^= 1;
+        }
+        issued = 1;
+        if (next >= 0 && nk >= 2) {
+            // second stage of the next tile: the buffer just computed is free once every wave is past its MFMAs
+            __builtin_amdgcn_s_barrier();
+            stage(cur ^ 1, 1);
+            issued = 2;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x4 (&a4)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[hh * 4]);
+            nt_epilogue(g, a4, bm * 256 + wm * 128 + hh * 64 + (lane & 15), n_base, bias);
+        }
+        if (next < 0) break;
+        tile = next;
     }
 }
 
@@ -716,13 +1008,22 @@ extern "C" int tnr_gemm_nt_ex(const void* A, int64_t lda, const void* B, int64_t
     static const char* ver_s = getenv("TNR_GEMM_VER");
     static const int ver = ver_s ? atoi(ver_s) : 3;
     static const char* probe_s = getenv("TNR_GEMM_PROBE");
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int devid = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
     static const bool probe = probe_s && probe_s[0] == '1';
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -733,10 +1034,14 @@ extern "C" int tnr_gemm_nt_ex(const void* A, int64_t lda, const void* B, int64_t
         int nwg = (int)(((M + 255) / 256) * (N / 128));
         if (probe) hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), RING2, st, g);
         else hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), RING2, st, g);
-    } else {
+    } else if (ver == 3 || probe) {
         int nwg = (int)(((M + 255) / 256) * (N / 256));
-        if (probe) hipLaunchKernelGGL(gemm_nt256x256_kernel<1>, dim3(nwg), dim3(512), RING3, st, g);
-        else hipLaunchKernelGGL(gemm_nt256x256_kernel<0>, dim3(nwg), dim3(512), RING3, st, g);
+        if (probe) hipLaunchKernelGGL(gemm_nt256x256_kernel<1>, dim3(nwg), dim3(512), LDS3_BYTES, st, g);
+        else hipLaunchKernelGGL(gemm_nt256x256_kernel<0>, dim3(nwg), dim3(512), LDS3_BYTES, st, g);
+    } else {
+        int ntile = (int)(((M + 255) / 256) * (N / 256));
+        int nwg = ntile < n_cu ? ntile : n_cu;
+        hipLaunchKernelGGL(gemm_nt256x256_persistent_kernel, dim3(nwg), dim3(512), RING3, st, g);
     }
     TNR_CHECK_LAUNCH("tnr_gemm_nt");
     return TNR_OK;

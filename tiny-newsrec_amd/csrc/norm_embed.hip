@@ -191,6 +191,22 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         out[i] = accumulate ? out[i] + t : t;
     }
 }
+// first level for tall inputs: chunk y sums its rows IN PLACE into its first row (each block only touches its own
+// 64 columns of its own chunk), so that the second level reads `chunks` rows instead of `rows`
+__global__ __launch_bounds__(256) void reduce_rows_chunk_kernel(float* __restrict__ part, int64_t rows, int64_t stride,
+                                                                int64_t n, int64_t chunk) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk;
+    const int64_t r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    float s = 0.f;
+    if (i < n)
+        for (int64_t r = r0 + rl; r < r1; r += 4) s += part[r * stride + i];
+    red[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && i < n) part[r0 * stride + i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
 __global__ __launch_bounds__(256) void reduce_rows_narrow_kernel(const float* __restrict__ part, int64_t rows,
                                                                  int64_t stride, float* __restrict__ out, int accumulate) {
     __shared__ float red[256];
@@ -332,12 +348,25 @@ extern "C" int64_t tnr_ln_bwd_part_elems(int64_t M, int H) { return ((M + LNB_RO
 extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
                                void* stream) {
     TNR_CHECK_ARG(part && out && rows >= 1 && n >= 1, "tnr_reduce_rows: bad argument");
-    if (n < 64 && rows >= 256)
+    const int64_t colblk = (n + 63) / 64;
+    if (n < 64 && rows >= 256) {
         hipLaunchKernelGGL(reduce_rows_narrow_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, part, rows,
                            stride, out, accumulate);
-    else
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, part,
-                           rows, stride, n, out, accumulate);
+    } else if (rows >= 128 && colblk < 512) {
+        // two levels: enough workgroups to stream the partials at HBM rate; `part` is clobbered (it is scratch)
+        int64_t chunks = 1024 / colblk;
+        if (chunks > rows / 16) chunks = rows / 16;
+        if (chunks < 2) chunks = 2;
+        int64_t chunk = (rows + chunks - 1) / chunks;
+        chunks = (rows + chunk - 1) / chunk;
+        hipLaunchKernelGGL(reduce_rows_chunk_kernel, dim3((unsigned)colblk, (unsigned)chunks), dim3(256), 0,
+                           (hipStream_t)stream, (float*)part, rows, stride, n, chunk);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)colblk), dim3(256), 0, (hipStream_t)stream, part, chunks,
+                           chunk * stride, n, out, accumulate);
+    } else {
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)colblk), dim3(256), 0, (hipStream_t)stream, part, rows,
+                           stride, n, out, accumulate);
+    }
     TNR_CHECK_LAUNCH("tnr_reduce_rows");
     return TNR_OK;
 }
