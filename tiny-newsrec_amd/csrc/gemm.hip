@@ -56,19 +56,23 @@ __device__ __forceinline__ void tile_coords(int wg, int nbm, int nbn, int GM, in
 // The closed form costs ~35 VALU issue slots per element and made the FFN epilogues VALU-bound (13 us per
 // 256x256 tile); the table costs ~12 slots + one ds_read2_b32.
 constexpr int LUT_N = 2048;
-__device__ __forceinline__ void lut_build(float* lut, bool grad) {
-    for (int i = threadIdx.x; i <= LUT_N; i += blockDim.x) {
-        float x = (float)(i - LUT_N / 2) * (1.0f / 128.0f);
-        lut[i] = grad ? gelu_erf_grad(x) : gelu_erf(x);
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// node i holds {f(x_i), f(x_i+1) - f(x_i)}: ONE 8-byte gather per element on the 64-bank ds_read_b64 path
+__device__ __forceinline__ void lut_build(f32x2* lut, bool grad) {
+    for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
+        float x0 = (float)(i - LUT_N / 2) * (1.0f / 128.0f), x1 = (float)(i + 1 - LUT_N / 2) * (1.0f / 128.0f);
+        float a = grad ? gelu_erf_grad(x0) : gelu_erf(x0);
+        float b = grad ? gelu_erf_grad(x1) : gelu_erf(x1);
+        lut[i] = (f32x2){a, b - a};
     }
 }
 template <bool GRAD>
-__device__ __forceinline__ float lut_eval(const float* lut, float x) {
+__device__ __forceinline__ float lut_eval(const f32x2* lut, float x) {
     float t = fminf(fmaxf(fmaf(x, 128.0f, (float)(LUT_N / 2)), 0.0f), (float)LUT_N - 0.001f);
     int i = (int)t;
     float fr = t - (float)i;
-    float a = lut[i], b = lut[i + 1];
-    float y = fmaf(fr, b - a, a);
+    f32x2 e = lut[i];
+    float y = fmaf(fr, e[1], e[0]);
     const float hi = GRAD ? 1.0f : x;           // |x| >= 8: Phi is 0 or 1 to fp32 precision
     return x >= 8.0f ? hi : (x <= -8.0f ? 0.0f : y);
 }
@@ -87,7 +91,7 @@ __device__ __forceinline__ NTBias nt_load_bias(const NTArgs& g, int n_base) {
 }
 
 __device__ __forceinline__ void nt_epilogue(const NTArgs& g, f32x4 (&acc)[4][4], int m_base, int n_base,
-                                            const NTBias& bias, const float* lut = nullptr) {
+                                            const NTBias& bias, const f32x2* lut = nullptr) {
     const int flags = g.flags;
     bf16x4 rr[4][4], uu[4][4];
     if (flags & TNR_EPI_RES) {
@@ -557,9 +561,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs g) {
 // 16-byte residual / aux loads and C / aux stores, two full 512-byte row segments per wave instruction.
 constexpr int EPI_LD = 256 * 4 + 16;                 // bytes per staged row
 constexpr int EPI_BYTES = 128 * EPI_LD;              // 133,120 B
-constexpr int LDS3_BYTES = EPI_BYTES + (LUT_N + 4) * 4;
+constexpr int LDS3_BYTES = EPI_BYTES + LUT_N * 8;
 
-__device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&acc)[8][4], char* smem, const float* lut,
+__device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&acc)[8][4], char* smem, const f32x2* lut,
                                                       int bm, int bn, int wm, int wn, int lane) {
     const int flags = g.flags;
     const int tid = threadIdx.x;
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float* lut = (float*)(smem + EPI_BYTES);             // own LDS region, built while the first loads fly
+    f32x2* lut = (f32x2*)(smem + EPI_BYTES);             // own LDS region, built while the first loads fly
     if (g.flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (g.flags & TNR_EPI_MULDGELU) != 0);
     const int nk = g.K >> 6;
     stage(0, 0);

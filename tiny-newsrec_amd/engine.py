@@ -334,9 +334,10 @@ class Engine:
 
     @staticmethod
     def _wgrad_splits(N, K):
-        """-> (splits, workspace elems): about two waves of 256-thread... workgroups on the 256 CUs."""
+        """-> (splits over M, workspace elems): one full round of workgroups on the 256 CUs (one 256x256 output
+        tile x split each); more splits only add fp32 slab traffic (N*K*4 B written and re-read per split)."""
         tiles = (N // 256) * (K // 256) if (N % 256 == 0 and K % 256 == 0) else (N // 128) * (K // 128)
-        splits = max(1, min(64, 512 // max(tiles, 1)))
+        splits = max(1, min(64, 256 // max(tiles, 1)))
         return splits, T.query("tnr_gemm_tn_ws_elems", N, K, splits)
 
     # ------------------------------------------------------------------ kernel wrappers
