@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--trainable", type=int, nargs="+", default=None)
     ap.add_argument("--teachers", type=int, default=4)
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit activation type (same MFMA rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -100,7 +101,7 @@ def main():
     trainable = tuple(a.trainable) if a.trainable else (a.layers - 2, a.layers - 1)
     cfg_kw = dict(n_layers=a.layers, trainable_layers=trainable, num_teachers=a.teachers)
     cfg = E.EngineConfig(**cfg_kw)
-    eng = E.Engine(cfg, dev, max_batch=a.batch)
+    eng = E.Engine(cfg, dev, max_batch=a.batch, dtype=a.dtype)
     seed = 1234
     eng.load_state_dict(hashinit.init_state_dict(seed, state_shapes(FULL, a.layers, cfg.D, a.teachers)))
     D.broadcast_flat([eng.flat[True], eng.flat[False]])
@@ -123,7 +124,8 @@ def main():
     for i in range(W):
         one_step(i)
     if not a.no_kernel_timing:
-        T.TIMED["tnr_gemm_nt_ex"] = []
+        TKEY = "tnr_gemm_nt_ex_f16" if a.dtype == "fp16" else "tnr_gemm_nt_ex"
+        T.TIMED[TKEY] = []
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -134,7 +136,7 @@ def main():
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     dt = float(D.all_reduce_max(dt).item())
     loss = float(eng.total_loss().item())
-    rec = T.TIMED.pop("tnr_gemm_nt_ex", None)
+    rec = T.TIMED.pop("tnr_gemm_nt_ex_f16", None) or T.TIMED.pop("tnr_gemm_nt_ex", None)
 
     if rank == 0:
         value = world * B * K / dt
@@ -142,7 +144,7 @@ def main():
         out = {
             "metric": "training impressions/sec", "value": round(value, 2), "unit": "impressions/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * dt / K, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "Tiny-NewsRec %d-layer student (train %s) + %d-teacher KD (title-emb MSE + soft-CE), "
                                    "fwd+bwd+AMSGrad%s" % (a.layers, list(trainable), a.teachers,
                                                            " + RCCL grad all-reduce" if world > 1 else ""),

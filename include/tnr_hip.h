@@ -29,7 +29,7 @@ extern "C" {
 #define TNR_ELAUNCH (-3)     /* hipGetLastError() after a launch */
 
 #define TNR_BF16 0
-#define TNR_F16 1            /* reserved */
+#define TNR_F16 1            /* IEEE half: the *_f16 entry points */
 #define TNR_F32 2
 
 /* gemm epilogue flags */
@@ -198,6 +198,48 @@ int tnr_refresh_shadows(const int64_t* desc, int n_desc, int64_t total_tiles, co
 /* elementwise helpers */
 int tnr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int tnr_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+
+/* ---- fp16 activations ------------------------------------------------------------------------------
+ * Every entry point that touches 16-bit tensors exists a second time with the suffix _f16: identical
+ * signature and semantics with IEEE half instead of bf16 (same MFMA rate, 3 more mantissa bits: the build used
+ * for the 1e-3 parity bound).  The sources are compiled twice (-DTNR_BUILD_F16). */
+int tnr_embed_ln_fwd_f16(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
+                     const float* type0, const float* gamma, const float* beta, float eps,
+                     void* out, float* mask_add, void* stream);
+int tnr_embed_ln_fwd_indexed_f16(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
+                             const float* word, const float* pos, const float* type0, const float* gamma,
+                             const float* beta, float eps, void* out, float* mask_add, void* stream);
+int tnr_gemm_nt_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                void* aux, int64_t ldaux, int flags, void* stream);
+int tnr_gemm_nt_ex_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                   void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream);
+int64_t tnr_gemm_colsum_rows_f16(int64_t M);
+int tnr_gemm_tn_wgrad_f16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
+                      int64_t M, int64_t N, int64_t K, float* ws, int splits, int accumulate, void* stream);
+int64_t tnr_gemm_tn_ws_elems_f16(int64_t N, int64_t K, int splits);
+int tnr_ln_fwd_f16(const void* x, const float* gamma, const float* beta, float eps, void* y, float* stats,
+               int64_t M, int H, void* stream);
+int tnr_ln_bwd_f16(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+               float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream);
+int tnr_attn_l32_fwd_f16(const void* qkv, const float* mask_add, const float* rel, void* ctx,
+                     int64_t n_seq, int L, int A, void* stream);
+int tnr_attn_l32_bwd_f16(const void* qkv, const float* mask_add, const float* rel, const void* dctx,
+                     void* dqkv, float* bias_part, int64_t n_seq, int L, int A, void* stream);
+int tnr_colsum_f16(const void* X, int64_t ldx, int dtype, int64_t M, int64_t N, float* out, float* part,
+               int accumulate, void* stream);
+int tnr_colsum_batched_f16(const void* X, int64_t ldx, int64_t sX, int dtype, int64_t M, int64_t N, int batch,
+                       float* out, float* part, int accumulate, void* stream);
+int tnr_attpool_fwd_f16(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
+                    float* nv, float* alpha, float* den, int64_t n_seq, int L, int H, void* stream);
+int tnr_attpool_bwd_f16(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
+                    const float* alpha, const float* den, void* dy_direct, void* dpre, int64_t lddpre,
+                    float* dw2_part, float* db2_part, float* db1_part, int64_t n_seq, int L, int H, void* stream);
+int tnr_refresh_shadows_f16(const int64_t* desc, int n_desc, int64_t total_tiles, const int64_t* tile_start,
+                        void* stream);
+int tnr_cast_f32_to_bf16_f16(const float* src, void* dst, int64_t n, void* stream);
+int tnr_cast_bf16_to_f32_f16(const void* src, float* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,9 @@
 """GPU parity of the whole training step (forward, backward, AMSGrad) through the C ABI, against
 (1) the golden vectors captured from the imported reference and (2) the numpy oracle on the same inputs.
 
-Tolerances (bf16 activations/weights in the encoder GEMMs, fp32 heads; BASELINE.json north_star asks
-for logits / KD-loss within 1e-3 at fp16-class precision -- bf16 carries 8 mantissa bits, so the
-bound used here is 1e-3 * max(1, |ref|) * 16 on logits and losses; measured errors are printed)."""
+Tolerances (BASELINE.json north_star: logits / KD-loss within 1e-3 at fp16 precision):
+  fp16 build: |err| <= 1e-3 * max(1, |ref|) on logits, losses, news / user vectors; gradients 1.5e-2 relative L2.
+  bf16 build (8 significand bits instead of 11): the same bounds x 16; gradients 6e-2.  Measured errors are printed."""
 import numpy as np
 import pytest
 import torch
@@ -18,12 +18,12 @@ DEV = "cuda:0"
 LOGIT_TOL = 1.6e-2
 
 
-def _engine_for(cfg, z, T_):
+def _engine_for(cfg, z, T_, dtype="bf16"):
     seed, B, _, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
     ec = E.EngineConfig(n_layers=nl, trainable_layers=cfg["trainable_layers"], num_teachers=T_, user_log_length=U,
                         npratio=C - 1, num_words=L, news_dim=D, user_log_mask=cfg["user_log_mask"],
                         temperature=cfg["temperature"], coef=cfg["coef"])
-    return E.Engine(ec, DEV, max_batch=B), B
+    return E.Engine(ec, DEV, max_batch=B, dtype=dtype), B
 
 
 def _dev_inputs(inp):
@@ -32,11 +32,18 @@ def _dev_inputs(inp):
     return t(hist), t(mask), t(cand), t(label), [t(x) for x in th], [t(x) for x in tc]
 
 
+# fp16 activations: 11 significand bits -> the north-star bound 1e-3 * max(1, |ref|) on logits and losses
+TOL = {"bf16": LOGIT_TOL, "fp16": 1e-3}
+GTOL = {"bf16": 6e-2, "fp16": 1.5e-2}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", ["full_model_0.npz", "full_model_1.npz", "full_model_2.npz"])
-def test_training_step_matches_reference_and_oracle(name):
+def test_training_step_matches_reference_and_oracle(name, dtype):
+    LOGIT_TOL = TOL[dtype]
     z, P, cfg, inp = load_case(name)
     T_ = len(inp[4])
-    eng, B = _engine_for(cfg, z, T_)
+    eng, B = _engine_for(cfg, z, T_, dtype)
     eng.load_state_dict(P)
     hist, mask, cand, label, th, tc = _dev_inputs(inp)
     losses, score = eng.forward(hist, mask, cand, label, th, tc)
@@ -44,7 +51,7 @@ def test_training_step_matches_reference_and_oracle(name):
     l = losses.cpu().numpy()
     got = dict(distill=l[0], target=l[1], emb=l[2], total=l[0] + cfg["coef"] * l[1] + l[2])
     sc = score.cpu().numpy()
-    print("\n[%s] score max|err| %.3e (|ref| max %.2f)" % (name, np.abs(sc - z["score"]).max(), np.abs(z["score"]).max()))
+    print("\n[%s %s] score max|err| %.3e (|ref| max %.2f)" % (name, dtype, np.abs(sc - z["score"]).max(), np.abs(z["score"]).max()))
     for k in got:
         print("   %s: got %.6f ref %.6f err %.2e" % (k, got[k], float(z[k]), abs(got[k] - float(z[k]))))
         assert abs(got[k] - float(z[k])) <= LOGIT_TOL * max(1.0, abs(float(z[k]))), k
@@ -62,9 +69,9 @@ def test_training_step_matches_reference_and_oracle(name):
     out = O.model_fwd(P, cfg, *inp)
     G = O.model_bwd(P, cfg, out)
     worst = 0.0
-    for k, g in eng.grads.items():
+    for k in eng.grads:
         ref = G[k]
-        got_g = g.cpu().numpy()
+        got_g = eng.grad(k).cpu().numpy()
         rn = np.sqrt((ref.astype(np.float64) ** 2).sum())
         if k.endswith("self.key.bias") or k.endswith("att_fc2.bias"):
             assert np.abs(got_g).max() < 1e-3          # mathematical no-ops: rounding noise only
@@ -74,9 +81,9 @@ def test_training_step_matches_reference_and_oracle(name):
             continue
         err = np.sqrt(((got_g - ref).astype(np.float64) ** 2).sum()) / (rn + 1e-12)
         worst = max(worst, err)
-        assert err < 6e-2, "%s: relative L2 error %.3e (norm %.3e)" % (k, err, rn)
+        assert err < GTOL[dtype], "%s: relative L2 error %.3e (norm %.3e)" % (k, err, rn)
         # golden reference norms (fp32 autograd of the imported reference)
-        assert abs(np.sqrt((got_g.astype(np.float64) ** 2).sum()) - float(z["gnorm." + k])) <= 6e-2 * float(z["gnorm." + k]) + 1e-7, k
+        assert abs(np.sqrt((got_g.astype(np.float64) ** 2).sum()) - float(z["gnorm." + k])) <= GTOL[dtype] * float(z["gnorm." + k]) + 1e-7, k
     print("   worst gradient relative L2 error %.3e" % worst)
 
     # ---- optimiser step: AMSGrad on the flat buffer + bf16 copies refreshed
@@ -87,10 +94,10 @@ def test_training_step_matches_reference_and_oracle(name):
     k = E.layer_param_order(max(cfg["trainable_layers"]))[10]           # intermediate.dense.weight
     p = p0[k].cpu().numpy().copy()
     m, v, vm = np.zeros_like(p), np.zeros_like(p), np.zeros_like(p)
-    O.amsgrad_step(p, eng.grads[k].cpu().numpy(), m, v, vm, 1, lr=1e-4)
+    O.amsgrad_step(p, g0[eng.off(k):eng.off(k) + p.size].view(p.shape).cpu().numpy() / eng.gscale, m, v, vm, 1, lr=1e-4)
     np.testing.assert_allclose(eng.params[k].cpu().numpy(), p, rtol=1e-5, atol=1e-7)
     sh = eng.sh[max(cfg["trainable_layers"])]
-    assert torch.equal(sh["w1"], eng.params[k].to(torch.bfloat16)) and torch.equal(sh["w1T"], eng.params[k].t().to(torch.bfloat16))
+    assert torch.equal(sh["w1"], eng.params[k].to(eng.tdt)) and torch.equal(sh["w1T"], eng.params[k].t().to(eng.tdt))
     frozen = E.BERT + "embeddings.word_embeddings.weight"
     assert torch.equal(eng.params[frozen], p0[frozen])
     assert torch.equal(eng.flat_g, g0)

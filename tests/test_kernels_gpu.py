@@ -499,3 +499,44 @@ def test_reduce_rows_shapes():
         T.call("tnr_reduce_rows", dev(x), rows, n, n, o, 1)
         torch.cuda.synchronize()
         np.testing.assert_allclose(o.cpu().numpy(), 1 + x.sum(0), rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ fp16 build
+def hf(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.float16).float().numpy()
+
+
+def test_f16_variants_gemm_attention_ln():
+    """Same sources compiled with IEEE half: exact integer GEMMs (NT + wgrad) and attention / LayerNorm spot checks."""
+    rs = np.random.RandomState(5)
+    M, N, K = 700, 512, 256
+    A = rs.randint(-3, 4, (M, K)).astype(np.float32); A[:, 1] += np.arange(M) % 3
+    B = rs.randint(-3, 4, (N, K)).astype(np.float32); B[:, 0] += np.arange(N) % 5
+    c = torch.zeros((M, N), device=DEV)
+    T.call("tnr_gemm_nt_f16", dev(A, torch.float16), K, dev(B, torch.float16), K, c, N, M, N, K, None, None, 0, None, 0, T.EPI_OUTF32)
+    Mp = (M + 63) // 64 * 64
+    dY, X = np.zeros((Mp, N), np.float32), np.zeros((Mp, K), np.float32)
+    dY[:M] = rs.randint(-2, 3, (M, N)); X[:M] = A
+    ws = torch.zeros(T.query("tnr_gemm_tn_ws_elems_f16", N, K, 4), device=DEV)
+    dW = torch.zeros((N, K), device=DEV)
+    T.call("tnr_gemm_tn_wgrad_f16", dev(dY, torch.float16), N, dev(X, torch.float16), K, dW, K, M, N, K, ws, 4, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy(), A @ B.T) and np.array_equal(dW.cpu().numpy(), dY.T @ X)
+    # attention forward in half precision
+    Ns, L, Ah, d = 3, 30, 12, 64
+    qkv = hf(rnd((Ns * L, 3 * Ah * d), 1))
+    mask = (rs.rand(Ns, L) > 0.3).astype(np.float32); mask[0] = 1
+    w = rnd((Ah, 32), 2, 0.5)
+    relt, madd = torch.zeros((Ah, 32, 32), device=DEV), dev(np.concatenate([(1 - mask) * -10000.0, np.full((Ns, 2), -1e30)], 1).astype(np.float32))
+    T.call("tnr_relpos_table", dev(w), Ah, L, relt)
+    ctx = torch.zeros((Ns * L, Ah * d), device=DEV, dtype=torch.float16)
+    T.call("tnr_attn_l32_fwd_f16", dev(qkv, torch.float16), madd, relt, ctx, Ns, L, Ah)
+    torch.cuda.synchronize()
+    want = _attn_ref(qkv, mask, O.relpos_bias_table(w, L), Ns, L, Ah)[4]
+    np.testing.assert_allclose(ctx.float().cpu().numpy(), want, rtol=3e-3, atol=3e-3)
+    # LayerNorm
+    x = hf(rnd((77, 768), 3, 2.0)); g, b = 1 + rnd((768,), 4, 0.1), rnd((768,), 5, 0.1)
+    y, st = torch.zeros((77, 768), device=DEV, dtype=torch.float16), torch.zeros((77, 2), device=DEV)
+    T.call("tnr_ln_fwd_f16", dev(x, torch.float16), dev(g), dev(b), 1e-12, y, st, 77, 768)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.float().cpu().numpy(), O.layer_norm_fwd(x, g, b, 1e-12)[0], rtol=2e-3, atol=2e-3)

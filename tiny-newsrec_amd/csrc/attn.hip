@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     }
     f32x16 st = zero16();
 #pragma unroll
-    for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
+    for (int s = 0; s < 4; ++s) st = TNR_MFMA_32x32x16(kf[s], qf[s], st, 0, 0, 0);
 
     const float* relp = rel + a * 1024 + row * 32;
     const float* mp = mask_add + n * 32;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         o[ct] = zero16();
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[s], tr_frag(my, s, ct, lane), o[ct], 0, 0, 0);
+            o[ct] = TNR_MFMA_32x32x16(pf[s], tr_frag(my, s, ct, lane), o[ct], 0, 0, 0);
     }
     acc_to_lds(my, o[0], 0, lane, 1.0f);
     acc_to_lds(my, o[1], 1, lane, 1.0f);
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     f32x16 st = zero16(), dpt = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], df[s], dpt, 0, 0, 0);
+        st = TNR_MFMA_32x32x16(kf[s], qf[s], st, 0, 0, 0);
+        dpt = TNR_MFMA_32x32x16(vf[s], df[s], dpt, 0, 0, 0);
     }
     {
         const float* relp = rel + a * 1024 + row * 32;
@@ -224,15 +224,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         dq[ct] = zero16();
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            dq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dstf[s], tr_frag(tK, s, ct, lane), dq[ct], 0, 0, 0);
+            dq[ct] = TNR_MFMA_32x32x16(dstf[s], tr_frag(tK, s, ct, lane), dq[ct], 0, 0, 0);
     }
 
     // ---- natural orientation: lanes = keys, regs = queries
     f32x16 sn = zero16(), dpn = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[s], kf[s], sn, 0, 0, 0);
-        dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[s], vf[s], dpn, 0, 0, 0);
+        sn = TNR_MFMA_32x32x16(qf[s], kf[s], sn, 0, 0, 0);
+        dpn = TNR_MFMA_32x32x16(df[s], vf[s], dpn, 0, 0, 0);
     }
     {
         const float mk = mp[row];                  // this lane's key
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         dk[ct] = zero16();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            dv[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pnf[s], tr_frag(tO, s, ct, lane), dv[ct], 0, 0, 0);
-            dk[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf[s], tr_frag(tQ, s, ct, lane), dk[ct], 0, 0, 0);
+            dv[ct] = TNR_MFMA_32x32x16(pnf[s], tr_frag(tO, s, ct, lane), dv[ct], 0, 0, 0);
+            dk[ct] = TNR_MFMA_32x32x16(dsf[s], tr_frag(tQ, s, ct, lane), dk[ct], 0, 0, 0);
         }
     }
     // ---- bias gradient partials: column sums over the 32 token rows (rows >= L are exactly zero: padded
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
 
 }  // namespace
 
-extern "C" int tnr_attn_l32_fwd(const void* qkv, const float* mask_add, const float* rel, void* ctx, int64_t n_seq,
+extern "C" int TNR_NAME(tnr_attn_l32_fwd)(const void* qkv, const float* mask_add, const float* rel, void* ctx, int64_t n_seq,
                                 int L, int A, void* stream) {
     TNR_CHECK_ARG(qkv && mask_add && rel && ctx, "tnr_attn_l32_fwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 32 && A >= 1 && n_seq >= 1, "tnr_attn_l32_fwd: need 1<=L<=32");
@@ -320,7 +320,7 @@ extern "C" int tnr_attn_l32_fwd(const void* qkv, const float* mask_add, const fl
     return TNR_OK;
 }
 
-extern "C" int tnr_attn_l32_bwd(const void* qkv, const float* mask_add, const float* rel, const void* dctx, void* dqkv,
+extern "C" int TNR_NAME(tnr_attn_l32_bwd)(const void* qkv, const float* mask_add, const float* rel, const void* dctx, void* dqkv,
                                 float* bias_part, int64_t n_seq, int L, int A, void* stream) {
     TNR_CHECK_ARG(qkv && mask_add && rel && dctx && dqkv, "tnr_attn_l32_bwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 32 && A >= 1 && n_seq >= 1, "tnr_attn_l32_bwd: need 1<=L<=32");

@@ -6,10 +6,23 @@
 
 #include "../../include/tnr_hip.h"
 
+// The 16-bit activation type.  The sources are compiled twice: once with bf16 (entry points tnr_*) and once
+// with -DTNR_F16 (IEEE half, entry points tnr_*_f16, same MFMA rate, 3 more mantissa bits).  The identifier
+// `bf16` below means "the 16-bit type of this build".
+#ifdef TNR_BUILD_F16
+typedef _Float16 bf16;
+#define TNR_NAME(x) x##_f16
+#define TNR_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define TNR_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
 typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#define TNR_NAME(x) x
+#define TNR_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define TNR_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
+typedef __attribute__((ext_vector_type(8))) bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -76,5 +89,5 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // transposed LDS read: per 16-lane group a 4-row x 16-col block of 16-bit elements, delivered
 // column-major (lane i gets column i, rows 0..3); lane 4q+p supplies the address of row q, cols 4p..4p+3.
 __device__ __forceinline__ bf16x4 ds_read_tr16(const void* lds_ptr) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)lds_ptr);
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_ptr));
 }

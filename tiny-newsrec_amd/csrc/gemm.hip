@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs g) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], yf[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TNR_MFMA_16x16x32(xf[j], yf[i], acc[i][j], 0, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
         cur = cur == 2 ? 0 : cur + 1;
         nxt = nxt == 2 ? 0 : nxt + 1;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(TNArgs g) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], yf[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TNR_MFMA_16x16x32(xf[j], yf[i], acc[i][j], 0, 0, 0);
             }
             cur = cur == 2 ? 0 : cur + 1;
             nxt = nxt == 2 ? 0 : nxt + 1;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
     nt_epilogue_coalesced(g, acc, smem, lut, bm, bn, wm, wn, lane);
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_persistent_kernel(NTArg
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
             cur ^= 1;
         }
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], yf[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TNR_MFMA_16x16x32(xf[j], yf[i], acc[i][j], 0, 0, 0);
             }
         }
     }
@@ -978,19 +978,19 @@ __global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int
 
 }  // namespace
 
-extern "C" int tnr_gemm_nt_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                               void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream);
 
-extern "C" int tnr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+extern "C" int TNR_NAME(tnr_gemm_nt)(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                            int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                            void* aux, int64_t ldaux, int flags, void* stream) {
-    return tnr_gemm_nt_ex(A, lda, B, ldb, C, ldc, M, N, K, bias, res, ldres, aux, ldaux, flags, nullptr, stream);
+    return TNR_NAME(tnr_gemm_nt_ex)(A, lda, B, ldb, C, ldc, M, N, K, bias, res, ldres, aux, ldaux, flags, nullptr, stream);
 }
 
-extern "C" int64_t tnr_gemm_colsum_rows(int64_t M) { return ((M + 255) / 256) * 4; }
+extern "C" int64_t TNR_NAME(tnr_gemm_colsum_rows)(int64_t M) { return ((M + 255) / 256) * 4; }
 
-extern "C" int tnr_gemm_nt_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                               void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream) {
     TNR_CHECK_ARG(A && B && C, "tnr_gemm_nt: null operand");
@@ -1051,9 +1051,9 @@ extern "C" int tnr_gemm_nt_ex(const void* A, int64_t lda, const void* B, int64_t
     return TNR_OK;
 }
 
-extern "C" int64_t tnr_gemm_tn_ws_elems(int64_t N, int64_t K, int splits) { return N * K * (int64_t)splits; }
+extern "C" int64_t TNR_NAME(tnr_gemm_tn_ws_elems)(int64_t N, int64_t K, int splits) { return N * K * (int64_t)splits; }
 
-extern "C" int tnr_gemm_tn_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
+extern "C" int TNR_NAME(tnr_gemm_tn_wgrad)(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
                                  int64_t lddw, int64_t M, int64_t N, int64_t K, float* ws, int splits,
                                  int accumulate, void* stream) {
     TNR_CHECK_ARG(dY && X && dW && ws, "tnr_gemm_tn_wgrad: null operand");

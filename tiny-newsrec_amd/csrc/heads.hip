@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const bf16* __restrict
     }
 }
 
+#ifndef TNR_BUILD_F16
 // ------------------------------------------------------------------------------------------------
 // small batched fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain): tile 64x64, BK 16
 struct SgemmArgs {
@@ -511,9 +512,11 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
     }
 }
 
+#endif   // !TNR_BUILD_F16 (type-independent fp32 kernels are compiled once)
+
 }  // namespace
 
-extern "C" int tnr_attpool_fwd(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
+extern "C" int TNR_NAME(tnr_attpool_fwd)(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
                                float* nv, float* alpha, float* den, int64_t n_seq, int L, int H, void* stream) {
     TNR_CHECK_ARG(y && e && w2 && b2 && nv && alpha && den, "tnr_attpool_fwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 32 && (H % 4) == 0 && Q >= 1 && lde >= Q && n_seq >= 1, "tnr_attpool_fwd: bad shape");
@@ -523,7 +526,7 @@ extern "C" int tnr_attpool_fwd(const void* y, const float* e, int64_t lde, const
     return TNR_OK;
 }
 
-extern "C" int tnr_attpool_bwd(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
+extern "C" int TNR_NAME(tnr_attpool_bwd)(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
                                const float* alpha, const float* den, void* dy_direct, void* dpre, int64_t lddpre,
                                float* dw2_part, float* db2_part, float* db1_part, int64_t n_seq, int L, int H, void* stream) {
     (void)den;
@@ -536,6 +539,7 @@ extern "C" int tnr_attpool_bwd(const void* y, const float* e, int64_t lde, const
     return TNR_OK;
 }
 
+#ifndef TNR_BUILD_F16
 extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
                                void* stream);
 
@@ -652,3 +656,5 @@ extern "C" int tnr_score_bwd(const float* vec, const int32_t* cidx, const float*
     TNR_CHECK_LAUNCH("tnr_score_bwd");
     return TNR_OK;
 }
+
+#endif   // !TNR_BUILD_F16

@@ -290,6 +290,7 @@ __global__ void cast_b2f_kernel(const bf16* __restrict__ s, float* __restrict__ 
 
 }  // namespace
 
+#ifndef TNR_BUILD_F16
 extern "C" int tnr_relpos_table(const float* weight, int A, int L, float* table, void* stream) {
     TNR_CHECK_ARG(weight && table && A >= 1 && L >= 1 && L <= 32, "tnr_relpos_table: need 1<=L<=32");
     hipLaunchKernelGGL(relpos_kernel, dim3((A * 1024 + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, A, L, table);
@@ -297,7 +298,9 @@ extern "C" int tnr_relpos_table(const float* weight, int A, int L, float* table,
     return TNR_OK;
 }
 
-extern "C" int tnr_embed_ln_fwd(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
+#endif
+
+extern "C" int TNR_NAME(tnr_embed_ln_fwd)(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
                                 const float* type0, const float* gamma, const float* beta, float eps, void* out,
                                 float* mask_add, void* stream) {
     TNR_CHECK_ARG(tok && word && pos && type0 && gamma && beta && out && mask_add, "tnr_embed_ln_fwd: null pointer");
@@ -313,7 +316,7 @@ extern "C" int tnr_embed_ln_fwd(const int64_t* tok, int64_t n_seq, int L, int H,
     return TNR_OK;
 }
 
-extern "C" int tnr_embed_ln_fwd_indexed(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
+extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed)(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
                                         const float* word, const float* pos, const float* type0, const float* gamma,
                                         const float* beta, float eps, void* out, float* mask_add, void* stream) {
     TNR_CHECK_ARG(news_combined && nidx && word && pos && type0 && gamma && beta && out && mask_add,
@@ -330,7 +333,7 @@ extern "C" int tnr_embed_ln_fwd_indexed(const int32_t* news_combined, const int3
     return TNR_OK;
 }
 
-extern "C" int tnr_ln_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* stats,
+extern "C" int TNR_NAME(tnr_ln_fwd)(const void* x, const float* gamma, const float* beta, float eps, void* y, float* stats,
                           int64_t M, int H, void* stream) {
     TNR_CHECK_ARG(x && gamma && beta && y && M >= 1, "tnr_ln_fwd: null pointer");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_ln_fwd: H must be 256/512/768/1024");
@@ -343,6 +346,7 @@ extern "C" int tnr_ln_fwd(const void* x, const float* gamma, const float* beta, 
     return TNR_OK;
 }
 
+#ifndef TNR_BUILD_F16
 extern "C" int64_t tnr_ln_bwd_part_elems(int64_t M, int H) { return ((M + LNB_ROWS - 1) / LNB_ROWS) * 3 * H; }
 
 extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
@@ -371,7 +375,12 @@ extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, 
     return TNR_OK;
 }
 
-extern "C" int tnr_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+#else
+extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
+                               void* stream);
+#endif
+
+extern "C" int TNR_NAME(tnr_ln_bwd)(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                           float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream) {
     TNR_CHECK_ARG(dy && x && stats && gamma && dx && M >= 1, "tnr_ln_bwd: null pointer");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_ln_bwd: H must be 256/512/768/1024");
@@ -394,16 +403,18 @@ extern "C" int tnr_ln_bwd(const void* dy, const void* x, const float* stats, con
     return TNR_OK;
 }
 
+#ifndef TNR_BUILD_F16
 extern "C" int64_t tnr_colsum_part_elems(int64_t M, int64_t N) { return ((M + CS_ROWS - 1) / CS_ROWS) * N; }
+#endif
 
-extern "C" int tnr_colsum_batched(const void* X, int64_t ldx, int64_t sX, int dtype, int64_t M, int64_t N, int batch,
+extern "C" int TNR_NAME(tnr_colsum_batched)(const void* X, int64_t ldx, int64_t sX, int dtype, int64_t M, int64_t N, int batch,
                                   float* out, float* part, int accumulate, void* stream) {
     TNR_CHECK_ARG(X && out && part && M >= 1 && N >= 4 && (N % 4) == 0 && (ldx % 4) == 0 && batch >= 1, "tnr_colsum: bad argument");
-    TNR_CHECK_ARG(dtype == TNR_BF16 || dtype == TNR_F32, "tnr_colsum: dtype");
+    TNR_CHECK_ARG(dtype == TNR_BF16 || dtype == TNR_F16 || dtype == TNR_F32, "tnr_colsum: dtype");
     int64_t nby = (M + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)nby, (unsigned)batch), blk(256);
     // partials laid out (nby, batch, N) so that ONE row reduction yields out (batch, N)
-    if (dtype == TNR_BF16)
+    if (dtype != TNR_F32)      // the 16-bit type of this build
         hipLaunchKernelGGL(colsum_kernel<bf16>, grid, blk, 0, (hipStream_t)stream, (const bf16*)X, ldx, M, N, part, sX, N);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)X, ldx, M, N, part, sX, N);
@@ -411,18 +422,18 @@ extern "C" int tnr_colsum_batched(const void* X, int64_t ldx, int64_t sX, int dt
     return tnr_reduce_rows(part, nby, (int64_t)batch * N, (int64_t)batch * N, out, accumulate, stream);
 }
 
-extern "C" int tnr_colsum(const void* X, int64_t ldx, int dtype, int64_t M, int64_t N, float* out, float* part,
+extern "C" int TNR_NAME(tnr_colsum)(const void* X, int64_t ldx, int dtype, int64_t M, int64_t N, float* out, float* part,
                           int accumulate, void* stream) {
-    return tnr_colsum_batched(X, ldx, 0, dtype, M, N, 1, out, part, accumulate, stream);
+    return TNR_NAME(tnr_colsum_batched)(X, ldx, 0, dtype, M, N, 1, out, part, accumulate, stream);
 }
 
-extern "C" int tnr_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+extern "C" int TNR_NAME(tnr_cast_f32_to_bf16)(const float* src, void* dst, int64_t n, void* stream) {
     TNR_CHECK_ARG(src && dst && n >= 1, "tnr_cast_f32_to_bf16: bad argument");
     hipLaunchKernelGGL(cast_f2b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n);
     TNR_CHECK_LAUNCH("tnr_cast_f32_to_bf16");
     return TNR_OK;
 }
-extern "C" int tnr_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+extern "C" int TNR_NAME(tnr_cast_bf16_to_f32)(const void* src, float* dst, int64_t n, void* stream) {
     TNR_CHECK_ARG(src && dst && n >= 1, "tnr_cast_bf16_to_f32: bad argument");
     hipLaunchKernelGGL(cast_b2f_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, dst, n);
     TNR_CHECK_LAUNCH("tnr_cast_bf16_to_f32");

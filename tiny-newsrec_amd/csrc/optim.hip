@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void refresh_kernel(const int64_t* __restrict_
 
 }  // namespace
 
+#ifndef TNR_BUILD_F16
 extern "C" int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step, float lr,
                                 float beta1, float beta2, float eps, float grad_scale, void* stream) {
     TNR_CHECK_ARG(p && g && m && v && vmax && n >= 1 && step >= 1, "tnr_amsgrad_step: bad argument");
@@ -88,7 +89,9 @@ extern "C" int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, fl
     return TNR_OK;
 }
 
-extern "C" int tnr_refresh_shadows(const int64_t* desc, int n_desc, int64_t total_tiles, const int64_t* tile_start,
+#endif
+
+extern "C" int TNR_NAME(tnr_refresh_shadows)(const int64_t* desc, int n_desc, int64_t total_tiles, const int64_t* tile_start,
                                    void* stream) {
     TNR_CHECK_ARG(desc && tile_start && n_desc >= 1 && total_tiles >= 1, "tnr_refresh_shadows: bad argument");
     hipLaunchKernelGGL(refresh_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, desc, n_desc,

@@ -120,9 +120,20 @@ def is_trainable(cfg, name):
     return True
 
 
+LOSS_SCALE = 1024.0     # static scale of the 16-bit backward in fp16 mode (gradients of ~1e-6 would underflow)
+
+
 class Engine:
-    def __init__(self, cfg, device="cuda:0", max_batch=32):
+    def __init__(self, cfg, device="cuda:0", max_batch=32, dtype="bf16"):
+        """dtype: 16-bit activation / weight-copy type, "bf16" (default) or "fp16".  fp16 has the same MFMA rate and
+        3 more mantissa bits; its backward runs on gradients scaled by LOSS_SCALE from the pooling backward down
+        (everything 16-bit), un-scaled inside the AMSGrad kernel."""
         T.lib()                      # fail loudly if the HIP library is missing
+        assert dtype in ("bf16", "fp16")
+        self.f16 = dtype == "fp16"
+        self.dtype = dtype
+        self.tdt = torch.float16 if self.f16 else torch.bfloat16
+        self.gscale = LOSS_SCALE if self.f16 else 1.0
         self.cfg, self.dev = cfg, torch.device(device)
         self.step_count = 0
         self._n_alloc = 0
@@ -200,6 +211,13 @@ class Engine:
             if tr:
                 self.grads[name] = self.flat_g[o:o + n].view(shp)
 
+    def _c(self, name, *args):
+        """Kernel call; 16-bit entry points take the _f16 variant in fp16 mode."""
+        T.call(name + "_f16" if (self.f16 and name in T.TYPED) else name, *args)
+
+    def _q(self, name, *args):
+        return T.query(name + "_f16" if (self.f16 and name in T.TYPED) else name, *args)
+
     def p(self, name):
         return self.params[name]
 
@@ -229,7 +247,7 @@ class Engine:
 
     # ------------------------------------------------------------------ bf16 weight copies
     def _build_shadows(self):
-        cfg, dev, bf = self.cfg, self.dev, torch.bfloat16
+        cfg, dev, bf = self.cfg, self.dev, self.tdt
         H, I = cfg.H, cfg.I
         lo = min(cfg.trainable_layers) if cfg.trainable_layers else cfg.n_layers
         self.lo = lo
@@ -270,13 +288,13 @@ class Engine:
 
     def refresh_shadows(self, all_layers=False):
         d = self.desc_all if all_layers else self.desc_train
-        T.call("tnr_refresh_shadows", d[0], d[1], d[2], d[3])
+        self._c("tnr_refresh_shadows", d[0], d[1], d[2], d[3])
         if all_layers:
             T.call("tnr_relpos_table", self.p(BERT + "rel_pos_bias.weight"), self.cfg.A, self.cfg.L, self.rel)
 
     # ------------------------------------------------------------------ workspaces
     def _alloc_workspace(self, B):
-        cfg, dev, bf = self.cfg, self.dev, torch.bfloat16
+        cfg, dev, bf = self.cfg, self.dev, self.tdt
         H, I, D, L = cfg.H, cfg.I, cfg.D, cfg.L
         N = B * (cfg.U + cfg.C)
         Mp = _rup(N * L, 128)
@@ -343,19 +361,19 @@ class Engine:
     # ------------------------------------------------------------------ kernel wrappers
     def _gemm(self, a, w, c, M, bias=None, res=None, aux=None, flags=0, colsum=None):
         N, K = w.shape
-        T.call("tnr_gemm_nt_ex", a, a.stride(0), w, w.stride(0), c, c.stride(0), M, N, K, bias, res,
+        self._c("tnr_gemm_nt_ex", a, a.stride(0), w, w.stride(0), c, c.stride(0), M, N, K, bias, res,
                res.stride(0) if res is not None else 0, aux, aux.stride(0) if aux is not None else 0, flags, colsum)
 
     def _wgrad(self, dy, x, dw, M):
         N, K = dw.shape
-        T.call("tnr_gemm_tn_wgrad", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws,
+        self._c("tnr_gemm_tn_wgrad", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws,
                self._wgrad_splits(N, K)[0], 0)
 
-    def _colsum(self, x, out, M, dtype=T.BF16):
-        T.call("tnr_colsum", x, x.stride(0), dtype, M, x.shape[1], out, self.cs_part, 0)
+    def _colsum(self, x, out, M, dtype=T.BF16):   # dtype BF16 = "the 16-bit type of the build"
+        self._c("tnr_colsum", x, x.stride(0), dtype, M, x.shape[1], out, self.cs_part, 0)
 
-    def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, ksplit=1):
-        T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, 1.0, 0.0,
+    def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, ksplit=1, alpha=1.0):
+        T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, alpha, 0.0,
                ksplit, self.sg_part if ksplit > 1 else None)
 
     # ------------------------------------------------------------------ forward
@@ -371,9 +389,9 @@ class Engine:
                g(BERT + "embeddings.token_type_embeddings.weight"), g(BERT + "embeddings.LayerNorm.weight"),
                g(BERT + "embeddings.LayerNorm.bias"), cfg.ln_eps, self.x0, self.mask_add)
         if nidx is None:
-            T.call("tnr_embed_ln_fwd", tok, n_seq, L, H, *emb)
+            self._c("tnr_embed_ln_fwd", tok, n_seq, L, H, *emb)
         else:
-            T.call("tnr_embed_ln_fwd_indexed", tok, nidx, n_seq, L, H, *emb)
+            self._c("tnr_embed_ln_fwd_indexed", tok, nidx, n_seq, L, H, *emb)
         x = self.x0
         self.x_in = {}
         for l in range(cfg.n_layers):
@@ -385,18 +403,18 @@ class Engine:
             bqkv = self._view(names[3], 3 * H, (3 * H,))
             self.x_in[l] = x
             self._gemm(x, sh["qkv"], a["qkv"], M, bias=bqkv, flags=T.EPI_BIAS)
-            T.call("tnr_attn_l32_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A)
+            self._c("tnr_attn_l32_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A)
             self._gemm(a["ctx"], sh["o"], a["h1pre"], M, bias=g(names[7]), res=x, flags=T.EPI_BIAS | T.EPI_RES)
-            T.call("tnr_ln_fwd", a["h1pre"], g(names[8]), g(names[9]), cfg.ln_eps, a["h1"], a["st1"], M, H)
+            self._c("tnr_ln_fwd", a["h1pre"], g(names[8]), g(names[9]), cfg.ln_eps, a["h1"], a["st1"], M, H)
             fl = T.EPI_BIAS | T.EPI_GELU | (T.EPI_AUXOUT if kept else 0)
             self._gemm(a["h1"], sh["w1"], a["g"], M, bias=g(names[11]), aux=a["u"] if kept else None, flags=fl)
             self._gemm(a["g"], sh["w2"], a["ypre"], M, bias=g(names[13]), res=a["h1"], flags=T.EPI_BIAS | T.EPI_RES)
-            T.call("tnr_ln_fwd", a["ypre"], g(names[14]), g(names[15]), cfg.ln_eps, y, a["st2"], M, H)
+            self._c("tnr_ln_fwd", a["ypre"], g(names[14]), g(names[15]), cfg.ln_eps, y, a["st2"], M, H)
             x = y
         self.y_last = x
         # AttentionPooling (no mask) + dense  model_bert.py:133-136
         self._gemm(x, self.sh_a1, self.e, M, bias=self.b_a1, flags=T.EPI_BIAS | T.EPI_TANH | T.EPI_OUTF32)
-        T.call("tnr_attpool_fwd", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
+        self._c("tnr_attpool_fwd", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
                self.nv, self.alpha, self.den, n_seq, L, H)
         wd = g(PFX + "dense.weight")
         self._sgemm(self.nv, H, 1, 0, wd, H, 1, 0, self.S, cfg.D, 0, g(PFX + "dense.bias"), 0, n_seq, cfg.D, H)
@@ -507,7 +525,7 @@ class Engine:
             dbt = self._view("transform_matrix.0.bias", T_ * D, (T_, D), grad=True)
             self._sgemm(self.dP, 1, D, Rt * D, self.X, 1, D, self.X.stride(0), dWt, D, D * D, None, 0, D, D, Rt, batch=T_,
                         ksplit=self.KS)
-            T.call("tnr_colsum_batched", self.dP, D, Rt * D, T.F32, Rt, D, T_, dbt, self.cs_part, 0)
+            self._c("tnr_colsum_batched", self.dP, D, Rt * D, T.F32, Rt, D, T_, dbt, self.cs_part, 0)
         # scorer + user encoder
         T.call("tnr_score_bwd", S, cidx, S[N:], self.dscore, dS, dS[N:], B, C, D)
         ue = "student.user_encoder."
@@ -520,10 +538,10 @@ class Engine:
         dvec = dS[:N]
         wd = g(PFX + "dense.weight")
         self._sgemm(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N, ksplit=self.KS)
-        T.call("tnr_colsum", dvec, D, T.F32, N, D, gr[PFX + "dense.bias"], self.cs_part, 0)
-        self._sgemm(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D)
+        self._c("tnr_colsum", dvec, D, T.F32, N, D, gr[PFX + "dense.bias"], self.cs_part, 0)
+        self._sgemm(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D, alpha=self.gscale)   # loss scale enters here
         y = self.y_last
-        T.call("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
+        self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
                self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
         T.call("tnr_reduce_rows", self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], 0)
         T.call("tnr_reduce_rows", self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], 0)
@@ -541,7 +559,7 @@ class Engine:
             tr = l in cfg.trainable_layers
             x_in = self.x_in[l]
             # bias gradients ride along: dx column sums from LayerNorm backward, the dgrad epilogue, attention backward
-            T.call("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, gr[names[14]] if tr else None,
+            self._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, gr[names[14]] if tr else None,
                    gr[names[15]] if tr else None, gr[names[13]] if tr else None, self.ln_part, M, H)
             if tr:
                 self._wgrad(self.dypre, a["g"], gr[names[12]], M)
@@ -551,12 +569,12 @@ class Engine:
                 T.call("tnr_reduce_rows", self.gcs_part, self.gcs_part.shape[0], I, I, gr[names[11]], 0)
                 self._wgrad(self.du, a["h1"], gr[names[10]], M)
             self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
-            T.call("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, gr[names[8]] if tr else None,
+            self._c("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, gr[names[8]] if tr else None,
                    gr[names[9]] if tr else None, gr[names[7]] if tr else None, self.ln_part, M, H)
             if tr:
                 self._wgrad(self.dh1pre, a["ctx"], gr[names[6]], M)
             self._gemm(self.dh1pre, sh["oT"], self.dctx, M)
-            T.call("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv,
+            self._c("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv,
                    self.qkvb_part if tr else None, N, L, cfg.A)
             if tr:
                 T.call("tnr_reduce_rows", self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), 0)
@@ -568,6 +586,12 @@ class Engine:
             if tr and after_bucket:
                 after_bucket(bucket)
                 bucket += 1
+
+    def grad(self, name):
+        """Gradient of a trainable parameter with the fp16 loss scale removed (flat_g itself stays scaled until
+        the AMSGrad kernel divides it out)."""
+        g = self.grads[name]
+        return g / self.gscale if (self.gscale != 1.0 and self.off(name) < self.off(PFX + "dense.weight")) else g
 
     def bucket_ranges(self):
         """Contiguous [start, end) slices of flat_g in the order their gradients complete."""
@@ -583,6 +607,8 @@ class Engine:
     def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
         """torch.optim.Adam(amsgrad=True).step() (run.py:134,195) + refresh of the bf16 weight copies."""
         self.step_count += 1
-        T.call("tnr_amsgrad_step", self.flat[True], self.flat_g, self.adam_m, self.adam_v, self.adam_vmax, self.n_train,
-               self.step_count, lr, beta1, beta2, eps, grad_scale)
+        cut = self.off(PFX + "dense.weight")     # [0, cut): encoder layers + pooling head = gradients carrying the loss scale
+        for lo_, hi_, sc in ((0, cut, grad_scale / self.gscale), (cut, self.n_train, grad_scale)):
+            T.call("tnr_amsgrad_step", self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_],
+                   self.adam_v[lo_:hi_], self.adam_vmax[lo_:hi_], hi_ - lo_, self.step_count, lr, beta1, beta2, eps, sc)
         self.refresh_shadows(all_layers=False)

@@ -79,7 +79,8 @@ class Model(_Shell):
         super().__init__()
         self.args = args
         dev = device or ("cuda:%d" % torch.cuda.current_device())
-        self.engine = E.Engine(engine_config_from_args(args), dev, max_batch=max_batch or args.batch_size)
+        self.engine = E.Engine(engine_config_from_args(args), dev, max_batch=max_batch or args.batch_size,
+                               dtype=getattr(args, "dtype", "bf16"))
         self._adopt(self.engine, "")
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self._after_bucket = None
@@ -93,7 +94,7 @@ class Model(_Shell):
     def _bind_grads(self):
         for k, p in self.named_parameters():
             if p.requires_grad and p.grad is None:
-                p.grad = self.engine.grads[k]
+                p.grad = self.engine.grads[k]      # NB fp16 mode: encoder/pooling grads carry engine.gscale until step()
 
     def load_state_dict(self, sd, strict=True):
         out = super().load_state_dict(sd, strict=strict)

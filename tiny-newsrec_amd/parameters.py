@@ -65,6 +65,7 @@ _FLAGS = [
     ("num_teachers", int, 4),
     # --- additions (defaults keep the reference behaviour)
     ("resident_tables", _B, True, dict(help="keep news_combined / teacher tables in HBM and ship indices only")),
+    ("dtype", str, "bf16", dict(choices=["bf16", "fp16"], help="16-bit activation type of the HIP kernels")),
     ("synthetic", _B, False, dict(help="random-init weights + synthetic MIND-shaped data (no files needed)")),
 ]
 

@@ -49,7 +49,14 @@ _SIG = {
     "tnr_cast_f32_to_bf16": [_P, _P, _L, _P],
     "tnr_cast_bf16_to_f32": [_P, _P, _L, _P],
 }
-_RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_gemm_colsum_rows": _L, "tnr_ln_bwd_part_elems": _L, "tnr_colsum_part_elems": _L,
+# entry points that exist twice: bf16 (plain name) and fp16 (suffix _f16)
+TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_colsum_rows",
+         "tnr_gemm_tn_wgrad", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd",
+         "tnr_colsum", "tnr_colsum_batched", "tnr_attpool_fwd", "tnr_attpool_bwd", "tnr_refresh_shadows",
+         "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32"]
+for _n in TYPED:
+    _SIG[_n + "_f16"] = _SIG[_n]
+_RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_gemm_tn_ws_elems_f16": _L, "tnr_gemm_colsum_rows_f16": _L, "tnr_gemm_colsum_rows": _L, "tnr_ln_bwd_part_elems": _L, "tnr_colsum_part_elems": _L,
         "tnr_user_bwd_part_stride": _L}
 EXPORTS = sorted(_SIG) + ["tnr_last_error"]
 
@@ -94,7 +101,7 @@ TIMED = {}
 
 
 def _work(name, conv):
-    if name in ("tnr_gemm_nt", "tnr_gemm_nt_ex"):
+    if name in ("tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_nt_f16", "tnr_gemm_nt_ex_f16"):
         return 2.0 * conv[6] * conv[7] * conv[8]
     if name == "tnr_gemm_tn_wgrad":
         return 2.0 * conv[6] * conv[7] * conv[8]
