@@ -563,8 +563,10 @@ constexpr int EPI_LD = 256 * 4 + 16;                 // bytes per staged row
 constexpr int EPI_BYTES = 128 * EPI_LD;              // 133,120 B
 constexpr int LDS3_BYTES = EPI_BYTES + LUT_N * 8;
 
-__device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&acc)[8][4], char* smem, const f32x2* lut,
+template <int MI>
+__device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&acc)[MI][4], char* smem, const f32x2* lut,
                                                       int bm, int bn, int wm, int wn, int lane) {
+    constexpr int PR = 16 * MI;          // rows per pass (= rows per wave), tile height 2 * PR
     const int flags = g.flags;
     const int tid = threadIdx.x;
     const int c8 = (tid & 31) * 8, rg = tid >> 5;            // 8 columns, row group 0..15
@@ -582,17 +584,17 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
         __syncthreads();                                       // staging area free (K loop / previous pass done)
         if (wm == pass) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     *(f32x4*)(smem + (i * 16 + (lane & 15)) * EPI_LD + (wn * 64 + j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
         }
         __syncthreads();
-        const int m0 = bm * 256 + pass * 128;
-        bf16x8 rr[8], uu[8];
+        const int m0 = bm * (2 * PR) + pass * PR;
+        bf16x8 rr[MI], uu[MI];
         if (flags & TNR_EPI_RES) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < MI; ++it) {
                 int m = m0 + rg + 16 * it;
                 m = m < g.M ? m : g.M - 1;
                 rr[it] = *(const bf16x8*)(g.res + (int64_t)m * g.ldres + n);
@@ -600,14 +602,14 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
         }
         if (flags & TNR_EPI_MULDGELU) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < MI; ++it) {
                 int m = m0 + rg + 16 * it;
                 m = m < g.M ? m : g.M - 1;
                 uu[it] = *(const bf16x8*)(g.aux + (int64_t)m * g.ldaux + n);
             }
         }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < MI; ++it) {
             const int row = rg + 16 * it;
             const int m = m0 + row;
             if (m >= g.M) continue;
@@ -662,7 +664,7 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
-            float* pr = g.colsum_part + (int64_t)(bm * 4) * g.N + bn * 256 + tid;   // 4 partial rows per tile (v2 layout)
+            float* pr = g.colsum_part + (int64_t)(bm * 4) * g.N + bn * 256 + tid;   // 4 partial rows per row-tile (v2 layout)
             pr[0] = t;
             pr[g.N] = 0.f;
             pr[2 * (int64_t)g.N] = 0.f;
@@ -679,26 +681,32 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
 constexpr int STAGE3 = 4 * TILE_BYTES;
 constexpr int RING3 = 2 * STAGE3;
 
-template <int PROBE>
+// MI = 16-row MFMA tiles per wave along M: tile height BM = 32 * MI (256 or 224).  The host picks the height
+// that minimises ceil(tiles / CUs) * BM for the launch (e.g. N = 768: 621 tiles of 256 rows = 3 rounds on 256 CUs;
+// 708 tiles of 224 rows are 3 rounds too, each 12.5 % shorter).
+template <int PROBE, int MI>
 __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PR = 16 * MI, BM = 2 * PR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;
     const int nbn = g.N >> 8;
-    const int nbm = (g.M + 255) >> 8;
+    const int nbm = (g.M + BM - 1) / BM;
     const int wg = xcd_remap(blockIdx.x, nbm * nbn);
     int bm, bn;
     tile_coords(wg, nbm, nbn, 8, bm, bn);
 
     const bf16* src[8];
     int dst[8];
+    bool live[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         int p = w * 8 + q, sub = p >> 4, pp = p & 15;
         int row = pp * 8 + (lane >> 3);
         int chunk = (lane & 7) ^ (row & 7);
+        live[q] = sub >= 2 || pp * 8 < PR;                 // A sub-tiles hold PR rows (PR/8 pieces of 8 rows)
         if (sub < 2) {
-            int gm = bm * 256 + sub * 128 + row;
+            int gm = bm * BM + sub * PR + row;
             gm = gm < g.M ? gm : g.M - 1;
             src[q] = g.A + (int64_t)gm * g.lda + chunk * 8;
         } else {
@@ -709,15 +717,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE3;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) glds16(src[q] + kt * 64, base + dst[q]);
+        for (int q = 0; q < 8; ++q)
+            if (MI == 8 || live[q]) glds16(src[q] + kt * 64, base + dst[q]);     // wave-uniform predicate
     };
     int foff[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
 
-    f32x4 acc[8][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -734,19 +743,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
         const char* sb = smem + cur * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
 #pragma unroll
         for (int s = 0; s < (PROBE == 1 ? 0 : 2); ++s) {
-            bf16x8 af[8], bfr[4];
+            bf16x8 af[MI], bfr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    nt_epilogue_coalesced(g, acc, smem, lut, bm, bn, wm, wn, lane);
+    nt_epilogue_coalesced<MI>(g, acc, smem, lut, bm, bn, wm, wn, lane);
 }
 
 // ================================================================================================
@@ -1025,8 +1034,9 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         attr_set = true;
     }
@@ -1039,9 +1049,15 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         if (probe) hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), RING2, st, g);
         else hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), RING2, st, g);
     } else if (ver == 3 || probe) {
-        int nwg = (int)(((M + 255) / 256) * (N / 256));
-        if (probe) hipLaunchKernelGGL(gemm_nt256x256_kernel<1>, dim3(nwg), dim3(512), LDS3_BYTES, st, g);
-        else hipLaunchKernelGGL(gemm_nt256x256_kernel<0>, dim3(nwg), dim3(512), LDS3_BYTES, st, g);
+        // tile height: 256 or 224 rows, whichever needs less (rounds of workgroups) x (rows per tile)
+        static const char* bm_s = getenv("TNR_GEMM_BM");
+        const int64_t t256 = ((M + 255) / 256) * (N / 256), t224 = ((M + 223) / 224) * (N / 256);
+        const int64_t c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
+        bool use224 = c224 * 108 < c256 * 100 && !(flags & TNR_EPI_COLSUM);   // per-tile fixed costs: need a clear win
+        if (bm_s) use224 = atoi(bm_s) == 224 && !(flags & TNR_EPI_COLSUM);
+        if (probe) hipLaunchKernelGGL((gemm_nt256x256_kernel<1, 8>), dim3((int)t256), dim3(512), LDS3_BYTES, st, g);
+        else if (use224) hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 7>), dim3((int)t224), dim3(512), LDS3_BYTES, st, g);
+        else hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 8>), dim3((int)t256), dim3(512), LDS3_BYTES, st, g);
     } else {
         int ntile = (int)(((M + 255) / 256) * (N / 256));
         int nwg = ntile < n_cu ? ntile : n_cu;
