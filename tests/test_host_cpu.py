@@ -158,3 +158,30 @@ def test_gradient_average_two_ranks_gloo():
     for r, flat, scale, p in res:
         assert np.array_equal(flat, want.numpy()) and scale == 0.5   # sum on the wire, 1/world folded into AMSGrad
         assert np.array_equal(p, np.zeros(10, np.float32))            # parameters broadcast from rank 0
+
+
+def test_metrics_match_sklearn_and_reference_formulas():
+    import metrics
+    from sklearn.metrics import roc_auc_score
+    rs = np.random.RandomState(0)
+    for _ in range(100):
+        n = rs.randint(2, 30)
+        y = rs.randint(0, 2, n)
+        if y.mean() in (0, 1):
+            continue
+        s = np.round(rs.randn(n), 1)           # ties included
+        assert abs(metrics.roc_auc_score(y, s) - roc_auc_score(y, s)) < 1e-12
+    y, s = np.array([0, 1, 0, 1]), np.array([0.1, 0.9, 0.8, 0.3])
+    assert abs(metrics.mrr_score(y, s) - (1 / 1 + 1 / 3) / 2) < 1e-12
+    assert abs(metrics.ndcg_score(y, s, 10) - (1 + 1 / np.log2(4)) / (1 + 1 / np.log2(3))) < 1e-12
+
+
+def test_eval_loader_index_level():
+    import dataloader
+    z = np.load(os.path.join(GOLDEN, "datapath.npz"))
+    news_index = {str(k): int(v) for k, v in zip(z["news_ids"], z["news_index"])}
+    args = types.SimpleNamespace(npratio=4, user_log_length=50, batch_size=2, shuffle_buffer_size=7, num_teachers=0)
+    dl = dataloader.DataLoaderTest(DATA, "none", args, 1, 0, 0, news_index, enable_gpu=False)
+    h, m, c, y = dl._process([b"1\tU1\tt\tN1 N2 N999\tN3-1 N4-0 N777-0"])
+    assert h.shape == (1, 50) and h[0, -3:].tolist() == [news_index["N1"], news_index["N2"], 0] and m[0].sum() == 3
+    assert c[0].tolist() == [news_index["N3"], news_index["N4"], 0] and y[0].tolist() == [1, 0, 0]

@@ -1,0 +1,94 @@
+"""GPU: forward-only paths of SURVEY.md section 8-f N2 -- news_scoring (run.py:276-287 / 438-444), the eval user
+encoder (run.py:343) and `run.test` end to end -- against the oracle on the same inputs."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import engine as E                        # noqa: E402
+import hashinit                           # noqa: E402
+from helpers import FULL, GOLDEN, state_shapes   # noqa: E402
+from oracle import newsrec_oracle as O   # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _setup(ulm=True):
+    z = np.load(os.path.join(GOLDEN, "datapath.npz"))
+    comb = z["news_combined"].astype(np.int32)                    # 41 real tokenised titles incl. pad row 0
+    P = hashinit.init_state_dict(7, state_shapes(FULL, 2, 256, 0))
+    cfg = E.EngineConfig(n_layers=2, trainable_layers=(), num_teachers=0, user_log_mask=ulm)
+    eng = E.Engine(cfg, DEV, max_batch=4)
+    eng.load_state_dict(P)
+    return z, comb, P, eng
+
+
+def test_news_scoring_and_eval_user_vectors():
+    z, comb, P, eng = _setup()
+    ns = eng.encode_news(torch.from_numpy(comb).to(DEV))
+    torch.cuda.synchronize()
+    want, _ = O.news_encoder_fwd(P, comb.astype(np.int64), 2, 12)
+    got = ns.cpu().numpy()
+    assert got.shape == want.shape == (41, 256)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1.6e-2)
+    rs = np.random.RandomState(0)
+    hidx = rs.randint(0, 41, (3, 50)).astype(np.int32)
+    mask = (rs.rand(3, 50) > 0.5).astype(np.float32)
+    mask[1] = 0
+    uv = eng.user_vectors(ns, torch.from_numpy(hidx).to(DEV), torch.from_numpy(mask).to(DEV)).cpu().numpy()
+    ref, _ = O.user_encoder_fwd(P, "student.user_encoder.", got[hidx], mask, True)
+    np.testing.assert_allclose(uv, ref, rtol=1e-4, atol=1e-5)
+    assert np.abs(uv[1]).max() == 0.0          # empty history under user_log_mask: all-zero user vector
+
+
+def test_run_test_mode_end_to_end(tmp_path, monkeypatch):
+    import metrics
+    import run
+    z, comb, P, eng = _setup()
+    del eng
+    news_index = {str(k): int(v) for k, v in zip(z["news_ids"], z["news_index"])}
+    rs = np.random.RandomState(3)
+    lines = []
+    for j in range(9):
+        hist = " ".join("N%d" % rs.randint(1, 41) for _ in range(rs.randint(0, 60)))
+        n = rs.randint(2, 12)
+        labs = rs.randint(0, 2, n)
+        if j == 4:
+            labs[:] = 0                       # skipped by the metric loop (label mean 0)
+        imp = " ".join("N%d-%d" % (rs.randint(1, 44), l) for l in labs)
+        lines.append("%d\tU%d\tt\t%s\t%s" % (j, j, hist, imp))
+    d = tmp_path / "test"
+    d.mkdir()
+    (d / "behaviors_0.tsv").write_text("\n".join(lines) + "\n")
+    torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in P.items()}, "category_dict": {}, "word_dict": None,
+                "subcategory_dict": {}}, str(tmp_path / "epoch-1.pt"))
+    monkeypatch.setattr(run, "_news_table", lambda a, dd, mode: (news_index, comb))
+    args = types.SimpleNamespace(enable_hvd=False, enable_gpu=True, model_dir=str(tmp_path), load_ckpt_name="epoch-1.pt",
+                                 test_data_dir=str(d), filename_pat="behaviors_*.tsv", batch_size=4, npratio=4,
+                                 user_log_length=50, shuffle_buffer_size=100, num_teachers=0, num_student_layers=2,
+                                 bert_trainable_layer=[], config_name=None, pooling="att", model="NAML", news_dim=256,
+                                 news_query_vector_dim=200, user_query_vector_dim=200, num_words_title=30,
+                                 user_log_mask=True, temperature=1.0, coef=1.0, num_teacher_layers=12, log_steps=1, dtype="fp16")
+    sums, n_local, n_metric = run.test(args)
+    assert n_local == 9
+    # oracle side: same pipeline in numpy
+    vec, _ = O.news_encoder_fwd(P, comb.astype(np.int64), 2, 12)
+    from oracle import data_oracle as DO
+    want, cnt = np.zeros(4), 0
+    for ln in lines:
+        f = ln.split("\t")
+        h, m = DO.pad_to_fix_len(DO.trans_to_nindex(news_index, f[3].split()), 50)
+        c = DO.trans_to_nindex(news_index, [i.split("-")[0] for i in f[4].split()])
+        y = np.array([int(i.split("-")[1]) for i in f[4].split()])
+        if y.mean() in (0, 1):
+            continue
+        u, _ = O.user_encoder_fwd(P, "student.user_encoder.", vec[np.array(h)][None], np.array(m, np.float32)[None], True)
+        sc = vec[np.array(c)] @ u[0]
+        want += [metrics.roc_auc_score(y, sc), metrics.mrr_score(y, sc), metrics.ndcg_score(y, sc, 5), metrics.ndcg_score(y, sc, 10)]
+        cnt += 1
+    assert cnt == n_metric
+    np.testing.assert_allclose(sums / n_metric, want / cnt, rtol=0, atol=0.03)     # rank flips on near-ties only

@@ -142,3 +142,29 @@ class DataLoaderTrain:
                     pass
             self._thread = None
         self.sampler = None
+
+
+class DataLoaderTest(DataLoaderTrain):
+    """Eval loader (Tiny-NewsRec/dataloader.py:208-314) at index level: lines `iid uid time history impressions`
+    with impressions = "N1-0 N2-1 ..." -> (hist_idx (B,U) int32, mask (B,U) f32, [cand_idx arrays], [label arrays])."""
+
+    def __init__(self, data_dir, filename_pat, args, world_size, worker_rank, cuda_device_idx, news_index, news_scoring=None,
+                 word_dict=None, enable_prefetch=True, enable_shuffle=False, enable_gpu=True):
+        super().__init__(data_dir, filename_pat, args, world_size, worker_rank, cuda_device_idx, news_index, None, [],
+                         word_dict, enable_prefetch, enable_shuffle, enable_gpu, resident=False)
+        self.news_scoring = news_scoring
+
+    def _process(self, batch):
+        H, M, C, Y = [], [], [], []
+        for raw in batch:
+            line = raw.decode("utf-8").split("\t")
+            click, mask = self.pad_to_fix_len(self.trans_to_nindex(line[3].split()), self.user_log_length)
+            imp = line[4].split()
+            H.append(click)
+            M.append(mask)
+            C.append(np.asarray(self.trans_to_nindex([i.split("-")[0] for i in imp]), np.int64))
+            Y.append(np.asarray([int(i.split("-")[1]) for i in imp]))
+        h, m = torch.from_numpy(np.asarray(H, np.int32)), torch.from_numpy(np.asarray(M, np.float32))
+        if self.enable_gpu:
+            h, m = h.cuda(), m.cuda()
+        return h, m, C, Y

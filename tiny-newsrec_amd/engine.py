@@ -420,6 +420,41 @@ class Engine:
         self._sgemm(self.nv, H, 1, 0, wd, H, 1, 0, self.S, cfg.D, 0, g(PFX + "dense.bias"), 0, n_seq, cfg.D, H)
         return self.S[:n_seq]
 
+    # ------------------------------------------------------------------ forward-only paths
+    @torch.no_grad()
+    def encode_news(self, news_combined):
+        """news_scoring of run.py:276-287 / :438-444: every row of the resident token table (n+1, 2L) int32
+        through NewsEncoder.forward, in passes of the workspace's sequence capacity.  -> (n+1, D) fp32."""
+        n = news_combined.shape[0]
+        cap = self.N_alloc
+        out = torch.empty((n, self.cfg.D), device=self.dev, dtype=torch.float32)
+        for s0 in range(0, n, cap):
+            cnt = min(cap, n - s0)
+            idx = torch.arange(s0, s0 + cnt, device=self.dev, dtype=torch.int32)
+            out[s0:s0 + cnt].copy_(self.encode(news_combined, cnt, nidx=idx))
+        return out
+
+    @torch.no_grad()
+    def user_vectors(self, news_scoring, hist_idx, history_mask):
+        """student.user_encoder(log_vecs, log_mask) of run.py:343 on rows of news_scoring gathered by index.
+        hist_idx (B,U) int32, mask (B,U) -> (B,D) fp32 (B <= the engine's batch)."""
+        cfg = self.cfg
+        B, U, D, Qu = hist_idx.shape[0], cfg.U, cfg.D, cfg.Qu
+        assert B <= self.B_alloc and hist_idx.shape[1] == U
+        g, ue = self.p, "student.user_encoder."
+        rows = self.X[0, :B * U]                                   # scratch: gathered history rows
+        T.call("tnr_gather_rows", news_scoring, news_scoring.shape[0], hist_idx.reshape(-1).contiguous(), B * U, D, 1, rows,
+               B * U, 0)
+        self._sgemm(rows, D, 1, 0, g(ue + "attn.att_fc1.weight"), D, 1, 0, self.epre_u, Qu, 0, g(ue + "attn.att_fc1.bias"), 0,
+                    B * U, Qu, D)
+        hidx = self.hidx[:B]
+        mask = history_mask.to(torch.float32).contiguous()
+        T.call("tnr_user_score_fwd", rows, B * U, hidx, hidx, mask, g(ue + "pad_doc"), g(ue + "attn.att_fc1.weight"),
+               g(ue + "attn.att_fc1.bias"), g(ue + "attn.att_fc2.weight"), g(ue + "attn.att_fc2.bias"),
+               int(cfg.user_log_mask), self.epre_u, self.dS, B * D, self.score, self.e_u, self.alpha_u, self.den_u, 1, B, U, 0,
+               D, Qu)
+        return self.dS[:B].clone()
+
     def _prepare(self, B):
         # buffers are sized for the exact batch: row strides of the stacked (T, Rt, D) arrays and the
         # zero rows the wgrad kernels rely on (rows [M, roundup(M,64))) both depend on it.  Only the last,

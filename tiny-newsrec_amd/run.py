@@ -121,12 +121,91 @@ def train(args):
         loader.join()
 
 
+def _news_table(args, data_dir, mode):
+    from preprocess import get_doc_input_bert, read_news_bert
+    if mode == "train":
+        news, news_index, cat, sub = read_news_bert(os.path.join(data_dir, "news.tsv"), args, mode="train")
+    else:
+        news, news_index = read_news_bert(os.path.join(data_dir, "news.tsv"), args, mode="test")
+        cat, sub = {}, {}
+    title, mask, _, _ = get_doc_input_bert(news, news_index, cat, sub, args)
+    return news_index, np.concatenate([title, mask], axis=-1).astype(np.int32)
+
+
+def _forward_engine(args, n_layers, sd, add_prefix=""):
+    """Frozen engine (no teachers, nothing trainable).  sd: reference Model keys ("student. ...") or, with
+    add_prefix="student.", PLM-NR ModelBert keys ("news_encoder. ...", "user_encoder. ...")."""
+    import types
+    import engine as E
+    from model_bert import engine_config_from_args
+    a = types.SimpleNamespace(**vars(args))
+    a.num_student_layers, a.bert_trainable_layer = n_layers, []
+    cfg = engine_config_from_args(a, num_teachers=0)
+    eng = E.Engine(cfg, "cuda:%d" % torch.cuda.current_device(), max_batch=args.batch_size, dtype=getattr(args, "dtype", "bf16"))
+    src = {add_prefix + k: v for k, v in sd.items()}
+    eng.load_state_dict({k: src[k] for k in eng.shapes})
+    return eng
+
+
 def get_teacher_emb(args):
-    raise NotImplementedError("get_teacher_emb (run.py:382-460) is SURVEY section 8-f N2; Engine.encode() is its forward path")
+    """run.py:382-460: every train news through each teacher's news encoder -> pickled (n+1, D) float32 tables."""
+    utils.init_hvd_cuda(False, args.enable_gpu)
+    _, news_combined = _news_table(args, args.train_data_dir, "train")
+    dev_news = torch.from_numpy(news_combined).cuda()
+    for ckpt_path, out_path in zip(args.teacher_ckpts, args.teacher_emb_paths):
+        sd = torch.load(ckpt_path, map_location="cpu")["model_state_dict"]          # PLM-NR keys: news_encoder.* / user_encoder.*
+        eng = _forward_engine(args, args.num_hidden_layers, sd, add_prefix="student.")
+        logging.info(f"loaded teacher model: {ckpt_path}")
+        news_scoring = eng.encode_news(dev_news).cpu().numpy()
+        logging.info("news scoring num: {}".format(news_scoring.shape[0]))
+        with open(out_path, "wb") as f:
+            pickle.dump(news_scoring, f)
+        logging.info(f"teacher embedding saved at {out_path}")
+        del eng
+        torch.cuda.empty_cache()
 
 
 def test(args):
-    raise NotImplementedError("test (run.py:219-379) is SURVEY section 8-f N2; Engine.encode() is its forward path")
+    """run.py:219-379: encode all test news once, user vectors per impression batch, host metrics, scalar all-reduce."""
+    import dist
+    from dataloader import DataLoaderTest
+    from metrics import mrr_score, ndcg_score, roc_auc_score
+    size, rank, local = utils.init_hvd_cuda(args.enable_hvd, args.enable_gpu)
+    ckpt_path = utils.get_checkpoint(args.model_dir, args.load_ckpt_name) if args.load_ckpt_name else utils.latest_checkpoint(args.model_dir)
+    assert ckpt_path is not None, "No ckpt found"
+    sd = torch.load(ckpt_path, map_location="cpu")["model_state_dict"]
+    eng = _forward_engine(args, args.num_student_layers, sd)
+    logging.info(f"Model loaded from {ckpt_path}")
+    news_index, news_combined = _news_table(args, args.test_data_dir, "test")
+    news_scoring = eng.encode_news(torch.from_numpy(news_combined).cuda())
+    scoring_host = news_scoring.cpu().numpy()
+    logging.info("news scoring num: {}".format(scoring_host.shape[0]))
+    loader = DataLoaderTest(news_index=news_index, data_dir=args.test_data_dir, filename_pat=args.filename_pat, args=args,
+                            world_size=size, worker_rank=rank, cuda_device_idx=local, enable_prefetch=True,
+                            enable_shuffle=False, enable_gpu=True)
+    sums, n_local = np.zeros(4), 0
+    cnt_metric = 0
+    for cnt, (h, m, cands, labels) in enumerate(loader):
+        n_local += h.shape[0]
+        users = eng.user_vectors(news_scoring, h, m).cpu().numpy()
+        for u, c, y in zip(users, cands, labels):
+            if y.mean() == 0 or y.mean() == 1:
+                continue
+            score = scoring_host[c] @ u
+            sums += [roc_auc_score(y, score), mrr_score(y, score), ndcg_score(y, score, 5), ndcg_score(y, score, 10)]
+            cnt_metric += 1
+        if cnt % args.log_steps == 0 and cnt_metric:
+            logging.info("[{}] Ed: {}: {}".format(rank, n_local, "\t".join("{:0.2f}".format(x * 100) for x in sums / cnt_metric)))
+    loader.join()
+    logging.info("[{}] local_sample_num: {}".format(rank, n_local))
+    tot = torch.tensor([float(n_local)] + list(sums), dtype=torch.float64, device="cuda")
+    if size > 1:
+        torch.distributed.all_reduce(tot)                                               # hvd.allreduce(Sum), run.py:372-376
+    if rank == 0:
+        t = tot.cpu().numpy()
+        # the reference divides the metric sums by the SAMPLE count (run.py:377-379), impressions skipped above included
+        logging.info("[{}] Ed: {}: {}".format(rank, int(t[0]), "\t".join("{:0.2f}".format(x * 100) for x in t[1:] / t[0])))
+    return sums, n_local, cnt_metric
 
 
 if __name__ == "__main__":
