@@ -185,3 +185,21 @@ def test_eval_loader_index_level():
     h, m, c, y = dl._process([b"1\tU1\tt\tN1 N2 N999\tN3-1 N4-0 N777-0"])
     assert h.shape == (1, 50) and h[0, -3:].tolist() == [news_index["N1"], news_index["N2"], 0] and m[0].sum() == 3
     assert c[0].tolist() == [news_index["N3"], news_index["N4"], 0] and y[0].tolist() == [1, 0, 0]
+
+
+def test_split_file_writes_loader_format(tmp_path):
+    import split_file
+    import streaming
+    src = tmp_path / "behaviors.tsv"
+    src.write_text("1\tU1\tt1\tN1 N2\tN3-1 N4-0 N5-0 N6-0 N7-0 N8-1\n"
+                   "2\tU2\tt2\t\tN3-0 N4-0\n"                 # no positive: dropped
+                   "3\tU3\tt3\tN9\tN1-1 N2-0\n")              # 1 negative, 4 wanted: sampled from the repeated pool
+    paths, n = split_file.split(str(src), 2, npratio=4, seed=0)
+    assert n == 3 and [os.path.basename(p) for p in paths] == ["behaviors_np4_0.tsv", "behaviors_np4_1.tsv"]
+    lines = [l for p in paths for l in open(p).read().splitlines()]
+    assert len(lines) == 3
+    for l in lines:
+        f = l.split("\t")
+        assert len(f) == 6 and len(f[4].split()) == 1 and len(f[5].split()) == 4
+    assert sorted(l.split("\t")[4] for l in lines) == ["N1", "N3", "N8"]
+    assert sorted(streaming.get_stat(str(tmp_path), "behaviors_np4_*.tsv").values()) == [1, 2]
