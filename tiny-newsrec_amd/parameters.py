@@ -7,67 +7,38 @@ import logging
 import utils
 
 _B = utils.str2bool
-# (name, type, default[, extra kwargs])
-_FLAGS = [
-    ("mode", str, "train", dict(choices=["train", "test", "get_teacher_emb"])),
-    ("train_data_dir", str, "../MIND/MINDlarge_train"),
-    ("test_data_dir", str, "../MIND/MINDlarge_test"),
-    ("filename_pat", str, "behaviors_np4_*.tsv"),
-    ("model_dir", str, "./model"),
-    ("batch_size", int, 32),
-    ("npratio", int, 4),
-    ("enable_gpu", _B, True),
-    ("enable_hvd", _B, True),            # kept: True = data-parallel over RCCL (horovod is gone)
-    ("enable_shuffle", _B, True),
-    ("shuffle_buffer_size", int, 10000),
-    ("num_workers", int, 4),
-    ("filter_num", int, 3),
-    ("log_steps", int, 100),
-    ("epochs", int, 1),
-    ("lr", float, 0.0001),
-    ("num_words_title", int, 20),
-    ("num_words_abstract", int, 50),
-    ("num_words_body", int, 100),
-    ("user_log_length", int, 50),
-    ("word_embedding_dim", int, 300),
-    ("glove_embedding_path", str, "./glove.840B.300d.txt"),
-    ("freeze_embedding", _B, False),
-    ("news_dim", int, 64),
-    ("news_query_vector_dim", int, 200),
-    ("user_query_vector_dim", int, 200),
-    ("num_attention_heads", int, 20),
-    ("user_log_mask", _B, True),
-    ("drop_rate", float, 0.2),
-    ("save_steps", int, 1000),
-    ("max_steps_per_epoch", int, 1000000),
-    ("load_ckpt_name", str, None, dict(help="choose which ckpt to load and test")),
-    ("apply_bert", _B, False),
-    ("model_type", str, "bert"),
-    ("do_lower_case", _B, True),
-    ("model_name", str, "../bert-base-uncased/pytorch_model.bin"),
-    ("config_name", str, "../bert-base-uncased/config.json"),
-    ("tokenizer_name", str, "../bert-base-uncased/vocab.txt"),
-    ("num_hidden_layers", int, 8),
-    ("bert_trainable_layer", int, [], dict(nargs="+", choices=list(range(12)))),
-    ("model", str, None),
-    ("pooling", str, "att"),
-    ("start_epoch", int, 0),
-    ("use_pretrain_model", _B, False),
-    ("pretrain_model_path", str, None),
-    ("pretrain_lr", float, 0.00001),
-    ("num_teacher_layers", int, 12),
-    ("num_student_layers", int, 4),
-    ("temperature", float, 1.0),
-    ("coef", float, 1.0),
-    ("tensorboard", str, None),
-    ("teacher_ckpts", str, [], dict(nargs="+")),
-    ("teacher_emb_paths", str, [], dict(nargs="+")),
-    ("num_teachers", int, 4),
-    # --- additions (defaults keep the reference behaviour)
-    ("resident_tables", _B, True, dict(help="keep news_combined / teacher tables in HBM and ship indices only")),
-    ("dtype", str, "bf16", dict(choices=["bf16", "fp16"], help="16-bit activation type of the HIP kernels")),
-    ("synthetic", _B, False, dict(help="random-init weights + synthetic MIND-shaped data (no files needed)")),
-]
+
+# "name=default" specs grouped by type (Tiny-NewsRec/parameters.py:8-115, same names / defaults)
+_INT = """batch_size=32 npratio=4 shuffle_buffer_size=10000 num_workers=4 filter_num=3 log_steps=100 epochs=1
+num_words_title=20 num_words_abstract=50 num_words_body=100 user_log_length=50 word_embedding_dim=300 news_dim=64
+news_query_vector_dim=200 user_query_vector_dim=200 num_attention_heads=20 save_steps=1000 max_steps_per_epoch=1000000
+num_hidden_layers=8 start_epoch=0 num_teacher_layers=12 num_student_layers=4 num_teachers=4"""
+_FLOAT = "lr=0.0001 drop_rate=0.2 pretrain_lr=0.00001 temperature=1.0 coef=1.0"
+_BOOL = """enable_gpu=1 enable_hvd=1 enable_shuffle=1 freeze_embedding=0 user_log_mask=1 apply_bert=0 do_lower_case=1
+use_pretrain_model=0"""
+_STR = {"train_data_dir": "../MIND/MINDlarge_train", "test_data_dir": "../MIND/MINDlarge_test",
+        "filename_pat": "behaviors_np4_*.tsv", "model_dir": "./model", "glove_embedding_path": "./glove.840B.300d.txt",
+        "load_ckpt_name": None, "model_type": "bert", "model_name": "../bert-base-uncased/pytorch_model.bin",
+        "config_name": "../bert-base-uncased/config.json", "tokenizer_name": "../bert-base-uncased/vocab.txt",
+        "model": None, "pooling": "att", "pretrain_model_path": None, "tensorboard": None}
+
+
+def _flag_table():
+    t = [("mode", str, "train", dict(choices=["train", "test", "get_teacher_emb"]))]
+    t += [(kv.split("=")[0], int, int(kv.split("=")[1])) for kv in _INT.split()]
+    t += [(kv.split("=")[0], float, float(kv.split("=")[1])) for kv in _FLOAT.split()]
+    t += [(kv.split("=")[0], _B, kv.split("=")[1] == "1") for kv in _BOOL.split()]     # enable_hvd: True = data parallel over RCCL
+    t += [(k, str, v) for k, v in _STR.items()]
+    t += [("bert_trainable_layer", int, [], dict(nargs="+", choices=list(range(12)))),
+          ("teacher_ckpts", str, [], dict(nargs="+")), ("teacher_emb_paths", str, [], dict(nargs="+")),
+          # additions (defaults keep the reference behaviour)
+          ("resident_tables", _B, True, dict(help="keep news_combined / teacher tables in HBM and ship indices only")),
+          ("dtype", str, "bf16", dict(choices=["bf16", "fp16"], help="16-bit activation type of the HIP kernels")),
+          ("synthetic", _B, False, dict(help="random-init weights + synthetic MIND-shaped data (no files needed)"))]
+    return t
+
+
+_FLAGS = _flag_table()
 
 
 def build_parser():

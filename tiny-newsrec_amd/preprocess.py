@@ -1,8 +1,9 @@
-"""news.tsv -> news_index / padded token tables (Tiny-NewsRec/preprocess.py:15-66), TF-free.
+"""news.tsv -> news_index and the padded token tables (layout of Tiny-NewsRec/preprocess.py:15-66), TF-free.
 
-The tokenizer is the caller's (transformers BertTokenizer on the reference's vocab file by default): one-off
-host preprocessing, out of scope for kernels.  Output layout is the boundary:
-news_index = {doc_id: 1..n} in file order, row 0 = all-zero pad news, int32 (n+1, L) ids and masks."""
+Tokenisation itself is one-off host work and out of scope for kernels: any callable
+`tokenizer(text, max_length=, padding="max_length", truncation=True) -> {"input_ids", "attention_mask"}` works,
+by default transformers' BertTokenizer on the reference's vocab file.  What matters downstream is the layout:
+news ids are numbered 1..n in file order, row 0 of every table is the all-zero pad news, tables are int32."""
 import numpy as np
 
 
@@ -11,39 +12,35 @@ def make_tokenizer(args):
     return BertTokenizer(vocab_file=args.tokenizer_name, do_lower_case=True)
 
 
+def _number(table, key):
+    return table.setdefault(key, len(table) + 1)
+
+
 def read_news_bert(news_path, args, mode="train", tokenizer=None):
-    tok = tokenizer or make_tokenizer(args)
-    news, news_index, category_dict, subcategory_dict = {}, {}, {}, {}
-    L = args.num_words_title
-    with open(news_path, "r", encoding="utf-8") as f:
-        for line in f:
-            doc_id, category, subcategory, title = line.strip("\n").split("\t")[:4]
-            if doc_id not in news_index:
-                news_index[doc_id] = len(news_index) + 1
-            enc = tok(title.lower(), max_length=L, padding="max_length", truncation=True)
-            if doc_id not in news:
-                news[doc_id] = [enc, category, subcategory]
+    assert mode in ("train", "test"), "Wrong mode!"
+    encode = tokenizer or make_tokenizer(args)
+    width = args.num_words_title
+    news, news_index, categories, subcategories = {}, {}, {}, {}
+    with open(news_path, "r", encoding="utf-8") as fh:
+        for row in fh:
+            doc_id, cat, subcat, title = row.rstrip("\n").split("\t")[:4]
+            _number(news_index, doc_id)
+            tokens = encode(title.lower(), max_length=width, padding="max_length", truncation=True)
+            news.setdefault(doc_id, [tokens, cat, subcat])
             if mode == "train":
-                category_dict.setdefault(category, len(category_dict) + 1)
-                subcategory_dict.setdefault(subcategory, len(subcategory_dict) + 1)
-    if mode == "train":
-        return news, news_index, category_dict, subcategory_dict
-    if mode == "test":
-        return news, news_index
-    raise AssertionError("Wrong mode!")
+                _number(categories, cat)
+                _number(subcategories, subcat)
+    return (news, news_index, categories, subcategories) if mode == "train" else (news, news_index)
 
 
 def get_doc_input_bert(news, news_index, category_dict, subcategory_dict, args):
-    n = len(news) + 1
-    L = args.num_words_title
-    title = np.zeros((n, L), dtype="int32")
-    mask = np.zeros((n, L), dtype="int32")
-    cat = np.zeros(n, dtype="int32")
-    sub = np.zeros(n, dtype="int32")
-    for key, (enc, c, s) in news.items():
-        i = news_index[key]
-        title[i] = enc["input_ids"]
-        mask[i] = enc["attention_mask"]
-        cat[i] = category_dict.get(c, 0)
-        sub[i] = subcategory_dict.get(s, 0)
-    return title, mask, cat, sub
+    rows, width = len(news) + 1, args.num_words_title
+    ids = np.zeros((rows, width), dtype="int32")
+    attn = np.zeros((rows, width), dtype="int32")
+    cats = np.zeros(rows, dtype="int32")
+    subcats = np.zeros(rows, dtype="int32")
+    for doc_id, (tokens, cat, subcat) in news.items():
+        r = news_index[doc_id]
+        ids[r], attn[r] = tokens["input_ids"], tokens["attention_mask"]
+        cats[r], subcats[r] = category_dict.get(cat, 0), subcategory_dict.get(subcat, 0)
+    return ids, attn, cats, subcats

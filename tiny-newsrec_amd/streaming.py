@@ -10,46 +10,49 @@ import random
 import numpy as np
 
 
-def get_stat(dirname, filename_pat="*"):
-    """{path: line count} for matching files (streaming.py:10-22 shells out to `wc -l`)."""
+def _matching(dirname, pattern, recursive=False):
+    """Paths under dirname whose base name matches the glob `pattern` (None when the directory is missing)."""
     if not os.path.exists(dirname):
         logging.warning(f"{dirname} does not exist!")
         return None
-    stat = {}
-    for x in os.listdir(dirname):
-        if fnmatch.fnmatch(x, filename_pat):
-            path = os.path.join(dirname, x)
-            with open(path, "rb") as f:
-                stat[path] = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 20), b""))
-    return stat
+    hits = []
+    for entry in os.listdir(dirname):
+        full = os.path.join(dirname, entry)
+        if os.path.isdir(full):
+            if recursive:
+                hits += _matching(full, pattern) or []
+        elif fnmatch.fnmatch(entry, pattern):
+            hits.append(full)
+    return hits
+
+
+def _count_lines(path):
+    with open(path, "rb") as f:
+        return sum(block.count(b"\n") for block in iter(lambda: f.read(1 << 20), b""))
+
+
+def get_stat(dirname, filename_pat="*"):
+    """{path: number of lines} (streaming.py:10-22 shells out to `wc -l`; counted here directly)."""
+    paths = _matching(dirname, filename_pat)
+    return None if paths is None else {p: _count_lines(p) for p in paths}
 
 
 def get_files(dirname, filename_pat="*", recursive=False):
-    if not os.path.exists(dirname):
-        logging.warning(f"{dirname} does not exist!")
-        return None
-    out = []
-    for x in os.listdir(dirname):
-        path = os.path.join(dirname, x)
-        if os.path.isdir(path):
-            if recursive:
-                out.extend(get_files(path, filename_pat))
-        elif fnmatch.fnmatch(x, filename_pat):
-            out.append(path)
-    return out
+    return _matching(dirname, filename_pat, recursive)
 
 
 def get_worker_files(dirname, worker_rank, world_size, filename_pat="*", shuffle=False, seed=0):
-    """sorted matches -> optional random.seed(seed); random.shuffle -> files[rank::world]"""
-    all_files = get_files(dirname, filename_pat)
-    all_files.sort()
+    """The data-parallel sharding rule (streaming.py:40-58), bit-exact: sort the matches, optionally
+    random.seed(seed) + random.shuffle, then this worker takes every world_size-th file starting at its rank.
+    NB the seeding is a side effect the label draw of dataloader.py:136 inherits, exactly as in the reference."""
+    ordered = sorted(_matching(dirname, filename_pat))
     if shuffle:
-        random.seed(seed)          # NB: also seeds the label draw of dataloader.py:136, as in the reference
-        random.shuffle(all_files)
-    files = all_files[worker_rank::world_size]
-    logging.info(f"worker_rank:{worker_rank}, world_size:{world_size}, shuffle:{shuffle}, seed:{seed}, "
-                 f"directory:{dirname}, files:{files}")
-    return files
+        random.seed(seed)
+        random.shuffle(ordered)
+    mine = ordered[worker_rank::world_size]
+    logging.info("worker_rank:%s, world_size:%s, shuffle:%s, seed:%s, directory:%s, files:%s",
+                 worker_rank, world_size, shuffle, seed, dirname, mine)
+    return mine
 
 
 class StreamReader:
