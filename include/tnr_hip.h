@@ -92,7 +92,9 @@ int64_t tnr_gemm_tn_ws_elems(int64_t N, int64_t K, int splits);
 int tnr_ln_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* stats,
                int64_t M, int H, void* stream);
 /* bwd: dx = LN'(dy) ; partial sums go to part (nblk,3,H) fp32 then are reduced into dgamma, dbeta and
- * dxsum = column sums of dx (the bias gradient of the Linear in front of this LayerNorm); each may be null. */
+ * dxsum = column sums of dx (the bias gradient of the Linear in front of this LayerNorm); each may be null.
+ * With all three null and part given, only the partials (nblk = ceil(M/128) rows of [dgamma|dbeta|dxsum]) are
+ * written and the caller reduces them (tnr_reduce_multi). */
 int tnr_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream);
 int64_t tnr_ln_bwd_part_elems(int64_t M, int H);
@@ -181,6 +183,11 @@ int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* lo
  * in place per row chunk, so its contents are clobbered. */
 int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
                     void* stream);
+
+/* many fixed-order row reductions in ONE launch.  jobs: n_jobs x 6 int64 on the device {part ptr, rows, stride, n,
+ * out ptr, accumulate}; block b handles columns [64*block_chunk[b], +64) of job block_job[b] (host-built maps). */
+int tnr_reduce_multi(const int64_t* jobs, const int32_t* block_job, const int32_t* block_chunk, int n_blocks,
+                     void* stream);
 
 /* ---- optimiser ------------------------------------------------------------------------------- */
 

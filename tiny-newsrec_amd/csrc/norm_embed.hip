@@ -191,6 +191,35 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         out[i] = accumulate ? out[i] + t : t;
     }
 }
+// many reductions in one launch: job table on the device, one block per (job, 64-column chunk), fixed order
+// (4 row lanes, each a strided subsequence, combined as ((0+1)+(2+3))).  jobs: n_jobs x 6 int64
+// {part ptr, rows, stride, n, out ptr, accumulate}; block_job / block_chunk map a block to its work.
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const int64_t* __restrict__ jobs, const int32_t* __restrict__ block_job,
+                                                           const int32_t* __restrict__ block_chunk) {
+    __shared__ float red[4][64];
+    const int64_t* j = jobs + (int64_t)block_job[blockIdx.x] * 6;
+    const float* part = (const float*)j[0];
+    const int64_t rows = j[1], stride = j[2], n = j[3];
+    float* out = (float*)j[4];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)block_chunk[blockIdx.x] * 64 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int64_t r = rl;
+        for (; r + 4 < rows; r += 8) {               // two independent chains: more loads in flight
+            s0 += part[r * stride + i];
+            s1 += part[(r + 4) * stride + i];
+        }
+        if (r < rows) s0 += part[r * stride + i];
+    }
+    red[rl][c] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && i < n) {
+        float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        out[i] = j[5] ? out[i] + t : t;
+    }
+}
+
 // first level for tall inputs: chunk y sums its rows IN PLACE into its first row (each block only touches its own
 // 64 columns of its own chunk), so that the second level reads `chunks` rows instead of `rows`
 __global__ __launch_bounds__(256) void reduce_rows_chunk_kernel(float* __restrict__ part, int64_t rows, int64_t stride,
@@ -380,15 +409,27 @@ extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, 
                                void* stream);
 #endif
 
+#ifndef TNR_BUILD_F16
+extern "C" int tnr_reduce_multi(const int64_t* jobs, const int32_t* block_job, const int32_t* block_chunk, int n_blocks,
+                                void* stream) {
+    TNR_CHECK_ARG(jobs && block_job && block_chunk && n_blocks >= 1, "tnr_reduce_multi: bad argument");
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, jobs, block_job,
+                       block_chunk);
+    TNR_CHECK_LAUNCH("tnr_reduce_multi");
+    return TNR_OK;
+}
+#endif
+
 extern "C" int TNR_NAME(tnr_ln_bwd)(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                           float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream) {
+    // dgamma == dbeta == dxsum == NULL with part != NULL: partials only, the caller reduces them (tnr_reduce_multi)
     TNR_CHECK_ARG(dy && x && stats && gamma && dx && M >= 1, "tnr_ln_bwd: null pointer");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_ln_bwd: H must be 256/512/768/1024");
     TNR_CHECK_ARG(!(dgamma || dbeta || dxsum) || part, "tnr_ln_bwd: part workspace required for dgamma/dbeta/dxsum");
     int64_t nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
     dim3 grid((unsigned)nblk), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    float* p = (dgamma || dbeta || dxsum) ? part : nullptr;
+    float* p = part;
 #define LAUNCH(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, blk, 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, p, M)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH

@@ -120,6 +120,32 @@ def is_trainable(cfg, name):
     return True
 
 
+class _ReduceBatch:
+    """Fixed-order partial-sum reductions of one gradient bucket, done by ONE tnr_reduce_multi launch.
+    The job list is static (same buffers every step): recorded during the first backward, then replayed."""
+
+    def __init__(self, dev):
+        self.dev, self.jobs, self.table = dev, [], None
+
+    def add(self, part, rows, stride, n, out, accumulate=0):
+        if self.table is None:
+            self.jobs.append((part.data_ptr(), rows, stride, n, out.data_ptr(), accumulate))
+
+    def flush(self):
+        if not self.jobs:
+            return
+        if self.table is None:
+            bj, bc = [], []
+            for j, job in enumerate(self.jobs):
+                for c in range((job[3] + 63) // 64):
+                    bj.append(j)
+                    bc.append(c)
+            self.table = (torch.tensor(self.jobs, dtype=torch.int64, device=self.dev),
+                          torch.tensor(bj, dtype=torch.int32, device=self.dev),
+                          torch.tensor(bc, dtype=torch.int32, device=self.dev), len(bj))
+        T.call("tnr_reduce_multi", *self.table)
+
+
 LOSS_SCALE = 1024.0     # static scale of the 16-bit backward in fp16 mode (gradients of ~1e-6 would underflow)
 
 
@@ -340,6 +366,8 @@ class Engine:
         self.du = z(Mp, I)
         self.dqkv = z(Mp, 3 * H)
         self.ln_part = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
+        self.ln_part1 = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
+        self.red = {}                                                      # gradient bucket -> _ReduceBatch
         self.cs_part = f(max(T.query("tnr_colsum_part_elems", Mp, QPAD), T_ * T.query("tnr_colsum_part_elems", Rt, D)))
         self.gcs_part = f(T.query("tnr_gemm_colsum_rows", Mp), I)        # b1 gradient partials from the dgrad epilogue
         self.qkvb_part = f(N, 3 * H)                                       # q/k/v bias gradient partials from attention bwd
@@ -568,7 +596,8 @@ class Engine:
                g(ue + "attn.att_fc2.weight"), int(cfg.user_log_mask), dS[N:], self.e_u, self.alpha_u, self.den_u, dS,
                self.user_part, B, U, D, cfg.Qu)
         ps = self.user_part.shape[1]
-        T.call("tnr_reduce_rows", self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.weight", ps, (ps,), grad=True), 0)
+        rb = self.red.setdefault("heads", _ReduceBatch(self.dev))
+        rb.add(self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.weight", ps, (ps,), grad=True))
         # dense + pooling of the news encoder
         dvec = dS[:N]
         wd = g(PFX + "dense.weight")
@@ -578,9 +607,10 @@ class Engine:
         y = self.y_last
         self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
                self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
-        T.call("tnr_reduce_rows", self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], 0)
-        T.call("tnr_reduce_rows", self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], 0)
-        T.call("tnr_reduce_rows", self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), 0)
+        rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"])
+        rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"])
+        rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True))
+        rb.flush()
         self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M)
         if after_bucket:
             after_bucket(0)
@@ -593,27 +623,35 @@ class Engine:
             names, sh, a = layer_param_order(l), self.sh[l], self.act[l - self.lo]
             tr = l in cfg.trainable_layers
             x_in = self.x_in[l]
-            # bias gradients ride along: dx column sums from LayerNorm backward, the dgrad epilogue, attention backward
-            self._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, gr[names[14]] if tr else None,
-                   gr[names[15]] if tr else None, gr[names[13]] if tr else None, self.ln_part, M, H)
+            # bias gradients ride along: dx column sums from LayerNorm backward, the dgrad epilogue, attention backward;
+            # all partial sums of the layer are reduced by one launch at the end (fixed order)
+            rb = self.red.setdefault(l, _ReduceBatch(self.dev)) if tr else None
+            nblk = (M + 127) // 128
+            self._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None,
+                    self.ln_part if tr else None, M, H)
             if tr:
+                rb.add(self.ln_part, nblk, 3 * H, 2 * H, self._view(names[14], 2 * H, (2 * H,), grad=True))   # [dgamma | dbeta]
+                rb.add(self.ln_part[2 * H:], nblk, 3 * H, H, gr[names[13]])                                     # output.dense.bias
                 self._wgrad(self.dypre, a["g"], gr[names[12]], M)
             self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if tr else 0),
                        colsum=self.gcs_part if tr else None)
             if tr:
-                T.call("tnr_reduce_rows", self.gcs_part, self.gcs_part.shape[0], I, I, gr[names[11]], 0)
+                rb.add(self.gcs_part, self.gcs_part.shape[0], I, I, gr[names[11]])
                 self._wgrad(self.du, a["h1"], gr[names[10]], M)
             self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
-            self._c("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, gr[names[8]] if tr else None,
-                   gr[names[9]] if tr else None, gr[names[7]] if tr else None, self.ln_part, M, H)
+            self._c("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, None, None, None,
+                    self.ln_part1 if tr else None, M, H)
             if tr:
+                rb.add(self.ln_part1, nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True))
+                rb.add(self.ln_part1[2 * H:], nblk, 3 * H, H, gr[names[7]])                                   # attention.output.dense.bias
                 self._wgrad(self.dh1pre, a["ctx"], gr[names[6]], M)
             self._gemm(self.dh1pre, sh["oT"], self.dctx, M)
             self._c("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv,
-                   self.qkvb_part if tr else None, N, L, cfg.A)
+                    self.qkvb_part if tr else None, N, L, cfg.A)
             if tr:
-                T.call("tnr_reduce_rows", self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), 0)
+                rb.add(self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True))
                 self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M)
+                rb.flush()
             if l > self.lo:
                 nxt = self.dy2 if dy is self.dy else self.dy
                 self._gemm(self.dqkv, sh["qkvT"], nxt, M, res=self.dh1pre, flags=T.EPI_RES)
