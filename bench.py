@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--trainable", type=int, nargs="+", default=None)
     ap.add_argument("--teachers", type=int, default=4)
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit activation type (same MFMA rate)")
+    ap.add_argument("--force-dp", action="store_true", help="run the RCCL broadcast / bucketed all-reduce path even at world size 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -94,6 +95,10 @@ def main():
     import tnr_hip as T
     from tests.helpers import FULL, state_shapes
 
+    if a.force_dp and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
     world, rank, local = D.init()
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
     torch.cuda.set_device(local)
@@ -104,7 +109,7 @@ def main():
     eng = E.Engine(cfg, dev, max_batch=a.batch, dtype=a.dtype)
     seed = 1234
     eng.load_state_dict(hashinit.init_state_dict(seed, state_shapes(FULL, a.layers, cfg.D, a.teachers)))
-    D.broadcast_flat([eng.flat[True], eng.flat[False]])
+    D.broadcast_flat([eng.flat[True], eng.flat[False]], force=a.force_dp)
     eng.refresh_shadows(all_layers=True)
 
     B, K, W = a.batch, a.steps, a.warmup
@@ -112,12 +117,12 @@ def main():
     tables = torch.from_numpy(synth.teacher_tables(seed, max(a.teachers, 1), N_NEWS, cfg.D)).to(dev)
     hidx, mask, cidx, label = [torch.from_numpy(x).to(dev) for x in
                                synth.impressions(seed + 1 + rank, (K + W) * B, N_NEWS, cfg.U, cfg.C)]
-    gs = D.GradSync(eng.flat_g, eng.bucket_ranges(), world)
+    gs = D.GradSync(eng.flat_g, eng.bucket_ranges(), world, force=a.force_dp)
 
     def one_step(i):
         s = slice(i * B, (i + 1) * B)
         eng.forward_indexed(comb, hidx[s], mask[s], cidx[s], label[s], tables if a.teachers else None)
-        eng.backward(after_bucket=gs.launch if world > 1 else None)
+        eng.backward(after_bucket=gs.launch if (world > 1 or a.force_dp) else None)
         gs.wait()
         eng.step(lr=1e-4, grad_scale=gs.scale)
 

@@ -184,10 +184,10 @@ int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* lo
 int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
                     void* stream);
 
-/* many fixed-order row reductions in ONE launch.  jobs: n_jobs x 6 int64 on the device {part ptr, rows, stride, n,
- * out ptr, accumulate}; block b handles columns [64*block_chunk[b], +64) of job block_job[b] (host-built maps). */
-int tnr_reduce_multi(const int64_t* jobs, const int32_t* block_job, const int32_t* block_chunk, int n_blocks,
-                     void* stream);
+/* many fixed-order row reductions in ONE launch: desc = n_blocks x 6 int64 on the device, one per workgroup,
+ * {src ptr, rows, row stride in floats, ncols <= 64, dst ptr, accumulate}: dst[c] (+)= sum_r src[r*stride + c].
+ * Callers reduce tall partial matrices in two launches (row chunks in place, then the chunk rows). */
+int tnr_reduce_multi(const int64_t* desc, int n_blocks, void* stream);
 
 /* ---- optimiser ------------------------------------------------------------------------------- */
 

@@ -72,3 +72,16 @@ def test_run_py_train_entry_point(tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), "epoch-1.pt"), map_location="cpu")
     assert set(ck) == {"model_state_dict", "category_dict", "word_dict", "subcategory_dict"}
     assert "student.user_encoder.pad_doc" in ck["model_state_dict"]
+
+
+def test_bench_dp_path_under_torchrun_single_rank():
+    """The driver launches bench.py with torch.distributed.run for N > 1; here N = 1 but with --force-dp, so the RCCL
+    process group, the flat broadcast and the overlapped bucketed all-reduce + scaled AMSGrad all execute."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--force-dp"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and np.isfinite(d["config"]["final_loss"])

@@ -191,32 +191,32 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         out[i] = accumulate ? out[i] + t : t;
     }
 }
-// many reductions in one launch: job table on the device, one block per (job, 64-column chunk), fixed order
-// (4 row lanes, each a strided subsequence, combined as ((0+1)+(2+3))).  jobs: n_jobs x 6 int64
-// {part ptr, rows, stride, n, out ptr, accumulate}; block_job / block_chunk map a block to its work.
-__global__ __launch_bounds__(256) void reduce_multi_kernel(const int64_t* __restrict__ jobs, const int32_t* __restrict__ block_job,
-                                                           const int32_t* __restrict__ block_chunk) {
+// many reductions in one launch: one descriptor per BLOCK on the device, 6 int64
+// {src ptr, rows, row stride (floats), ncols <= 64, dst ptr, accumulate}: dst[c] (+)= sum_r src[r*stride + c].
+// Fixed order (4 row lanes, each a strided subsequence, combined as ((0+1)+(2+3))).  The host builds two tables
+// per batch: level 1 sums row chunks IN PLACE (dst = first row of the chunk), level 2 sums the chunk rows.
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const int64_t* __restrict__ desc) {
     __shared__ float red[4][64];
-    const int64_t* j = jobs + (int64_t)block_job[blockIdx.x] * 6;
-    const float* part = (const float*)j[0];
-    const int64_t rows = j[1], stride = j[2], n = j[3];
-    float* out = (float*)j[4];
+    const int64_t* d = desc + (int64_t)blockIdx.x * 6;
+    const float* src = (const float*)d[0];
+    const int64_t rows = d[1], stride = d[2];
+    const int ncols = (int)d[3];
+    float* dst = (float*)d[4];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int64_t i = (int64_t)block_chunk[blockIdx.x] * 64 + c;
     float s0 = 0.f, s1 = 0.f;
-    if (i < n) {
+    if (c < ncols) {
         int64_t r = rl;
         for (; r + 4 < rows; r += 8) {               // two independent chains: more loads in flight
-            s0 += part[r * stride + i];
-            s1 += part[(r + 4) * stride + i];
+            s0 += src[r * stride + c];
+            s1 += src[(r + 4) * stride + c];
         }
-        if (r < rows) s0 += part[r * stride + i];
+        if (r < rows) s0 += src[r * stride + c];
     }
     red[rl][c] = s0 + s1;
     __syncthreads();
-    if (rl == 0 && i < n) {
+    if (rl == 0 && c < ncols) {
         float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-        out[i] = j[5] ? out[i] + t : t;
+        dst[c] = d[5] ? dst[c] + t : t;
     }
 }
 
@@ -410,11 +410,9 @@ extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, 
 #endif
 
 #ifndef TNR_BUILD_F16
-extern "C" int tnr_reduce_multi(const int64_t* jobs, const int32_t* block_job, const int32_t* block_chunk, int n_blocks,
-                                void* stream) {
-    TNR_CHECK_ARG(jobs && block_job && block_chunk && n_blocks >= 1, "tnr_reduce_multi: bad argument");
-    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, jobs, block_job,
-                       block_chunk);
+extern "C" int tnr_reduce_multi(const int64_t* desc, int n_blocks, void* stream) {
+    TNR_CHECK_ARG(desc && n_blocks >= 1, "tnr_reduce_multi: bad argument");
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, desc);
     TNR_CHECK_LAUNCH("tnr_reduce_multi");
     return TNR_OK;
 }

@@ -25,12 +25,13 @@ def init(backend=None):
 class GradSync:
     """Bucketed all-reduce of a flat gradient buffer. ranges: [(start, end)] in completion order."""
 
-    def __init__(self, flat_g, ranges, world):
+    def __init__(self, flat_g, ranges, world, force=False):
         self.flat_g, self.ranges, self.world = flat_g, list(ranges), world
+        self.force = force and dist.is_initialized()      # exercise the collective path even with one rank
         self.pending = []
 
     def launch(self, bucket):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         s, e = self.ranges[bucket]
         self.pending.append(dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True))
@@ -45,9 +46,9 @@ class GradSync:
         return 1.0 / self.world
 
 
-def broadcast_flat(tensors, src=0):
+def broadcast_flat(tensors, src=0, force=False):
     """hvd.broadcast_parameters (run.py:142): every flat buffer from rank 0."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force):
         for t in tensors:
             dist.broadcast(t, src=src)
 

@@ -135,15 +135,26 @@ class _ReduceBatch:
         if not self.jobs:
             return
         if self.table is None:
-            bj, bc = [], []
-            for j, job in enumerate(self.jobs):
-                for c in range((job[3] + 63) // 64):
-                    bj.append(j)
-                    bc.append(c)
-            self.table = (torch.tensor(self.jobs, dtype=torch.int64, device=self.dev),
-                          torch.tensor(bj, dtype=torch.int32, device=self.dev),
-                          torch.tensor(bc, dtype=torch.int32, device=self.dev), len(bj))
-        T.call("tnr_reduce_multi", *self.table)
+            l1, l2 = [], []
+            for part, rows, stride, n, out, acc in self.jobs:
+                chunks = max(1, min(rows // 32, 16))                 # row chunks summed in place first (tall partials)
+                per = (rows + chunks - 1) // chunks
+                chunks = (rows + per - 1) // per
+                for c0 in range(0, n, 64):
+                    nc = min(64, n - c0)
+                    if chunks > 1:
+                        for ch in range(chunks):
+                            r0 = ch * per
+                            src = part + 4 * (r0 * stride + c0)
+                            l1.append((src, min(per, rows - r0), stride, nc, src, 0))
+                        l2.append((part + 4 * c0, chunks, per * stride, nc, out + 4 * c0, acc))
+                    else:
+                        l2.append((part + 4 * c0, rows, stride, nc, out + 4 * c0, acc))
+            mk = lambda rows_: (torch.tensor(rows_, dtype=torch.int64, device=self.dev), len(rows_)) if rows_ else None
+            self.table = (mk(l1), mk(l2))
+        for t in self.table:
+            if t is not None:
+                T.call("tnr_reduce_multi", t[0], t[1])
 
 
 LOSS_SCALE = 1024.0     # static scale of the 16-bit backward in fp16 mode (gradients of ~1e-6 would underflow)

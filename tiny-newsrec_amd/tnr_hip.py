@@ -44,7 +44,7 @@ _SIG = {
     "tnr_kd_score_loss": [_P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _P],
     "tnr_kd_embed_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "tnr_reduce_rows": [_P, _L, _L, _L, _P, _I, _P],
-    "tnr_reduce_multi": [_P, _P, _P, _I, _P],
+    "tnr_reduce_multi": [_P, _I, _P],
     "tnr_amsgrad_step": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "tnr_refresh_shadows": [_P, _I, _L, _P, _P],
     "tnr_cast_f32_to_bf16": [_P, _P, _L, _P],
