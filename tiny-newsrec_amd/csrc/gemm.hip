@@ -15,6 +15,9 @@
 
 namespace {
 
+// rasterisation group height (row tiles per group); TNR_GEMM_GM overrides for experiments
+static int g_group_m = 8;
+
 struct NTArgs {
     const bf16* A; int64_t lda;
     const bf16* B; int64_t ldb;
@@ -25,6 +28,7 @@ struct NTArgs {
     bf16* aux; int64_t ldaux;
     int flags;
     float* colsum_part;        // TNR_EPI_COLSUM: (rows_of_partials, N) fp32, one row per 64-row strip of C
+    int gm;                    // rasterisation group height
 };
 
 constexpr int TILE_BYTES = 128 * 128;   // one operand tile: 128 rows x 64 bf16
@@ -694,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
     const int nbm = (g.M + BM - 1) / BM;
     const int wg = xcd_remap(blockIdx.x, nbm * nbn);
     int bm, bn;
-    tile_coords(wg, nbm, nbn, 8, bm, bn);
+    tile_coords(wg, nbm, nbn, g.gm, bm, bn);
 
     const bf16* src[8];
     int dst[8];
@@ -873,6 +877,218 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_persistent_kernel(NTArg
     }
 }
 
+// ================================================================================================
+// v5: persistent 256x256 kernel with the row-contiguous epilogue staged in the IDLE HALF of the stage ring.
+// One workgroup per CU walks its XCD's run of tiles.  During the last K step of a tile the first K stage of
+// the NEXT tile is issued into the free stage buffer; the epilogue then stages the fp32 tile through the buffer
+// that was just consumed (4 passes of 64 rows, 64 KB, 16-byte chunks XOR-swizzled by row) while that load is in
+// flight, so neither the cold start of a tile nor (part of) its epilogue leaves the L2->LDS pipe idle.
+__global__ __launch_bounds__(512, 2) void gemm_nt256x256_v5_kernel(NTArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: per-piece constants stay in SGPRs
+    const int wm = w >> 2, wn = w & 3;
+    const int nbn = g.N >> 8;
+    const int nbm = (g.M + 255) >> 8;
+    const int ntile = nbm * nbn;
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per = (G - xcd + 7) >> 3;
+    const int q8 = ntile >> 3, r8 = ntile & 7;
+    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
+    int tile = c0 + slot;
+    if (tile >= c1) return;
+
+    const int flags = g.flags;
+    f32x2* lut = (f32x2*)(smem + RING3);
+    if (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (flags & TNR_EPI_MULDGELU) != 0);
+
+    const int nk = g.K >> 6;
+    const bf16* src[8];
+    const int lrow = lane >> 3;                       // row of this lane inside an 8-row piece
+    const int lchunk = ((lane & 7) ^ lrow) * 8;       // swizzled 16-byte chunk (piece rows start at multiples of 8)
+    auto set_src = [&](int t) {
+        int bm, bn;
+        tile_coords(t, nbm, nbn, g.gm, bm, bn);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = w * 8 + q, sub = p >> 4, row = (p & 15) * 8 + lrow;
+            if (sub < 2) {
+                int gm = bm * 256 + sub * 128 + row;
+                gm = gm < g.M ? gm : g.M - 1;
+                src[q] = g.A + (int64_t)gm * g.lda + lchunk;
+            } else {
+                src[q] = g.B + (int64_t)(bn * 256 + (sub - 2) * 128 + row) * g.ldb + lchunk;
+            }
+        }
+    };
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE3;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = w * 8 + q;
+            glds16(src[q] + kt * 64, base + (p >> 4) * TILE_BYTES + (p & 15) * 1024);
+        }
+    };
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    // epilogue thread mapping: 8 consecutive columns (two 16-byte chunks), row group 0..15
+    const int c8 = (tid & 31) * 8, rg = tid >> 5;
+    const int ck0 = (tid & 31) * 2;
+
+    set_src(tile);
+    stage(0, 0);
+    int cur = 0;
+    while (true) {
+        const int next = tile + per < c1 ? tile + per : -1;
+        int bm, bn;
+        tile_coords(tile, nbm, nbn, g.gm, bm, bn);
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            TNR_WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) {
+                stage(cur ^ 1, kt + 1);
+            } else if (next >= 0) {
+                set_src(next);
+                stage(cur ^ 1, 0);
+            }
+            const char* sa = smem + cur * STAGE3 + wm * TILE_BYTES;
+            const char* sb = smem + cur * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 af[8], bfr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            cur ^= 1;
+        }
+        // ---- epilogue: staging buffer = the stage consumed last (cur ^ 1 after the toggle); the other one is receiving
+        char* stg = smem + (cur ^ 1) * STAGE3;
+        const int n = bn * 256 + c8;
+        f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (flags & TNR_EPI_BIAS) {
+            b0 = *(const f32x4*)(g.bias + n);
+            b1 = *(const f32x4*)(g.bias + n + 4);
+        }
+        float cs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            __builtin_amdgcn_s_barrier();              // staging rows of the previous pass / the K loop are consumed
+            if (wm == (pass >> 1)) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int row = ii * 16 + (lane & 15);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ck = wn * 16 + j * 4 + (lane >> 4);
+                        *(f32x4*)(stg + row * 1024 + ((ck ^ (row & 15)) << 4)) = acc[(pass & 1) * 4 + ii][j];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int m0 = bm * 256 + pass * 64;
+            bf16x8 rr[4], uu[4];
+            if (flags & TNR_EPI_RES) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    int m = m0 + rg + 16 * it;
+                    m = m < g.M ? m : g.M - 1;
+                    rr[it] = *(const bf16x8*)(g.res + (int64_t)m * g.ldres + n);
+                }
+            }
+            if (flags & TNR_EPI_MULDGELU) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    int m = m0 + rg + 16 * it;
+                    m = m < g.M ? m : g.M - 1;
+                    uu[it] = *(const bf16x8*)(g.aux + (int64_t)m * g.ldaux + n);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = rg + 16 * it;
+                const int m = m0 + row;
+                if (m >= g.M) continue;
+                f32x4 v0 = *(const f32x4*)(stg + row * 1024 + ((ck0 ^ (row & 15)) << 4)) + b0;
+                f32x4 v1 = *(const f32x4*)(stg + row * 1024 + (((ck0 + 1) ^ (row & 15)) << 4)) + b1;
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (flags & TNR_EPI_AUXOUT) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                    *(bf16x8*)(g.aux + (int64_t)m * g.ldaux + n) = o;
+                }
+                if (flags & TNR_EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = lut_eval<false>(lut, v[e]);
+                }
+                if (flags & TNR_EPI_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+                }
+                if (flags & TNR_EPI_MULDGELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= lut_eval<true>(lut, (float)uu[it][e]);
+                }
+                if (flags & TNR_EPI_RES) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rr[it][e];
+                }
+                if (flags & TNR_EPI_OUTF32) {
+                    float* c = (float*)g.C + (int64_t)m * g.ldc + n;
+                    *(f32x4*)c = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        o[e] = (bf16)v[e];
+                        cs[e] += (float)o[e];
+                    }
+                    *(bf16x8*)((bf16*)g.C + (int64_t)m * g.ldc + n) = o;
+                }
+            }
+        }
+        if (flags & TNR_EPI_COLSUM) {
+            __builtin_amdgcn_s_barrier();
+            float* red = (float*)stg;                              // [16][256]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[rg * 256 + c8 + e] = cs[e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < 256) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
+                float* pr = g.colsum_part + (int64_t)(bm * 4) * g.N + bn * 256 + tid;
+                pr[0] = t;
+                pr[g.N] = 0.f;
+                pr[2 * (int64_t)g.N] = 0.f;
+                pr[3 * (int64_t)g.N] = 0.f;
+            }
+        }
+        if (next < 0) break;
+        tile = next;
+    }
+}
+
 // wgrad v3: output tile 256 (n) x 256 (k); stage = [dY cols 0-127 | dY cols 128-255 | X cols 0-127 | X cols 128-255]
 template <int PROBE>
 __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
@@ -1017,9 +1233,11 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     TNR_CHECK_ARG(!(flags & TNR_EPI_COLSUM) || (colsum_part && !(flags & TNR_EPI_OUTF32) && M > 128),
                   "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part};
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, g_group_m};
+    static const char* gm_s = getenv("TNR_GEMM_GM");
+    if (gm_s) g.gm = atoi(gm_s) > 0 ? atoi(gm_s) : 8;
     static const char* ver_s = getenv("TNR_GEMM_VER");
-    static const int ver = ver_s ? atoi(ver_s) : 3;
+    static const int ver = ver_s ? atoi(ver_s) : 3;   // 5 = persistent variant (A/B: within noise of 3)
     static const char* probe_s = getenv("TNR_GEMM_PROBE");
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -1038,6 +1256,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_v5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3 + LUT_N * 8);
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1048,6 +1267,19 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         int nwg = (int)(((M + 255) / 256) * (N / 128));
         if (probe) hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), RING2, st, g);
         else hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), RING2, st, g);
+    } else if (ver == 5 && !probe) {
+        // persistent kernel unless the 224-row tiling of the non-persistent one is the better deal for this shape
+        static const char* bm_s = getenv("TNR_GEMM_BM");
+        const int64_t t256 = ((M + 255) / 256) * (N / 256), t224 = ((M + 223) / 224) * (N / 256);
+        const int64_t c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
+        bool use224 = c224 * 108 < c256 * 100 && !(flags & TNR_EPI_COLSUM);
+        if (bm_s) use224 = atoi(bm_s) == 224 && !(flags & TNR_EPI_COLSUM);
+        if (use224) {
+            hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 7>), dim3((int)t224), dim3(512), LDS3_BYTES, st, g);
+        } else {
+            int nwg = (int)(t256 < n_cu ? t256 : n_cu);
+            hipLaunchKernelGGL(gemm_nt256x256_v5_kernel, dim3(nwg), dim3(512), RING3 + LUT_N * 8, st, g);
+        }
     } else if (ver == 3 || probe) {
         // tile height: 256 or 224 rows, whichever needs less (rounds of workgroups) x (rows per tile)
         static const char* bm_s = getenv("TNR_GEMM_BM");
