@@ -22,8 +22,11 @@ for f in glob.glob(raw + "/pmc*/**/*counter_collection.csv", recursive=True):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dom = "gemm_nt256x256_kernel"
 c = {k: sum(v) / len(v) for k, v in agg[dom].items()}
-dom_row = [r for r in rows if short(r["Name"]) == dom][0]
-res = {"kernel": dom, "avg_launch_us_trace": float(dom_row["AverageNs"]) / 1e3, "launches_in_trace": int(dom_row["Calls"]),
+dom_rows = [r for r in rows if short(r["Name"]) == dom]      # the <MI=8> and <MI=7> instantiations of the one kernel
+dom_calls = sum(int(r["Calls"]) for r in dom_rows)
+dom_ns = sum(float(r["TotalDurationNs"]) for r in dom_rows)
+res = {"kernel": dom + " (all template instantiations; = every tnr_gemm_nt launch bench.py times)",
+       "avg_launch_us_trace": dom_ns / dom_calls / 1e3, "launches_in_trace": dom_calls,
        "counters_mean_per_launch": c,
        # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads exactly 1/2 of wide
        # coalesced reads (16 B/lane global_load and LDS-DMA alike) -> doubled; WRITE_SIZE is exact for 16-B stores
