@@ -48,12 +48,13 @@ const char* tnr_last_error(void);
 /* ---- encoder --------------------------------------------------------------------------------- */
 
 /* relative_position_bucket + one_hot + Linear(32->A) hoisted to one (A,32,32) fp32 table
- * (tnlrv3/modeling.py:345-373, 458-463).  weight (A,32) fp32.  Entries with i>=L or j>=L are 0. */
+ * (tnlrv3/modeling.py:345-373, 458-463).  weight (A,32) fp32.  Entries with i>=L or j>=L are 0.
+ * In general the table is (A, Lr, Lr) with Lr = roundup(L, 32), L <= 512. */
 int tnr_relpos_table(const float* weight, int A, int L, float* table, void* stream);
 
 /* BertEmbeddings.forward (tnlrv3/modeling.py:153-178) + extended mask (:446-454), reading the padded
  * token batch directly: tok = (N, 2L) int64 rows [ids | mask] (model_bert.py:124-127).
- * out (N*L, H) bf16 ; mask_add (N,32) fp32 = (1-mask)*-10000, and -inf-like (-1e30) for j>=L. */
+ * out (N*L, H) bf16 ; mask_add (N,Lr) fp32 = (1-mask)*-10000, and -inf-like (-1e30) for j>=L ; Lr = roundup(L,32). */
 int tnr_embed_ln_fwd(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
                      const float* type0, const float* gamma, const float* beta, float eps,
                      void* out, float* mask_add, void* stream);
@@ -108,6 +109,15 @@ int tnr_attn_l32_fwd(const void* qkv, const float* mask_add, const float* rel, v
  * per-sequence column sums of dqkv (rows sum to the q/k/v bias gradient). */
 int tnr_attn_l32_bwd(const void* qkv, const float* mask_add, const float* rel, const void* dctx,
                      void* dqkv, float* bias_part, int64_t n_seq, int L, int A, void* stream);
+
+/* The same attention for longer sequences (L <= 512: stage-1 title/body matching, Post-train_KD.ipynb cell 4-14):
+ * flash-style 32-key tiles with an online softmax.  mask_add (N, Lr), rel (A, Lr, Lr) from tnr_embed_ln_fwd /
+ * tnr_relpos_table with Lr = roundup(L, 32); lse (N, A, Lr) fp32 out (kept for backward). */
+int tnr_attn_long_fwd(const void* qkv, const float* mask_add, const float* rel, void* ctx, float* lse,
+                      int64_t n_seq, int L, int A, void* stream);
+/* backward in two deterministic passes (dQ per query tile, dK/dV per key tile); delta (N, A, Lr) fp32 workspace */
+int tnr_attn_long_bwd(const void* qkv, const float* mask_add, const float* rel, const void* ctx, const void* dctx,
+                      const float* lse, float* delta, void* dqkv, int64_t n_seq, int L, int A, void* stream);
 
 /* column sums (bias gradients): out[n] (+)= sum_m X[m,n] ; X bf16 or fp32 (dtype) ; part (nblk,N) fp32 */
 int tnr_colsum(const void* X, int64_t ldx, int dtype, int64_t M, int64_t N, float* out, float* part,
@@ -230,6 +240,10 @@ int tnr_ln_fwd_f16(const void* x, const float* gamma, const float* beta, float e
                int64_t M, int H, void* stream);
 int tnr_ln_bwd_f16(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream);
+int tnr_attn_long_fwd_f16(const void* qkv, const float* mask_add, const float* rel, void* ctx, float* lse,
+                          int64_t n_seq, int L, int A, void* stream);
+int tnr_attn_long_bwd_f16(const void* qkv, const float* mask_add, const float* rel, const void* ctx, const void* dctx,
+                          const float* lse, float* delta, void* dqkv, int64_t n_seq, int L, int A, void* stream);
 int tnr_attn_l32_fwd_f16(const void* qkv, const float* mask_add, const float* rel, void* ctx,
                      int64_t n_seq, int L, int A, void* stream);
 int tnr_attn_l32_bwd_f16(const void* qkv, const float* mask_add, const float* rel, const void* dctx,

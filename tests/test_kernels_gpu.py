@@ -540,3 +540,47 @@ def test_f16_variants_gemm_attention_ln():
     T.call("tnr_ln_fwd_f16", dev(x, torch.float16), dev(g), dev(b), 1e-12, y, st, 77, 768)
     torch.cuda.synchronize()
     np.testing.assert_allclose(y.float().cpu().numpy(), O.layer_norm_fwd(x, g, b, 1e-12)[0], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("N,L,A", [(2, 24, 3), (2, 33, 2), (1, 128, 12), (2, 200, 2), (1, 512, 2)])
+def test_attention_long_fwd_bwd(N, L, A):
+    """flash-style tiles + online softmax (stage-1 bodies, L up to 512) against the dense oracle math"""
+    d = 64
+    Lr = (L + 31) // 32 * 32
+    rs = np.random.RandomState(L)
+    qkv = bf(rnd((N * L, 3 * A * d), 1, 1.0))
+    mask = (rs.rand(N, L) > 0.3).astype(np.float32)
+    mask[0, :] = 1
+    if N > 1:
+        mask[1, L // 2:] = 0
+    w = rnd((A, 32), 2, 0.5)
+    rel = O.relpos_bias_table(w, L)
+    madd = np.full((N, Lr), -1e30, np.float32)
+    madd[:, :L] = (1.0 - mask) * -10000.0
+    relt = torch.zeros((A, Lr, Lr), device=DEV)
+    T.call("tnr_relpos_table", dev(w), A, L, relt)
+    torch.cuda.synchronize()
+    assert np.array_equal(relt.cpu().numpy()[:, :L, :L], rel)
+    ctx = torch.zeros((N * L, A * d), device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros((N, A, Lr), device=DEV)
+    qd, md = dev(qkv, torch.bfloat16), dev(madd)
+    T.call("tnr_attn_long_fwd", qd, md, relt, ctx, lse, N, L, A)
+    torch.cuda.synchronize()
+    q, k, v, p, want = _attn_ref(qkv, mask, rel, N, L, A)
+    np.testing.assert_allclose(ctx.float().cpu().numpy(), want, rtol=2e-2, atol=2e-2)
+    s = q @ k.transpose(0, 1, 3, 2) / 8.0 + ((1.0 - mask) * -10000.0)[:, None, None, :] + rel[None]
+    lse_ref = np.log(np.exp(s - s.max(-1, keepdims=True)).sum(-1)) + s.max(-1)
+    np.testing.assert_allclose(lse.cpu().numpy()[:, :, :L], lse_ref, rtol=1e-3, atol=2e-2)
+    dctx = bf(rnd((N * L, A * d), 3))
+    dqkv = torch.zeros((N * L, 3 * A * d), device=DEV, dtype=torch.bfloat16)
+    delta = torch.zeros((N, A, Lr), device=DEV)
+    T.call("tnr_attn_long_bwd", qd, md, relt, ctx, dev(dctx, torch.bfloat16), lse, delta, dqkv, N, L, A)
+    torch.cuda.synchronize()
+    dch = dctx.reshape(N, L, A, d).transpose(0, 2, 1, 3)
+    dp = dch @ v.transpose(0, 1, 3, 2)
+    dv = p.transpose(0, 1, 3, 2) @ dch
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True))
+    back = lambda t: t.transpose(0, 2, 1, 3).reshape(N * L, A * d)
+    want_d = np.concatenate([back(ds @ k / 8.0), back(ds.transpose(0, 1, 3, 2) @ q / 8.0), back(dv)], 1)
+    got = dqkv.float().cpu().numpy()
+    np.testing.assert_allclose(got, want_d, rtol=3e-2, atol=3e-2 * np.abs(want_d).max())

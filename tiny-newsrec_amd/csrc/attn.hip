@@ -306,6 +306,296 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     }
 }
 
+// ================================================================================================
+// Long sequences (L <= 512: stage-1 bodies, Post-train_KD.ipynb cell 4): flash-style tiling over 32-key tiles with
+// an online softmax.  Same 32x32 MFMA tile machinery as above; one wave per (sequence, head, 32-query tile).
+// The output is accumulated TRANSPOSED (O^T = V^T . P^T: rows = head dim in registers, columns = queries on
+// lanes) so the per-query rescale factor exp(m_old - m_new) is a per-lane scalar.
+// mask_add: (N, Lr) fp32, rel: (A, Lr, Lr) fp32, Lr = roundup(L, 32); lse: (N, A, Lr) fp32 = max + log(sum).
+__device__ __forceinline__ bf16x8 ld_frag(const bf16* base, int64_t ld, int row, int h, int s) {
+    return *(const bf16x8*)(base + (int64_t)row * ld + 16 * s + 8 * h);
+}
+
+__global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
+                                                            const float* __restrict__ rel, bf16* __restrict__ ctx,
+                                                            float* __restrict__ lse, int64_t n_items, int L, int Lr, int A) {
+    __shared__ __attribute__((aligned(16))) char lds[4][4096];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t item = (int64_t)blockIdx.x * 4 + w;
+    const bool valid = item < n_items;
+    if (!valid) item = n_items - 1;
+    const int nqt = Lr >> 5;
+    const int qt = (int)(item % nqt);
+    const int64_t na = item / nqt;
+    const int64_t n = na / A;
+    const int a = (int)(na - n * A);
+    const int HD = A * 64;
+    const int64_t ldq = 3 * HD;
+    const int row = lane & 31, h = lane >> 5;
+    char* my = lds[w];
+    const int qi = qt * 32 + row;                          // this lane's query
+    const int qic = qi < L ? qi : L - 1;
+    const bf16* qbase = qkv + (n * L) * ldq + a * 64;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = ld_frag(qbase, ldq, qic, h, s);
+    f32x16 o[2] = {zero16(), zero16()};
+    float m_run = NEG_BIG, l_run = 0.f;
+    const float* relq = rel + ((int64_t)a * Lr + (qi < Lr ? qi : Lr - 1)) * Lr;
+    const float* mp = mask_add + n * Lr;
+    for (int kt = 0; kt < nqt; ++kt) {
+        const int kj = kt * 32 + row;
+        const int kjc = kj < L ? kj : L - 1;
+        bf16x8 kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = ld_frag(qbase + HD, ldq, kjc, h, s);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                      // V tile -> LDS (row-major [32 keys][64])
+            int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
+            int rc = kt * 32 + r;
+            rc = rc < L ? rc : L - 1;
+            *(bf16x8*)(my + r * 128 + c * 16) = *(const bf16x8*)(qbase + 2 * HD + (int64_t)rc * ldq + c * 8);
+        }
+        f32x16 st = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) st = TNR_MFMA_32x32x16(kf[s], qf[s], st, 0, 0, 0);
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 mk = *(const f32x4*)(mp + kt * 32 + 8 * g + 4 * h);
+            f32x4 rl = *(const f32x4*)(relq + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = st[4 * g + e] * 0.125f + mk[e] + rl[e];
+                st[4 * g + e] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = __expf(st[r] - m_new);
+            sum += st[r];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+        bf16x8 pf[2];
+        acc_to_frags(st, pf);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) o[ct] = TNR_MFMA_32x32x16(tr_frag(my, s, ct, lane), pf[s], o[ct], 0, 0, 0);
+        }
+    }
+    const float inv = 1.0f / l_run;
+    if (valid && h == 0 && qi < Lr) lse[(n * A + a) * Lr + qi] = m_run + __logf(l_run);
+    // O^T (rows = head dim, cols = queries) -> LDS tile [query][head dim] -> coalesced rows
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int dd = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            *(bf16*)(my + row * 128 + dd * 2) = (bf16)(o[ct][r] * inv);
+        }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
+        int q = qt * 32 + r;
+        if (valid && q < L) *(bf16x8*)(ctx + (n * L + q) * HD + a * 64 + c * 8) = *(const bf16x8*)(my + r * 128 + c * 16);
+    }
+}
+
+// backward pass 1: dQ per (sequence, head, query tile); also writes delta_i = sum_d dO[i][d] O[i][d]
+__global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
+                                                               const float* __restrict__ rel, const bf16* __restrict__ ctx,
+                                                               const bf16* __restrict__ dctx, const float* __restrict__ lse,
+                                                               float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                               int64_t n_items, int L, int Lr, int A) {
+    __shared__ __attribute__((aligned(16))) char lds[4][4096];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t item = (int64_t)blockIdx.x * 4 + w;
+    const bool valid = item < n_items;
+    if (!valid) item = n_items - 1;
+    const int nqt = Lr >> 5;
+    const int qt = (int)(item % nqt);
+    const int64_t na = item / nqt;
+    const int64_t n = na / A;
+    const int a = (int)(na - n * A);
+    const int HD = A * 64;
+    const int64_t ldq = 3 * HD;
+    const int row = lane & 31, h = lane >> 5;
+    char* my = lds[w];
+    const int qi = qt * 32 + row;
+    const int qic = qi < L ? qi : L - 1;
+    const bf16* qbase = qkv + (n * L) * ldq + a * 64;
+    const bf16* obase = ctx + (n * L) * HD + a * 64;
+    const bf16* dobase = dctx + (n * L) * HD + a * 64;
+    bf16x8 qf[4], df[4];
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = ld_frag(qbase, ldq, qic, h, s);
+        df[s] = ld_frag(dobase, HD, qic, h, s);
+        bf16x8 of = ld_frag(obase, HD, qic, h, s);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)df[s][e] * (float)of[e];
+        if (qi >= L) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) df[s][e] = (bf16)0.f;
+        }
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (qi >= L) dl = 0.f;
+    const float lse_i = lse[(n * A + a) * Lr + (qi < Lr ? qi : Lr - 1)];
+    if (valid && h == 0 && qi < Lr) delta[(n * A + a) * Lr + qi] = dl;
+    const float* relq = rel + ((int64_t)a * Lr + (qi < Lr ? qi : Lr - 1)) * Lr;
+    const float* mp = mask_add + n * Lr;
+    f32x16 dq[2] = {zero16(), zero16()};
+    for (int kt = 0; kt < nqt; ++kt) {
+        const int kj = kt * 32 + row;
+        const int kjc = kj < L ? kj : L - 1;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = ld_frag(qbase + HD, ldq, kjc, h, s);
+            vf[s] = ld_frag(qbase + 2 * HD, ldq, kjc, h, s);
+            *(bf16x8*)(my + row * 128 + (16 * s + 8 * h) * 2) = kf[s];       // K tile for the dQ product
+        }
+        f32x16 st = zero16(), dpt = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            st = TNR_MFMA_32x32x16(kf[s], qf[s], st, 0, 0, 0);
+            dpt = TNR_MFMA_32x32x16(vf[s], df[s], dpt, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 mk = *(const f32x4*)(mp + kt * 32 + 8 * g + 4 * h);
+            f32x4 rl = *(const f32x4*)(relq + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float p = __expf(st[4 * g + e] * 0.125f + mk[e] + rl[e] - lse_i);
+                st[4 * g + e] = p * (dpt[4 * g + e] - dl);                       // dS^T
+            }
+        }
+        bf16x8 dsf[2];
+        acc_to_frags(st, dsf);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dq[ct] = TNR_MFMA_32x32x16(dsf[s], tr_frag(my, s, ct, lane), dq[ct], 0, 0, 0);
+    }
+    acc_to_lds(my, dq[0], 0, lane, 0.125f);
+    acc_to_lds(my, dq[1], 1, lane, 0.125f);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
+        int q = qt * 32 + r;
+        if (valid && q < L) *(bf16x8*)(dqkv + (n * L + q) * ldq + a * 64 + c * 8) = *(const bf16x8*)(my + r * 128 + c * 16);
+    }
+}
+
+// backward pass 2: dK, dV per (sequence, head, key tile), looping over the query tiles
+__global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
+                                                                const float* __restrict__ rel, const bf16* __restrict__ dctx,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                bf16* __restrict__ dqkv, int64_t n_items, int L, int Lr, int A) {
+    __shared__ __attribute__((aligned(16))) char lds[4][2 * 4096];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t item = (int64_t)blockIdx.x * 4 + w;
+    const bool valid = item < n_items;
+    if (!valid) item = n_items - 1;
+    const int nqt = Lr >> 5;
+    const int kt = (int)(item % nqt);
+    const int64_t na = item / nqt;
+    const int64_t n = na / A;
+    const int a = (int)(na - n * A);
+    const int HD = A * 64;
+    const int64_t ldq = 3 * HD;
+    const int row = lane & 31, h = lane >> 5;
+    char* tO = lds[w];
+    char* tQ = tO + 4096;
+    const int kj = kt * 32 + row;                          // this lane's key
+    const int kjc = kj < L ? kj : L - 1;
+    const bf16* qbase = qkv + (n * L) * ldq + a * 64;
+    const bf16* dobase = dctx + (n * L) * HD + a * 64;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = ld_frag(qbase + HD, ldq, kjc, h, s);
+        vf[s] = ld_frag(qbase + 2 * HD, ldq, kjc, h, s);
+    }
+    const float mk = mask_add[n * Lr + (kj < Lr ? kj : Lr - 1)];
+    const float* relc = rel + (int64_t)a * Lr * Lr + (kj < Lr ? kj : Lr - 1);
+    const float* lsep = lse + (n * A + a) * Lr;
+    const float* dlp = delta + (n * A + a) * Lr;
+    f32x16 dv[2] = {zero16(), zero16()}, dk[2] = {zero16(), zero16()};
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int qi = qt * 32 + row;
+        const int qic = qi < L ? qi : L - 1;
+        bf16x8 qf[4], df[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = ld_frag(qbase, ldq, qic, h, s);
+            df[s] = ld_frag(dobase, HD, qic, h, s);
+            if (qi >= L) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) df[s][e] = (bf16)0.f;
+            }
+            int off = row * 128 + (16 * s + 8 * h) * 2;
+            *(bf16x8*)(tO + off) = df[s];
+            *(bf16x8*)(tQ + off) = qf[s];
+        }
+        f32x16 sn = zero16(), dpn = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sn = TNR_MFMA_32x32x16(qf[s], kf[s], sn, 0, 0, 0);             // S[i][j]: regs = queries, lanes = keys
+            dpn = TNR_MFMA_32x32x16(df[s], vf[s], dpn, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 ls = *(const f32x4*)(lsep + qt * 32 + 8 * g + 4 * h);
+            f32x4 dd = *(const f32x4*)(dlp + qt * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int q = qt * 32 + 8 * g + 4 * h + e;
+                float p = __expf(sn[4 * g + e] * 0.125f + mk + relc[(int64_t)q * Lr] - ls[e]);
+                sn[4 * g + e] = p;
+                dpn[4 * g + e] = p * (dpn[4 * g + e] - dd[e]);
+            }
+        }
+        bf16x8 pnf[2], dsf[2];
+        acc_to_frags(sn, pnf);
+        acc_to_frags(dpn, dsf);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dv[ct] = TNR_MFMA_32x32x16(pnf[s], tr_frag(tO, s, ct, lane), dv[ct], 0, 0, 0);
+                dk[ct] = TNR_MFMA_32x32x16(dsf[s], tr_frag(tQ, s, ct, lane), dk[ct], 0, 0, 0);
+            }
+    }
+    acc_to_lds(tO, dk[0], 0, lane, 0.125f);
+    acc_to_lds(tO, dk[1], 1, lane, 0.125f);
+    acc_to_lds(tQ, dv[0], 0, lane, 1.0f);
+    acc_to_lds(tQ, dv[1], 1, lane, 1.0f);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
+        int j = kt * 32 + r;
+        if (valid && j < L) {
+            bf16* dst = dqkv + (n * L + j) * ldq + a * 64 + c * 8;
+            *(bf16x8*)(dst + HD) = *(const bf16x8*)(tO + r * 128 + c * 16);
+            *(bf16x8*)(dst + 2 * HD) = *(const bf16x8*)(tQ + r * 128 + c * 16);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int TNR_NAME(tnr_attn_l32_fwd)(const void* qkv, const float* mask_add, const float* rel, void* ctx, int64_t n_seq,
@@ -330,5 +620,34 @@ extern "C" int TNR_NAME(tnr_attn_l32_bwd)(const void* qkv, const float* mask_add
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)qkv, mask_add, rel, (const bf16*)dctx, (bf16*)dqkv, bias_part, pairs, L, A);
     TNR_CHECK_LAUNCH("tnr_attn_l32_bwd");
+    return TNR_OK;
+}
+
+extern "C" int TNR_NAME(tnr_attn_long_fwd)(const void* qkv, const float* mask_add, const float* rel, void* ctx, float* lse,
+                                           int64_t n_seq, int L, int A, void* stream) {
+    TNR_CHECK_ARG(qkv && mask_add && rel && ctx && lse, "tnr_attn_long_fwd: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 512 && A >= 1 && n_seq >= 1, "tnr_attn_long_fwd: need 1<=L<=512");
+    const int Lr = (L + 31) / 32 * 32;
+    int64_t items = n_seq * A * (Lr / 32);
+    hipLaunchKernelGGL(attn_long_fwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)qkv, mask_add, rel, (bf16*)ctx, lse, items, L, Lr, A);
+    TNR_CHECK_LAUNCH("tnr_attn_long_fwd");
+    return TNR_OK;
+}
+
+extern "C" int TNR_NAME(tnr_attn_long_bwd)(const void* qkv, const float* mask_add, const float* rel, const void* ctx,
+                                           const void* dctx, const float* lse, float* delta, void* dqkv, int64_t n_seq,
+                                           int L, int A, void* stream) {
+    TNR_CHECK_ARG(qkv && mask_add && rel && ctx && dctx && lse && delta && dqkv, "tnr_attn_long_bwd: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 512 && A >= 1 && n_seq >= 1, "tnr_attn_long_bwd: need 1<=L<=512");
+    const int Lr = (L + 31) / 32 * 32;
+    int64_t items = n_seq * A * (Lr / 32);
+    dim3 grid((unsigned)((items + 3) / 4)), blk(256);
+    hipLaunchKernelGGL(attn_long_bwd_dq_kernel, grid, blk, 0, (hipStream_t)stream, (const bf16*)qkv, mask_add, rel,
+                       (const bf16*)ctx, (const bf16*)dctx, lse, delta, (bf16*)dqkv, items, L, Lr, A);
+    TNR_CHECK_LAUNCH("tnr_attn_long_bwd/dq");
+    hipLaunchKernelGGL(attn_long_bwd_dkv_kernel, grid, blk, 0, (hipStream_t)stream, (const bf16*)qkv, mask_add, rel,
+                       (const bf16*)dctx, lse, delta, (bf16*)dqkv, items, L, Lr, A);
+    TNR_CHECK_LAUNCH("tnr_attn_long_bwd/dkv");
     return TNR_OK;
 }

@@ -41,10 +41,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const TokT* __restrict__ 
     const int64_t trow = nidx ? (int64_t)nidx[n] : n;       // news index -> row of the resident token table
     int64_t id = (int64_t)tok[trow * 2 * L + i];
     if (lane == 0) {
+        const int Lr = (L + 31) & ~31;                       // mask rows are padded to a multiple of 32 keys
         int64_t mk = (int64_t)tok[trow * 2 * L + L + i];
-        mask_add[n * 32 + i] = (1.0f - (float)mk) * -10000.0f;
+        mask_add[n * Lr + i] = (1.0f - (float)mk) * -10000.0f;
         if (i == 0)
-            for (int j = L; j < 32; ++j) mask_add[n * 32 + j] = -1e30f;
+            for (int j = L; j < Lr; ++j) mask_add[n * Lr + j] = -1e30f;
     }
     float x[V][4];
 #pragma unroll
@@ -301,10 +302,12 @@ __device__ __forceinline__ int relpos_bucket(int rel) {
     else b = 15;
     return (rel > 0 ? 16 : 0) + b;
 }
-__global__ void relpos_kernel(const float* __restrict__ weight, int A, int L, float* __restrict__ table) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= A * 1024) return;
-    int a = idx >> 10, i = (idx >> 5) & 31, j = idx & 31;
+__global__ void relpos_kernel(const float* __restrict__ weight, int A, int L, int Lr, float* __restrict__ table) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)A * Lr * Lr) return;
+    int a = (int)(idx / ((int64_t)Lr * Lr));
+    int rem = (int)(idx - (int64_t)a * Lr * Lr);
+    int i = rem / Lr, j = rem - i * Lr;
     table[idx] = (i < L && j < L) ? weight[a * 32 + relpos_bucket(j - i)] : 0.f;
 }
 
@@ -321,8 +324,10 @@ __global__ void cast_b2f_kernel(const bf16* __restrict__ s, float* __restrict__ 
 
 #ifndef TNR_BUILD_F16
 extern "C" int tnr_relpos_table(const float* weight, int A, int L, float* table, void* stream) {
-    TNR_CHECK_ARG(weight && table && A >= 1 && L >= 1 && L <= 32, "tnr_relpos_table: need 1<=L<=32");
-    hipLaunchKernelGGL(relpos_kernel, dim3((A * 1024 + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, A, L, table);
+    TNR_CHECK_ARG(weight && table && A >= 1 && L >= 1 && L <= 512, "tnr_relpos_table: need 1<=L<=512");
+    const int Lr = (L + 31) / 32 * 32;        // table is (A, Lr, Lr): (A,32,32) for the fused short kernel
+    hipLaunchKernelGGL(relpos_kernel, dim3((unsigned)(((int64_t)A * Lr * Lr + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, A, L, Lr, table);
     TNR_CHECK_LAUNCH("tnr_relpos_table");
     return TNR_OK;
 }
@@ -333,7 +338,7 @@ extern "C" int TNR_NAME(tnr_embed_ln_fwd)(const int64_t* tok, int64_t n_seq, int
                                 const float* type0, const float* gamma, const float* beta, float eps, void* out,
                                 float* mask_add, void* stream) {
     TNR_CHECK_ARG(tok && word && pos && type0 && gamma && beta && out && mask_add, "tnr_embed_ln_fwd: null pointer");
-    TNR_CHECK_ARG(L >= 1 && L <= 32 && n_seq >= 1, "tnr_embed_ln_fwd: need 1<=L<=32");
+    TNR_CHECK_ARG(L >= 1 && L <= 512 && n_seq >= 1, "tnr_embed_ln_fwd: need 1<=L<=512");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_embed_ln_fwd: H must be 256/512/768/1024");
     int64_t n_tok = n_seq * L;
     dim3 grid((unsigned)((n_tok + 3) / 4)), blk(256);
@@ -350,7 +355,7 @@ extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed)(const int32_t* news_combined, 
                                         const float* beta, float eps, void* out, float* mask_add, void* stream) {
     TNR_CHECK_ARG(news_combined && nidx && word && pos && type0 && gamma && beta && out && mask_add,
                   "tnr_embed_ln_fwd_indexed: null pointer");
-    TNR_CHECK_ARG(L >= 1 && L <= 32 && n_seq >= 1, "tnr_embed_ln_fwd_indexed: need 1<=L<=32");
+    TNR_CHECK_ARG(L >= 1 && L <= 512 && n_seq >= 1, "tnr_embed_ln_fwd_indexed: need 1<=L<=512");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_embed_ln_fwd_indexed: H must be 256/512/768/1024");
     int64_t n_tok = n_seq * L;
     dim3 grid((unsigned)((n_tok + 3) / 4)), blk(256);

@@ -30,6 +30,8 @@ _SIG = {
     "tnr_ln_bwd_part_elems": [_L, _I],
     "tnr_attn_l32_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "tnr_attn_l32_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "tnr_attn_long_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "tnr_attn_long_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "tnr_colsum": [_P, _L, _I, _L, _L, _P, _P, _I, _P],
     "tnr_colsum_batched": [_P, _L, _L, _I, _L, _L, _I, _P, _P, _I, _P],
     "tnr_colsum_part_elems": [_L, _L],
@@ -52,7 +54,7 @@ _SIG = {
 }
 # entry points that exist twice: bf16 (plain name) and fp16 (suffix _f16)
 TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_colsum_rows",
-         "tnr_gemm_tn_wgrad", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd",
+         "tnr_gemm_tn_wgrad", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd",
          "tnr_colsum", "tnr_colsum_batched", "tnr_attpool_fwd", "tnr_attpool_bwd", "tnr_refresh_shadows",
          "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32"]
 for _n in TYPED:
