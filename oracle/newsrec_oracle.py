@@ -415,6 +415,73 @@ def model_bwd(P, cfg, out):
 
 
 # --------------------------------------------------------------------------- #
+# Stage-1 KD: DistillModel.forward  (Post-train_KD.ipynb cell 14:13-44, TitleBodySimModel cell 12)
+# As published the cell multiplies a Python list by a tensor (cell 14:41); restated with the evident intent
+# torch.stack(teacher_MSEs, -1), the form model_bert.py:300 uses.
+# --------------------------------------------------------------------------- #
+def distill_fwd(P, cfg, title, body, label, teacher_titles, teacher_bodies, keep=True):
+    """title (B,1+K,2Lt) int, body (B,2Lb) int, label (B,), teacher_titles T x (B,1+K,D), teacher_bodies T x (B,D).
+    cfg: n_layers, heads, trainable_layers.  loss = target + distill(tau=1) + emb."""
+    B, C, W2 = title.shape
+    A, nl = cfg["heads"], cfg["n_layers"]
+    tr = sorted(cfg["trainable_layers"])
+    keep_from = (min(tr) if tr else nl) if keep else None
+    bvec, bc = news_encoder_fwd(P, body, nl, A, keep_from)                     # cell 12: body first
+    tvec, tc = news_encoder_fwd(P, title.reshape(B * C, W2), nl, A, keep_from)
+    D = bvec.shape[1]
+    tv = tvec.reshape(B, C, D)
+    score = np.einsum("bcd,bd->bc", tv, bvec).astype(F32)
+    target = cross_entropy_rows(score, label).mean(dtype=F32)
+    T = len(teacher_titles)
+    t_scores, t_losses, mses, ptit, pbod = [], [], [], [], []
+    for i in range(T):
+        tt, tb = teacher_titles[i].astype(F32), teacher_bodies[i].astype(F32)
+        ts = np.einsum("bcd,bd->bc", tt, tb).astype(F32)
+        t_scores.append(ts)
+        t_losses.append(cross_entropy_rows(ts, label))
+        W, b = P["transform_matrix.%d.weight" % i], P["transform_matrix.%d.bias" % i]
+        pt, pb = linear(tt, W, b).astype(F32), linear(tb, W, b).astype(F32)
+        mses.append(((tv - pt) ** 2).mean(-1).mean(-1) + ((bvec - pb) ** 2).mean(-1))
+        ptit.append(pt); pbod.append(pb)
+    tw = softmax(-np.stack(t_losses, -1), -1)
+    mix = np.einsum("bct,bt->bc", np.stack(t_scores, -1), tw).astype(F32)
+    pT = softmax(mix, -1)
+    distill = (-(pT * log_softmax(score, -1)).sum(-1)).mean(dtype=F32)
+    emb = (np.stack(mses, -1) * tw).sum(-1).mean(dtype=F32)
+    out = dict(total_loss=F32(target + distill + emb), target_loss=F32(target), distill_loss=F32(distill), emb_loss=F32(emb),
+               student_score=score, title_vec=tv, body_vec=bvec, teacher_weights=tw)
+    out["cache"] = dict(bc=bc, tc=tc, pT=pT, tw=tw, ptit=ptit, pbod=pbod, label=label, B=B, C=C, D=D,
+                        tt=[x.astype(F32) for x in teacher_titles], tb=[x.astype(F32) for x in teacher_bodies])
+    return out
+
+
+def distill_bwd(P, cfg, out):
+    c = out["cache"]
+    B, C, D, tw, label = c["B"], c["C"], c["D"], c["tw"], c["label"]
+    score, tv, bvec = out["student_score"], out["title_vec"], out["body_vec"]
+    onehot = np.zeros_like(score)
+    onehot[np.arange(B), label] = 1.0
+    dscore = ((softmax(score, -1) - c["pT"]) + (softmax(score, -1) - onehot)) / F32(B)
+    dtv = dscore[:, :, None] * bvec[:, None, :]
+    dbv = np.einsum("bc,bcd->bd", dscore, tv)
+    G = {}
+    for i in range(len(c["ptit"])):
+        w_i = tw[:, i]
+        dt = (2.0 / (C * D * B)) * w_i[:, None, None] * (tv - c["ptit"][i])
+        db_ = (2.0 / (D * B)) * w_i[:, None] * (bvec - c["pbod"][i])
+        dtv = dtv + dt
+        dbv = dbv + db_
+        G["transform_matrix.%d.weight" % i] = ((-dt).reshape(-1, D).T @ c["tt"][i].reshape(-1, D) + (-db_).T @ c["tb"][i]).astype(F32)
+        G["transform_matrix.%d.bias" % i] = ((-dt).reshape(-1, D).sum(0) + (-db_).sum(0)).astype(F32)
+    trl = set(cfg["trainable_layers"])
+    g1 = news_encoder_bwd(P, dtv.reshape(B * C, D).astype(F32), c["tc"], cfg["heads"], trl)
+    g2 = news_encoder_bwd(P, dbv.astype(F32), c["bc"], cfg["heads"], trl)
+    for k in g1:
+        G[k] = (g1[k] + g2[k]).astype(F32)
+    return G
+
+
+# --------------------------------------------------------------------------- #
 # PLM-NR ModelBert.forward  (PLM-NR/model_bert.py:187-207): same encoders + CE
 # --------------------------------------------------------------------------- #
 def plmnr_fwd(P, cfg, history, history_mask, candidate, label):

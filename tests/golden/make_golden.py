@@ -212,6 +212,7 @@ def golden_amsgrad():
 def main():
     golden_interface()
     R = ref_shim.load_reference()
+    golden_stage1(R)
     golden_relpos(R)
     golden_datapath(R)
     golden_amsgrad()
@@ -233,6 +234,80 @@ def main():
         np.savez_compressed(os.path.join(HERE, "full_model_%d.npz" % k), **rec)
         print("full", k, rec["total"], rec["distill"], rec["emb"], rec["target"])
 
+
+
+def _notebook_distill_classes(R, cfg_json):
+    """Execute the class / loss cells of the reference's Post-train_KD.ipynb (cells 11-14) in a namespace that
+    resolves their globals; only the published list*tensor bug of cell 14:41 is patched (torch.stack, as in
+    model_bert.py:300)."""
+    import json
+    import torch.nn.functional as Fn
+    nb = json.load(open(os.path.join(ref_shim.REF_ROOT, "Post-train_KD.ipynb")))
+    tmp = os.path.dirname(ref_shim.write_config(cfg_json))
+    os.replace(os.path.join(tmp, "config.json"), os.path.join(tmp, "unilm2-base-uncased-config.json"))
+    ns = dict(torch=torch, nn=torch.nn, F=Fn, np=np, os=os, MODEL_CLASSES=R.utils.MODEL_CLASSES, path_turing=tmp)
+    for i in (11, 12, 13, 14):
+        src = "".join(nb["cells"][i]["source"])
+        src = src.replace("        emb_loss = (teacher_MSEs * teacher_weights)",
+                          "        teacher_MSEs = torch.stack(teacher_MSEs, dim=-1)\n        emb_loss = (teacher_MSEs * teacher_weights)")
+        exec(compile(src, "Post-train_KD.ipynb cell %d" % i, "exec"), ns)
+    return ns
+
+
+def golden_stage1(R):
+    import types
+    cases = [("tiny", dict(ref_shim.BASE_CFG, hidden_size=64, num_attention_heads=4, intermediate_size=256, vocab_size=128,
+                           max_position_embeddings=64, num_hidden_layers=2), dict(news_dim=32, news_query_vector_dim=16),
+              (0, 1), 3, 4, 3, 10, 40, 128, True, 300),
+             ("full", dict(ref_shim.BASE_CFG, num_hidden_layers=2), dict(news_dim=256, news_query_vector_dim=200),
+              (0, 1), 2, 2, 4, 24, 128, 30522, False, 301)]
+    for name, cfg_json, dims, trainable, T, B, C, Lt, Lb, vocab, full, seed in cases:
+        ns = _notebook_distill_classes(R, cfg_json)
+        args = types.SimpleNamespace(num_hidden_layers=cfg_json["num_hidden_layers"], num_teachers=T, **dims)
+        model = ns["DistillModel"](args)
+        fill(model, seed)
+        for p in model.student.news_encoder.bert_model.parameters():
+            p.requires_grad = False
+        for i, layer in enumerate(model.student.news_encoder.bert_model.bert.encoder.layer):
+            if i in trainable:
+                for p in layer.parameters():
+                    p.requires_grad = True
+        D = dims["news_dim"]
+
+        def toks(tag, n, L):
+            ln = hashinit.hash_randint(seed, tag + "len", (n,), 3, L + 1)
+            ids = hashinit.hash_randint(seed, tag + "ids", (n, L), 1, vocab)
+            m = (np.arange(L)[None, :] < ln[:, None]).astype(np.int64)
+            return np.concatenate([ids * m, m], 1)
+        title = toks("t", B * C, Lt).reshape(B, C, 2 * Lt)
+        body = toks("b", B, Lb)
+        label = hashinit.hash_randint(seed, "lab", (B,), 0, C)
+        tt = [hashinit.hash_normal(seed, "tt%d" % i, (B, C, D), std=0.3) for i in range(T)]
+        tb = [hashinit.hash_normal(seed, "tb%d" % i, (B, D), std=0.3) for i in range(T)]
+        t_ = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+        loss, target, distill, emb, score = model(t_(title), t_(body), t_(label), [t_(x) for x in tt], [t_(x) for x in tb])
+        loss.backward()
+        rec = dict(total=loss.item(), target=target.item(), distill=distill.item(), emb=emb.item(), score=score.detach().numpy(),
+                   in_title=title, in_body=body, in_label=label,
+                   meta=np.array([seed, B, T, C, Lt, Lb, D, cfg_json["num_attention_heads"], cfg_json["num_hidden_layers"]]),
+                   trainable=np.array(sorted(trainable)))
+        for i in range(T):
+            rec["in_tt%d" % i], rec["in_tb%d" % i] = tt[i], tb[i]
+        gn = []
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.numpy()
+            gn.append(k)
+            rec["gnorm." + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            if full:
+                rec["grad." + k] = g
+            else:
+                idx, val = grad_samples(seed, k, g)
+                rec["gidx." + k], rec["gval." + k] = idx, val
+        rec["grad_names"] = np.array(gn)
+        np.savez_compressed(os.path.join(HERE, "stage1_%s.npz" % name), **rec)
+        print("stage1", name, rec["total"], rec["target"], rec["distill"], rec["emb"])
 
 
 def golden_interface():

@@ -76,3 +76,14 @@ def load_case(name):
     inp = (z["in_hist"], z["in_mask"], z["in_cand"], z["in_label"],
            [z["in_th%d" % i] for i in range(T)], [z["in_tc%d" % i] for i in range(T)])
     return z, P, cfg, inp
+
+
+def load_stage1_case(name):
+    """Stage-1 KD golden (Post-train_KD.ipynb DistillModel) -> (z, P, cfg, inputs)."""
+    z = np.load(os.path.join(GOLDEN, name))
+    seed, B, T, C, Lt, Lb, D, A, nl = [int(x) for x in z["meta"]]
+    dims = dict(TINY, Q=16) if name.startswith("stage1_tiny") else FULL
+    P = hashinit.init_state_dict(seed, state_shapes(dims, nl, D, T))
+    cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]])
+    inp = (z["in_title"], z["in_body"], z["in_label"], [z["in_tt%d" % i] for i in range(T)], [z["in_tb%d" % i] for i in range(T)])
+    return z, P, cfg, inp

@@ -116,3 +116,28 @@ def test_tiny_model_forward_backward(name):
 @pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "full_model_*.npz"))))
 def test_full_model_forward_backward(name):
     _check_model(name, False)
+
+
+@pytest.mark.parametrize("name", ["stage1_tiny.npz", "stage1_full.npz"])
+def test_stage1_distill_forward_backward(name):
+    """Stage-1 KD (title/body matching, bodies of 40 / 128 tokens) against the notebook's DistillModel."""
+    from helpers import load_stage1_case
+    z, P, cfg, inp = load_stage1_case(name)
+    out = O.distill_fwd(P, cfg, *inp)
+    for k, g in (("total_loss", "total"), ("target_loss", "target"), ("distill_loss", "distill"), ("emb_loss", "emb")):
+        np.testing.assert_allclose(out[k], z[g], rtol=RTOL, atol=ATOL, err_msg=k)
+    np.testing.assert_allclose(out["student_score"], z["score"], rtol=1e-3, atol=ATOL)
+    G = O.distill_bwd(P, cfg, out)
+    for n in [str(x) for x in z["grad_names"]]:
+        g = G[n]
+        ref_norm = float(z["gnorm." + n])
+        if n.endswith("self.key.bias") or n.endswith("att_fc2.bias"):
+            assert np.sqrt((g.astype(np.float64) ** 2).sum()) < 1e-4 and ref_norm < 1e-4
+            continue
+        np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), ref_norm, rtol=1e-3, atol=1e-9, err_msg=n)
+        if "grad." + n in z.files:
+            ref = z["grad." + n]
+            np.testing.assert_allclose(g, ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-10, err_msg=n)
+        else:
+            ref = z["gval." + n]
+            np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-10, err_msg=n)
