@@ -131,7 +131,7 @@ int64_t tnr_colsum_part_elems(int64_t M, int64_t N);
 
 /* AttentionPooling over the L tokens of each title, no mask (model_bert.py:15-34 called at :133).
  * e (N*L, lde) fp32 = tanh(fc1 y) from tnr_gemm_nt (padded columns must be 0) ; w2 (Q) ; b2 scalar.
- * out: nv (N,H) fp32, alpha (N,32) fp32 normalised weights, den (N) fp32 = sum exp + 1e-8. */
+ * out: nv (N,H) fp32, alpha (N,Lr) fp32 normalised weights (Lr = roundup(L,32), L <= 512), den (N) fp32 = sum exp + 1e-8. */
 int tnr_attpool_fwd(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
                     float* nv, float* alpha, float* den, int64_t n_seq, int L, int H, void* stream);
 /* backward: dnv (N,H) fp32 -> dy_direct (N*L,H) bf16 = alpha*dnv ; dpre (N*L, lddpre) bf16 =
@@ -144,7 +144,7 @@ int tnr_attpool_bwd(const void* y, const float* e, int64_t lde, const float* w2,
 /* small fp32 GEMM on the f32 MFMA (exact fp32):  for z in [0,batch):
  *   C_z[m,n] = alpha * sum_k A_z(m,k) B_z(n,k) + bias_z[n] + beta * C_z[m,n]
  * A_z(m,k) = A[z*sA + m*a_rs + k*a_cs] (a_idx must be NULL), likewise B.  ksplit > 1 splits K over workgroups
- * into part (ksplit, batch, M, N) fp32 and sums them in fixed order (needs dense C, no bias/alpha/beta). */
+ * into part (ksplit, batch, M, N) fp32 and sums them in fixed order (needs dense C, no bias/alpha; beta 0 or 1). */
 int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA, const int32_t* a_idx,
               const float* B, int64_t b_rs, int64_t b_cs, int64_t sB,
               float* C, int64_t ldc, int64_t sC, const float* bias, int64_t sBias,
@@ -185,6 +185,7 @@ int tnr_kd_score_loss(const float* s_score, const float* t_score, const int64_t*
                       float coef, float* tw, float* dscore, float* losses, int B, int C, int T, void* stream);
 /* embedding KD (model_bert.py:277-284, 300-303) on stacked rows [B*U history | B*C candidate | B user]:
  * S (Rtot,D) student rows ; P (T,Rtot,D) projected teacher rows ; tw (B,T) ; Rtot = B*(U+C+1).
+ * U = 0 is the stage-1 layout [B*C titles | B bodies] (Post-train_KD.ipynb cell 14).
  * out: emb loss (scalar) ; dS (Rtot,D) ; dP (T,Rtot,D) ; part (Rtot) workspace. */
 int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* loss, float* dS, float* dP,
                       float* part, int B, int U, int C, int D, int T, void* stream);

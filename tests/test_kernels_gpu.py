@@ -252,8 +252,10 @@ def test_attention_fwd_bwd(N, L, A):
 
 
 # ------------------------------------------------------------------------------------------------ heads
-def test_attpool_fwd_bwd():
-    N, L, H, Q, QP = 9, 30, 768, 200, 256
+@pytest.mark.parametrize("L", [30, 128])
+def test_attpool_fwd_bwd(L):
+    N, H, Q, QP = 9, 768, 200, 256
+    Lr = (L + 31) // 32 * 32
     y = bf(rnd((N, L, H), 1))
     w1, b1 = rnd((Q, H), 2, 0.05), rnd((Q,), 3, 0.05)
     w2, b2 = rnd((1, Q), 4, 0.2), rnd((1,), 5, 0.05)
@@ -261,7 +263,7 @@ def test_attpool_fwd_bwd():
     e = np.zeros((N * L, QP), np.float32)
     e[:, :Q] = c["e"].reshape(N * L, Q)
     nv = torch.zeros((N, H), device=DEV)
-    alpha = torch.zeros((N, 32), device=DEV)
+    alpha = torch.zeros((N, Lr), device=DEV)
     den = torch.zeros(N, device=DEV)
     yd, ed = dev(y.reshape(N * L, H), torch.bfloat16), dev(e)
     T.call("tnr_attpool_fwd", yd, ed, QP, dev(w2[0]), dev(b2), Q, nv, alpha, den, N, L, H)

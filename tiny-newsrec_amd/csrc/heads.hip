@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void attpool_fwd_kernel(const bf16* __restrict
                                                           int64_t lde, const float* __restrict__ w2,
                                                           const float* __restrict__ b2, int Q, float* __restrict__ nv,
                                                           float* __restrict__ alpha, float* __restrict__ den, int L, int H) {
-    __shared__ float al[32];
+    __shared__ float al[512];
+    const int Lr = (L + 31) & ~31;                 // alpha rows are padded to a multiple of 32 tokens
     const int64_t n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = w; i < L; i += 4) {
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void attpool_fwd_kernel(const bf16* __restrict
     float d = 0.f;
     for (int i = 0; i < L; ++i) d += al[i];
     d += 1e-8f;
-    if (tid < 32) alpha[n * 32 + tid] = tid < L ? al[tid] / d : 0.f;
+    for (int i = tid; i < Lr; i += 256) alpha[n * Lr + i] = i < L ? al[i] / d : 0.f;
     if (tid == 0) den[n] = d;
     for (int c = tid * 4; c < H; c += 1024) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -45,7 +46,9 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const bf16* __restrict
                                                           bf16* __restrict__ dy, bf16* __restrict__ dpre, int64_t lddpre,
                                                           float* __restrict__ dw2_part, float* __restrict__ db2_part,
                                                           float* __restrict__ db1_part, int L, int H) {
-    __shared__ float dw[32], da[32];
+    __shared__ float dw[512], da[512];
+    __shared__ float Sred;
+    const int Lr = (L + 31) & ~31;
     const int64_t n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = w; i < L; i += 4) {
@@ -60,14 +63,19 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const bf16* __restrict
         if (lane == 0) dw[i] = s;
     }
     __syncthreads();
-    float S = 0.f;
-    for (int i = 0; i < L; ++i) S += dw[i] * alpha[n * 32 + i];
-    if (tid < L) da[tid] = alpha[n * 32 + tid] * (dw[tid] - S);      // d loss / d (fc2 output) of token tid
+    if (tid == 0) {
+        float t = 0.f;
+        for (int i = 0; i < L; ++i) t += dw[i] * alpha[n * Lr + i];
+        Sred = t;
+    }
+    __syncthreads();
+    const float S = Sred;
+    for (int i = tid; i < L; i += 256) da[i] = alpha[n * Lr + i] * (dw[i] - S);      // d loss / d (fc2 output) of token i
     __syncthreads();
     for (int c = tid * 4; c < H; c += 1024) {
         f32x4 g = *(const f32x4*)(dnv + n * H + c);
         for (int i = 0; i < L; ++i) {
-            float wi = alpha[n * 32 + i];
+            float wi = alpha[n * Lr + i];
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (bf16)(wi * g[r]);
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
 extern "C" int TNR_NAME(tnr_attpool_fwd)(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
                                float* nv, float* alpha, float* den, int64_t n_seq, int L, int H, void* stream) {
     TNR_CHECK_ARG(y && e && w2 && b2 && nv && alpha && den, "tnr_attpool_fwd: null pointer");
-    TNR_CHECK_ARG(L >= 1 && L <= 32 && (H % 4) == 0 && Q >= 1 && lde >= Q && n_seq >= 1, "tnr_attpool_fwd: bad shape");
+    TNR_CHECK_ARG(L >= 1 && L <= 512 && (H % 4) == 0 && Q >= 1 && lde >= Q && n_seq >= 1, "tnr_attpool_fwd: bad shape");
     hipLaunchKernelGGL(attpool_fwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, e,
                        lde, w2, b2, Q, nv, alpha, den, L, H);
     TNR_CHECK_LAUNCH("tnr_attpool_fwd");
@@ -531,7 +539,7 @@ extern "C" int TNR_NAME(tnr_attpool_bwd)(const void* y, const float* e, int64_t 
                                float* dw2_part, float* db2_part, float* db1_part, int64_t n_seq, int L, int H, void* stream) {
     (void)den;
     TNR_CHECK_ARG(y && e && w2 && dnv && alpha && dy_direct && dpre && dw2_part && db2_part, "tnr_attpool_bwd: null pointer");
-    TNR_CHECK_ARG(L >= 1 && L <= 32 && (H % 4) == 0 && Q >= 1 && lde >= Q && lddpre >= Q && n_seq >= 1,
+    TNR_CHECK_ARG(L >= 1 && L <= 512 && (H % 4) == 0 && Q >= 1 && lde >= Q && lddpre >= Q && n_seq >= 1,
                   "tnr_attpool_bwd: bad shape");
     hipLaunchKernelGGL(attpool_bwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, e,
                        lde, w2, Q, dnv, alpha, (bf16*)dy_direct, (bf16*)dpre, lddpre, dw2_part, db2_part, db1_part, L, H);
@@ -552,17 +560,19 @@ extern "C" int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA,
     if (ksplit < 1) ksplit = 1;
     int kchunk = (int)K;
     if (ksplit > 1) {
-        TNR_CHECK_ARG(part && bias == nullptr && alpha == 1.0f && beta == 0.0f && ldc == N && (batch == 1 || sC == M * N),
-                      "tnr_sgemm: split-K needs a partial buffer, dense C, no bias/alpha/beta");
+        TNR_CHECK_ARG(part && bias == nullptr && alpha == 1.0f && (beta == 0.0f || beta == 1.0f) && ldc == N &&
+                          (batch == 1 || sC == M * N),
+                      "tnr_sgemm: split-K needs a partial buffer, dense C, no bias/alpha, beta 0 or 1");
         kchunk = (int)(((K + ksplit - 1) / ksplit + 15) / 16 * 16);
         ksplit = (int)((K + kchunk - 1) / kchunk);
     }
     SgemmArgs g{A, a_rs, a_cs, sA, B, b_rs, b_cs, sB, ksplit > 1 ? part : C, ldc, sC, bias, sBias, (int)M, (int)N, (int)K,
-                alpha, beta, ksplit, kchunk, batch};
+                alpha, ksplit > 1 ? 0.f : beta, ksplit, kchunk, batch};
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(batch * ksplit));
     hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     TNR_CHECK_LAUNCH("tnr_sgemm");
-    if (ksplit > 1) return tnr_reduce_rows(part, ksplit, (int64_t)batch * M * N, (int64_t)batch * M * N, C, 0, stream);
+    if (ksplit > 1)
+        return tnr_reduce_rows(part, ksplit, (int64_t)batch * M * N, (int64_t)batch * M * N, C, beta == 1.0f, stream);
     return TNR_OK;
 }
 
@@ -640,7 +650,7 @@ extern "C" int tnr_kd_score_loss(const float* s_score, const float* t_score, con
 extern "C" int tnr_kd_embed_loss(const float* S, const float* P, const float* tw, float* loss, float* dS, float* dP,
                                  float* part, int B, int U, int C, int D, int T, void* stream) {
     TNR_CHECK_ARG(S && P && tw && loss && dS && dP && part, "tnr_kd_embed_loss: null pointer");
-    TNR_CHECK_ARG(B >= 1 && U >= 1 && C >= 1 && (D % 4) == 0 && T >= 1, "tnr_kd_embed_loss: bad shape");
+    TNR_CHECK_ARG(B >= 1 && U >= 0 && C >= 1 && (D % 4) == 0 && T >= 1, "tnr_kd_embed_loss: bad shape");
     int64_t waves = (int64_t)B * (U + C + 1);
     hipLaunchKernelGGL(kd_embed_loss_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, P, tw,
                        dS, dP, part, B, U, C, D, T);

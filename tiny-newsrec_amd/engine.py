@@ -29,7 +29,10 @@ class EngineConfig:
     def __init__(self, n_layers=4, trainable_layers=(2, 3), hidden=768, heads=12, inter=3072, news_dim=256,
                  news_query=200, user_query=200, num_teachers=4, user_log_length=50, npratio=4, num_words=30,
                  user_log_mask=False, temperature=1.0, coef=0.2, vocab=30522, max_pos=512, type_vocab=2,
-                 ln_eps=1e-12):
+                 ln_eps=1e-12, stage1=False):
+        """stage1=True: the DistillModel of Post-train_KD.ipynb (no user encoders: parameters are
+        student.news_encoder.* and transform_matrix.* only; user_log_length is 0, npratio+1 titles per body)."""
+        self.stage1 = stage1
         self.n_layers, self.trainable_layers = n_layers, tuple(sorted(trainable_layers))
         self.H, self.A, self.I, self.D = hidden, heads, inter, news_dim
         self.Qn, self.Qu, self.T = news_query, user_query, num_teachers
@@ -38,7 +41,7 @@ class EngineConfig:
         self.vocab, self.max_pos, self.type_vocab, self.ln_eps = vocab, max_pos, type_vocab, ln_eps
         assert hidden == heads * 64, "attention kernel is built for head size 64"
         assert hidden % 256 == 0 and inter % 128 == 0 and news_dim % 4 == 0 and news_query <= QPAD
-        assert 1 <= num_words <= 32, "fused attention kernel covers titles of up to 32 tokens"
+        assert 1 <= num_words <= 512, "attention kernels cover sequences of up to 512 tokens"
         assert all(0 <= l < n_layers for l in self.trainable_layers)
 
 
@@ -57,15 +60,15 @@ def param_shapes(cfg):
     """state_dict schema of model_bert.Model, in the engine's storage order."""
     H, I, D, T_ = cfg.H, cfg.I, cfg.D, cfg.T
     s = {}
-    for i in range(T_):
+    for i in range(0 if cfg.stage1 else T_):
         s["teachers.%d.attn.att_fc1.weight" % i] = (cfg.Qu, D)
-    for i in range(T_):
+    for i in range(0 if cfg.stage1 else T_):
         s["teachers.%d.attn.att_fc1.bias" % i] = (cfg.Qu,)
-    for i in range(T_):
+    for i in range(0 if cfg.stage1 else T_):
         s["teachers.%d.attn.att_fc2.weight" % i] = (1, cfg.Qu)
-    for i in range(T_):
+    for i in range(0 if cfg.stage1 else T_):
         s["teachers.%d.pad_doc" % i] = (1, D)
-    for i in range(T_):
+    for i in range(0 if cfg.stage1 else T_):
         s["teachers.%d.attn.att_fc2.bias" % i] = (1,)
     s[BERT + "embeddings.word_embeddings.weight"] = (cfg.vocab, H)
     s[BERT + "embeddings.position_embeddings.weight"] = (cfg.max_pos, H)
@@ -96,11 +99,12 @@ def param_shapes(cfg):
     s[PFX + "attn.att_fc2.bias"] = (1,)
     s[PFX + "dense.weight"] = (D, H)
     s[PFX + "dense.bias"] = (D,)
-    s["student.user_encoder.attn.att_fc1.weight"] = (cfg.Qu, D)
-    s["student.user_encoder.attn.att_fc1.bias"] = (cfg.Qu,)
-    s["student.user_encoder.attn.att_fc2.weight"] = (1, cfg.Qu)
-    s["student.user_encoder.pad_doc"] = (1, D)
-    s["student.user_encoder.attn.att_fc2.bias"] = (1,)
+    if not cfg.stage1:
+        s["student.user_encoder.attn.att_fc1.weight"] = (cfg.Qu, D)
+        s["student.user_encoder.attn.att_fc1.bias"] = (cfg.Qu,)
+        s["student.user_encoder.attn.att_fc2.weight"] = (1, cfg.Qu)
+        s["student.user_encoder.pad_doc"] = (1, D)
+        s["student.user_encoder.attn.att_fc2.bias"] = (1,)
     for i in range(T_):
         s["transform_matrix.%d.weight" % i] = (D, D)
     for i in range(T_):
@@ -161,7 +165,7 @@ LOSS_SCALE = 1024.0     # static scale of the 16-bit backward in fp16 mode (grad
 
 
 class Engine:
-    def __init__(self, cfg, device="cuda:0", max_batch=32, dtype="bf16"):
+    def __init__(self, cfg, device="cuda:0", max_batch=32, dtype="bf16", share=None):
         """dtype: 16-bit activation / weight-copy type, "bf16" (default) or "fp16".  fp16 has the same MFMA rate and
         3 more mantissa bits; its backward runs on gradients scaled by LOSS_SCALE from the pooling backward down
         (everything 16-bit), un-scaled inside the AMSGrad kernel."""
@@ -174,8 +178,15 @@ class Engine:
         self.cfg, self.dev = cfg, torch.device(device)
         self.step_count = 0
         self._n_alloc = 0
-        self._build_params()
-        self._build_shadows()
+        if share is None:
+            self._build_params()
+            self._build_shadows()
+        else:
+            # a second pass over the SAME model at another sequence length (stage 1: titles and bodies): parameters,
+            # gradients, optimiser state and 16-bit weight copies are the other engine's, workspaces are its own
+            for k in ("shapes", "slot", "n_train", "n_frozen", "flat", "flat_g", "adam_m", "adam_v", "adam_vmax", "params",
+                      "grads", "lo", "sh", "sh_a1", "sh_a1T", "b_a1", "desc_all", "desc_train"):
+                setattr(self, k, getattr(share, k))
         self.max_batch = max_batch
         self._alloc_workspace(max_batch)
         self.comm = None             # set by dist.attach()
@@ -189,7 +200,7 @@ class Engine:
         T_ = cfg.T
         tstack = lambda suffix: ["teachers.%d.%s" % (i, suffix) for i in range(T_)]
         groups = []
-        if T_:
+        if T_ and not cfg.stage1:
             for suffix in ("attn.att_fc1.weight", "attn.att_fc1.bias", "attn.att_fc2.weight", "pad_doc", "attn.att_fc2.bias"):
                 groups.append((tstack(suffix), None))
         for k in ("word_embeddings.weight", "position_embeddings.weight", "token_type_embeddings.weight",
@@ -209,8 +220,9 @@ class Engine:
         for k in ("attn.att_fc2.weight", "attn.att_fc2.bias", "dense.weight", "dense.bias"):
             groups.append(([PFX + k], None))
         ue = "student.user_encoder."
-        groups.append(([ue + "attn.att_fc1.weight", ue + "attn.att_fc1.bias", ue + "attn.att_fc2.weight", ue + "pad_doc",
-                        ue + "attn.att_fc2.bias"], None))
+        if not cfg.stage1:
+            groups.append(([ue + "attn.att_fc1.weight", ue + "attn.att_fc1.bias", ue + "attn.att_fc2.weight", ue + "pad_doc",
+                            ue + "attn.att_fc2.bias"], None))
         if T_:
             groups.append((["transform_matrix.%d.weight" % i for i in range(T_)], None))
             groups.append((["transform_matrix.%d.bias" % i for i in range(T_)], None))
@@ -299,7 +311,6 @@ class Engine:
         self.sh_a1 = torch.zeros((QPAD, H), device=dev, dtype=bf)
         self.sh_a1T = torch.zeros((H, QPAD), device=dev, dtype=bf)
         self.b_a1 = self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,))
-        self.rel = torch.zeros((cfg.A, 32, 32), device=dev)
 
         def table(layers, with_heads):
             rows = []
@@ -327,7 +338,12 @@ class Engine:
         d = self.desc_all if all_layers else self.desc_train
         self._c("tnr_refresh_shadows", d[0], d[1], d[2], d[3])
         if all_layers:
-            T.call("tnr_relpos_table", self.p(BERT + "rel_pos_bias.weight"), self.cfg.A, self.cfg.L, self.rel)
+            self.refresh_rel()
+
+    def refresh_rel(self):
+        """(A, Lr, Lr) additive rel-pos table of this engine's sequence length (depends on a frozen weight only)."""
+        T.call("tnr_relpos_table", self.p(BERT + "rel_pos_bias.weight"), self.cfg.A, self.cfg.L, self.rel)
+        self._rel_stale = False
 
     # ------------------------------------------------------------------ workspaces
     def _alloc_workspace(self, B):
@@ -338,17 +354,23 @@ class Engine:
         self.B_alloc, self.N_alloc, self.Mp = B, N, Mp
         z = lambda *s, dt=bf: torch.zeros(s, device=dev, dtype=dt)
         f = lambda *s: torch.zeros(s, device=dev, dtype=torch.float32)
+        Lr = _rup(L, 32)
+        self.Lr = Lr
         self.tok = torch.zeros((N, 2 * L), device=dev, dtype=torch.int64)
-        self.mask_add = f(N, 32)
+        self.mask_add = f(N, Lr)
+        self.rel = f(cfg.A, Lr, Lr)
+        self.lse = f(N, cfg.A, Lr) if L > 32 else None        # long-sequence attention keeps the softmax statistics
+        self.delta = f(N, cfg.A, Lr) if L > 32 else None
         self.x0 = z(Mp, H)
         n_keep = cfg.n_layers - self.lo
         mk = lambda: dict(qkv=z(Mp, 3 * H), ctx=z(Mp, H), h1pre=z(Mp, H), st1=f(Mp, 2), h1=z(Mp, H), u=z(Mp, I),
-                          g=z(Mp, I), ypre=z(Mp, H), st2=f(Mp, 2), y=z(Mp, H))
+                          g=z(Mp, I), ypre=z(Mp, H), st2=f(Mp, 2), y=z(Mp, H),
+                          lse=f(N, cfg.A, Lr) if L > 32 else None)
         self.act = [mk() for _ in range(n_keep)]          # resident activations of layers >= lo
         self.scr = mk() if self.lo > 0 else None           # scratch for frozen layers below lo
         self.scr_y = [z(Mp, H), z(Mp, H)] if self.lo > 0 else None
         self.e = f(Mp, QPAD)
-        self.nv, self.alpha, self.den = f(N, H), f(N, 32), f(N)
+        self.nv, self.alpha, self.den = f(N, H), f(N, Lr), f(N)
         Rt = N + B
         self.Rt = Rt
         self.S = f(Rt, D)                 # student rows: [B*U history | B*C candidate | B user]
@@ -379,7 +401,8 @@ class Engine:
         self.ln_part = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
         self.ln_part1 = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
         self.red = {}                                                      # gradient bucket -> _ReduceBatch
-        self.cs_part = f(max(T.query("tnr_colsum_part_elems", Mp, QPAD), T_ * T.query("tnr_colsum_part_elems", Rt, D)))
+        self.cs_part = f(max(T.query("tnr_colsum_part_elems", Mp, 3 * H if L > 32 else QPAD),
+                             T_ * T.query("tnr_colsum_part_elems", Rt, D)))
         self.gcs_part = f(T.query("tnr_gemm_colsum_rows", Mp), I)        # b1 gradient partials from the dgrad epilogue
         self.qkvb_part = f(N, 3 * H)                                       # q/k/v bias gradient partials from attention bwd
         self.db1p = f(N, QPAD)
@@ -388,6 +411,7 @@ class Engine:
         self.KS = 8                                                        # split-K of the long-K small GEMMs
         self.sg_part = f(self.KS * max(T_ * D * D, D * H))
         self.ws = f(max(self._wgrad_splits(n_, k_)[1] for n_, k_ in ((3 * H, H), (H, H), (I, H), (H, I), (QPAD, H))))
+        self._rel_stale = True       # filled by the first encode() (no kernel launch at construction time)
 
     @staticmethod
     def _wgrad_splits(N, K):
@@ -403,20 +427,21 @@ class Engine:
         self._c("tnr_gemm_nt_ex", a, a.stride(0), w, w.stride(0), c, c.stride(0), M, N, K, bias, res,
                res.stride(0) if res is not None else 0, aux, aux.stride(0) if aux is not None else 0, flags, colsum)
 
-    def _wgrad(self, dy, x, dw, M):
+    def _wgrad(self, dy, x, dw, M, acc=0):
         N, K = dw.shape
         self._c("tnr_gemm_tn_wgrad", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws,
-               self._wgrad_splits(N, K)[0], 0)
+               self._wgrad_splits(N, K)[0], acc)
 
     def _colsum(self, x, out, M, dtype=T.BF16):   # dtype BF16 = "the 16-bit type of the build"
         self._c("tnr_colsum", x, x.stride(0), dtype, M, x.shape[1], out, self.cs_part, 0)
 
-    def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, ksplit=1, alpha=1.0):
-        T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, alpha, 0.0,
+    def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, ksplit=1, alpha=1.0,
+               beta=0.0):
+        T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, alpha, beta,
                ksplit, self.sg_part if ksplit > 1 else None)
 
     # ------------------------------------------------------------------ forward
-    def encode(self, tok, n_seq, nidx=None):
+    def encode(self, tok, n_seq, nidx=None, out=None):
         """NewsEncoder.forward model_bert.py:119-137 -> news vectors S[:n_seq] (fp32).
         tok (n_seq, 2L) int64 on device, or (nidx given) tok = resident news_combined (n+1, 2L) int32 and
         nidx (n_seq,) int32 news indices."""
@@ -424,6 +449,8 @@ class Engine:
         H, L = cfg.H, cfg.L
         M = n_seq * L
         g = self.p
+        if self._rel_stale:
+            self.refresh_rel()
         emb = (g(BERT + "embeddings.word_embeddings.weight"), g(BERT + "embeddings.position_embeddings.weight"),
                g(BERT + "embeddings.token_type_embeddings.weight"), g(BERT + "embeddings.LayerNorm.weight"),
                g(BERT + "embeddings.LayerNorm.bias"), cfg.ln_eps, self.x0, self.mask_add)
@@ -442,7 +469,11 @@ class Engine:
             bqkv = self._view(names[3], 3 * H, (3 * H,))
             self.x_in[l] = x
             self._gemm(x, sh["qkv"], a["qkv"], M, bias=bqkv, flags=T.EPI_BIAS)
-            self._c("tnr_attn_l32_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A)
+            if L <= 32:
+                self._c("tnr_attn_l32_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A)
+            else:
+                self._c("tnr_attn_long_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], a["lse"] if kept else self.lse,
+                        n_seq, L, cfg.A)
             self._gemm(a["ctx"], sh["o"], a["h1pre"], M, bias=g(names[7]), res=x, flags=T.EPI_BIAS | T.EPI_RES)
             self._c("tnr_ln_fwd", a["h1pre"], g(names[8]), g(names[9]), cfg.ln_eps, a["h1"], a["st1"], M, H)
             fl = T.EPI_BIAS | T.EPI_GELU | (T.EPI_AUXOUT if kept else 0)
@@ -456,8 +487,9 @@ class Engine:
         self._c("tnr_attpool_fwd", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
                self.nv, self.alpha, self.den, n_seq, L, H)
         wd = g(PFX + "dense.weight")
-        self._sgemm(self.nv, H, 1, 0, wd, H, 1, 0, self.S, cfg.D, 0, g(PFX + "dense.bias"), 0, n_seq, cfg.D, H)
-        return self.S[:n_seq]
+        dst = self.S if out is None else out
+        self._sgemm(self.nv, H, 1, 0, wd, H, 1, 0, dst, cfg.D, 0, g(PFX + "dense.bias"), 0, n_seq, cfg.D, H)
+        return dst[:n_seq]
 
     # ------------------------------------------------------------------ forward-only paths
     @torch.no_grad()
@@ -588,18 +620,12 @@ class Engine:
         bucket i (0 = heads, then one per layer from the top) is complete (dist.py overlaps its all-reduce)."""
         cfg = self.cfg
         B, N, Rt = self.cur
-        U, C, L, D, H, I, T_ = cfg.U, cfg.C, cfg.L, cfg.D, cfg.H, cfg.I, cfg.T
-        M = N * L
-        g, gr = self.p, self.grads
+        U, C, D, T_ = cfg.U, cfg.C, cfg.D, cfg.T
+        g = self.p
         S, dS = self.S[:Rt], self.dS
         hidx, cidx = self._idx(B)
         if T_ > 0:
-            # dW_i = dP_i^T X_i ; db_i = colsum(dP_i)   (transform_matrix, model_bert.py:278,283)
-            dWt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D), grad=True)
-            dbt = self._view("transform_matrix.0.bias", T_ * D, (T_, D), grad=True)
-            self._sgemm(self.dP, 1, D, Rt * D, self.X, 1, D, self.X.stride(0), dWt, D, D * D, None, 0, D, D, Rt, batch=T_,
-                        ksplit=self.KS)
-            self._c("tnr_colsum_batched", self.dP, D, Rt * D, T.F32, Rt, D, T_, dbt, self.cs_part, 0)
+            self._transform_grads(Rt)
         # scorer + user encoder
         T.call("tnr_score_bwd", S, cidx, S[N:], self.dscore, dS, dS[N:], B, C, D)
         ue = "student.user_encoder."
@@ -607,22 +633,41 @@ class Engine:
                g(ue + "attn.att_fc2.weight"), int(cfg.user_log_mask), dS[N:], self.e_u, self.alpha_u, self.den_u, dS,
                self.user_part, B, U, D, cfg.Qu)
         ps = self.user_part.shape[1]
-        rb = self.red.setdefault("heads", _ReduceBatch(self.dev))
+        rb = self.red.setdefault(("heads", 0), _ReduceBatch(self.dev))
         rb.add(self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.weight", ps, (ps,), grad=True))
+        self.backward_encoder(dS[:N], N, after_bucket=after_bucket)
+
+    def _transform_grads(self, Rt):
+        """dW_i = dP_i^T X_i ; db_i = colsum(dP_i)   (transform_matrix, model_bert.py:278,283)"""
+        D, T_ = self.cfg.D, self.cfg.T
+        dWt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D), grad=True)
+        dbt = self._view("transform_matrix.0.bias", T_ * D, (T_, D), grad=True)
+        self._sgemm(self.dP, 1, D, Rt * D, self.X, 1, D, self.X.stride(0), dWt, D, D * D, None, 0, D, D, Rt, batch=T_,
+                    ksplit=self.KS)
+        self._c("tnr_colsum_batched", self.dP, D, Rt * D, T.F32, Rt, D, T_, dbt, self.cs_part, 0)
+
+    def backward_encoder(self, dvec, N, acc=0, after_bucket=None):
+        """NewsEncoder backward for the N sequences of the last encode(): dvec (N,D) fp32 = d loss / d news vectors.
+        acc=1 adds to the gradients already in flat_g (second pass over the same parameters, stage 1)."""
+        cfg = self.cfg
+        L, D, H, I = cfg.L, cfg.D, cfg.H, cfg.I
+        M = N * L
+        g, gr = self.p, self.grads
+        rb = self.red.setdefault(("heads", acc), _ReduceBatch(self.dev))
         # dense + pooling of the news encoder
-        dvec = dS[:N]
         wd = g(PFX + "dense.weight")
-        self._sgemm(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N, ksplit=self.KS)
-        self._c("tnr_colsum", dvec, D, T.F32, N, D, gr[PFX + "dense.bias"], self.cs_part, 0)
+        self._sgemm(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N, ksplit=self.KS,
+                    beta=float(acc))
+        self._c("tnr_colsum", dvec, D, T.F32, N, D, gr[PFX + "dense.bias"], self.cs_part, acc)
         self._sgemm(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D, alpha=self.gscale)   # loss scale enters here
         y = self.y_last
         self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
                self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
-        rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"])
-        rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"])
-        rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True))
+        rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], acc)
+        rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], acc)
+        rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), acc)
         rb.flush()
-        self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M)
+        self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M, acc)
         if after_bucket:
             after_bucket(0)
         if not cfg.trainable_layers:
@@ -636,32 +681,40 @@ class Engine:
             x_in = self.x_in[l]
             # bias gradients ride along: dx column sums from LayerNorm backward, the dgrad epilogue, attention backward;
             # all partial sums of the layer are reduced by one launch at the end (fixed order)
-            rb = self.red.setdefault(l, _ReduceBatch(self.dev)) if tr else None
+            rb = self.red.setdefault((l, acc), _ReduceBatch(self.dev)) if tr else None
             nblk = (M + 127) // 128
             self._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None,
                     self.ln_part if tr else None, M, H)
             if tr:
-                rb.add(self.ln_part, nblk, 3 * H, 2 * H, self._view(names[14], 2 * H, (2 * H,), grad=True))   # [dgamma | dbeta]
-                rb.add(self.ln_part[2 * H:], nblk, 3 * H, H, gr[names[13]])                                     # output.dense.bias
-                self._wgrad(self.dypre, a["g"], gr[names[12]], M)
+                rb.add(self.ln_part, nblk, 3 * H, 2 * H, self._view(names[14], 2 * H, (2 * H,), grad=True), acc)   # [dgamma | dbeta]
+                rb.add(self.ln_part[2 * H:], nblk, 3 * H, H, gr[names[13]], acc)                                 # output.dense.bias
+                self._wgrad(self.dypre, a["g"], gr[names[12]], M, acc)
             self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if tr else 0),
                        colsum=self.gcs_part if tr else None)
             if tr:
-                rb.add(self.gcs_part, self.gcs_part.shape[0], I, I, gr[names[11]])
-                self._wgrad(self.du, a["h1"], gr[names[10]], M)
+                rb.add(self.gcs_part, self.gcs_part.shape[0], I, I, gr[names[11]], acc)
+                self._wgrad(self.du, a["h1"], gr[names[10]], M, acc)
             self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
             self._c("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, None, None, None,
                     self.ln_part1 if tr else None, M, H)
             if tr:
-                rb.add(self.ln_part1, nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True))
-                rb.add(self.ln_part1[2 * H:], nblk, 3 * H, H, gr[names[7]])                                   # attention.output.dense.bias
-                self._wgrad(self.dh1pre, a["ctx"], gr[names[6]], M)
+                rb.add(self.ln_part1, nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True), acc)
+                rb.add(self.ln_part1[2 * H:], nblk, 3 * H, H, gr[names[7]], acc)                               # attention.output.dense.bias
+                self._wgrad(self.dh1pre, a["ctx"], gr[names[6]], M, acc)
             self._gemm(self.dh1pre, sh["oT"], self.dctx, M)
-            self._c("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv,
-                    self.qkvb_part if tr else None, N, L, cfg.A)
+            if L <= 32:
+                self._c("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv,
+                        self.qkvb_part if tr else None, N, L, cfg.A)
+                if tr:
+                    rb.add(self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc)
+            else:
+                self._c("tnr_attn_long_bwd", a["qkv"], self.mask_add, self.rel, a["ctx"], self.dctx, a["lse"], self.delta,
+                        self.dqkv, N, L, cfg.A)
+                if tr:
+                    self._c("tnr_colsum", self.dqkv, 3 * H, T.BF16, M, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True),
+                            self.cs_part, acc)
             if tr:
-                rb.add(self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True))
-                self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M)
+                self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M, acc)
                 rb.flush()
             if l > self.lo:
                 nxt = self.dy2 if dy is self.dy else self.dy

@@ -1,0 +1,108 @@
+"""Stage-1 knowledge distillation (title/body matching post-training) on the HIP engine.
+
+Mirrors DistillModel.forward of the reference's Post-train_KD.ipynb (cells 12-14):
+    body_vec  = news_encoder(body)                       (B, D)        bodies of up to 512 tokens
+    title_vec = news_encoder(title)                      (B, 1+K, D)
+    score     = bmm(title_vec, body_vec)                 (B, 1+K)
+    loss      = CE(score, label) + kd_ce(mixed teacher scores, tau=1) + sum_t w_t * (MSE_title + MSE_body)
+with per-sample teacher weights w = softmax(-CE(teacher score)).  The list*tensor product the notebook writes
+for the weighted sum is evaluated as the stacked product it intends (oracle/newsrec_oracle.py:distill_fwd pins
+that reading against the notebook's own modules).
+
+One model, two sequence lengths: two Engine instances share parameters / gradients / optimiser state / 16-bit
+weight copies and own their workspaces.  The title pass writes its gradients, the body pass accumulates.
+Student rows live in one table S = [B*(1+K) title rows | B body rows], the layout tnr_kd_embed_loss and
+tnr_score_bwd already use in stage 2 with the body vector in the "user" slot.
+
+Trainable set: the engine's (heads + encoder layers in `trainable_layers`); the notebook fine-tunes with plain
+Adam and dropout on every parameter - pass trainable_layers = all layers for its encoder setting.  Not covered yet
+(DESIGN.md "stage 1"): dropout, trainable embeddings, and the non-AMSGrad Adam variant.
+"""
+import torch
+
+import tnr_hip as T
+from engine import Engine, EngineConfig
+
+
+class Stage1Engine:
+    def __init__(self, n_layers=4, trainable_layers=(0, 1, 2, 3), num_teachers=4, npratio=4, title_len=30, body_len=256,
+                 device="cuda:0", batch=32, dtype="bf16", **dims):
+        """dims: hidden, heads, inter, news_dim, news_query, vocab, ... (EngineConfig keywords)."""
+        assert num_teachers >= 1, "stage 1 distils from at least one teacher"
+        common = dict(n_layers=n_layers, trainable_layers=trainable_layers, num_teachers=num_teachers, user_log_length=0,
+                      temperature=1.0, coef=1.0, stage1=True, **dims)
+        self.cfg_t = EngineConfig(npratio=npratio, num_words=title_len, **common)
+        self.cfg_b = EngineConfig(npratio=0, num_words=body_len, **common)
+        self.title = Engine(self.cfg_t, device, max_batch=batch, dtype=dtype)
+        self.body = Engine(self.cfg_b, device, max_batch=batch, dtype=dtype, share=self.title)
+        self.dev = self.title.dev
+
+    # parameters / optimiser state are the title engine's
+    def load_state_dict(self, sd):
+        self.title.load_state_dict(sd)
+        self.body.refresh_rel()
+
+    def state_dict(self):
+        return self.title.state_dict()
+
+    def grad(self, name):
+        return self.title.grad(name)
+
+    @property
+    def shapes(self):
+        return self.title.shapes
+
+    def forward(self, title, body, label, teacher_titles, teacher_bodies):
+        """title (B,1+K,2Lt) / body (B,2Lb) int64 [ids | mask]; label (B,); teacher_* lists of (B,1+K,D) / (B,D) fp32
+        (or stacked (T,B,1+K,D) / (T,B,D)).  -> (losses [distill, target, emb, -], score (B,1+K))."""
+        t, b = self.title, self.body
+        cfg = self.cfg_t
+        B = title.shape[0]
+        C, D, T_ = cfg.C, cfg.D, cfg.T
+        assert title.shape[1:] == (C, 2 * cfg.L) and body.shape == (B, 2 * self.cfg_b.L)
+        t._prepare(B)
+        b._prepare(B)
+        N, Rt = B * C, B * C + B
+        self.cur = (B, N, Rt)
+        t.label = label.to(torch.int64).contiguous()
+        b.tok[:B].copy_(body)
+        t.tok[:N].copy_(title.reshape(N, 2 * cfg.L))
+        S = t.S[:Rt]
+        b.encode(b.tok[:B], B, out=t.S[N:])                      # cell 12 encodes the bodies first
+        t.encode(t.tok[:N], N)
+        # score[b, c] = <title_vec[b, c], body_vec[b]>
+        t._sgemm(S, D, 1, C * D, S[N:], D, 1, D, t.score, 1, C, None, 0, C, 1, D, batch=B)
+        X = t.X
+        for i in range(T_):
+            X[i, :N].copy_(teacher_titles[i].reshape(N, D))
+            X[i, N:Rt].copy_(teacher_bodies[i].reshape(B, D))
+            t._sgemm(X[i], D, 1, C * D, X[i, N:], D, 1, D, t.t_score[i], 1, C, None, 0, C, 1, D, batch=B)
+        T.call("tnr_kd_score_loss", t.score, t.t_score, t.label, 1.0, 1.0, t.tw, t.dscore, t.losses, B, C, T_)
+        Wt = t._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
+        bt = t._view("transform_matrix.0.bias", T_ * D, (T_, D))
+        t._sgemm(X, D, 1, X.stride(0), Wt, D, 1, D * D, t.Pm, D, t.Pm.stride(0), bt, D, Rt, D, D, batch=T_)
+        T.call("tnr_kd_embed_loss", S, t.Pm, t.tw, t.losses[2:], t.dS, t.dP, t.kd_part, B, 0, C, D, T_)
+        return t.losses, t.score[:B]
+
+    def total_loss(self):
+        """target + distill + emb (cell 14) as a device scalar."""
+        l = self.title.losses
+        return l[0] + l[1] + l[2]
+
+    def backward(self, after_bucket=None):
+        """Gradients of total_loss -> the shared flat_g.  Buckets complete (and after_bucket fires) during the body
+        pass, the second and accumulating one."""
+        t, b = self.title, self.body
+        B, N, Rt = self.cur
+        C, D = self.cfg_t.C, self.cfg_t.D
+        S, dS = t.S[:Rt], t.dS
+        t._transform_grads(Rt)
+        T.call("tnr_score_bwd", S, t.cidx, S[N:], t.dscore, dS, dS[N:], B, C, D)
+        t.backward_encoder(dS[:N], N, acc=0)
+        b.backward_encoder(dS[N:Rt], B, acc=1, after_bucket=after_bucket)
+
+    def bucket_ranges(self):
+        return self.title.bucket_ranges()
+
+    def step(self, lr, grad_scale=1.0, **kw):
+        self.title.step(lr, grad_scale, **kw)
