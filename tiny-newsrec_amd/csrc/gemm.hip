@@ -763,6 +763,87 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
 }
 
 // ================================================================================================
+// v6: the v3 tile fed by a DEEPER, FINER ring: k advances 32 per step, slot = [A 256 rows | B 256 rows] x 64 B
+// = 32 KB, four slots.  While step h is computed, steps h+1..h+3 (96 KB per CU) are in flight, instead of one
+// 64 KB burst that starts only after the barrier (v3): the loads never drain.  Rows are 64 B, so a 16x16x32
+// operand fragment is 1 KB contiguous; chunk c of row r sits at position c ^ f(r), f(r) = (-(r >> 2)) & 3, which makes
+// every ds_read_b128 lane group cover all 64 banks once.
+constexpr int SLOT6 = 32 * 1024;
+__device__ __forceinline__ int swz6(int row) { return (0 - (row >> 2)) & 3; }
+
+template <int PROBE>
+__global__ __launch_bounds__(512, 2) void gemm_nt256x256_k32_kernel(NTArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MI = 8;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int nbn = g.N >> 8;
+    const int nbm = (g.M + 255) / 256;
+    const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+    int bm, bn;
+    tile_coords(wg, nbm, nbn, g.gm, bm, bn);
+
+    const bf16* src[4];
+    int dst[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int p = w * 4 + q, sub = p >> 4, pp = p & 15;          // piece = 16 rows x 64 B
+        int row = pp * 16 + (lane >> 2);
+        int chunk = (lane & 3) ^ swz6(row);
+        if (sub == 0) {
+            int gm = bm * 256 + row;
+            gm = gm < g.M ? gm : g.M - 1;
+            src[q] = g.A + (int64_t)gm * g.lda + chunk * 8;
+        } else {
+            src[q] = g.B + (int64_t)(bn * 256 + row) * g.ldb + chunk * 8;
+        }
+        dst[q] = sub * (SLOT6 / 2) + pp * 1024;
+    }
+    auto stage = [&](int slot, int h) {
+        char* base = smem + slot * SLOT6;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(src[q] + h * 32, base + dst[q]);
+    };
+    const int foff = (lane & 15) * 64 + (((lane >> 4) ^ swz6(lane & 15)) << 4);
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x2* lut = (f32x2*)(smem + EPI_BYTES);
+    if (g.flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (g.flags & TNR_EPI_MULDGELU) != 0);
+    const int nh = g.K >> 5;                                   // >= 2 (K % 64 == 0)
+    stage(0, 0);
+    stage(1, 1);
+    if (nh > 2) stage(2, 2);
+    for (int h = 0; h < nh; ++h) {
+        const int left = nh - 1 - h;                            // steps already issued beyond h: min(left, 2)
+        if (left >= 2) TNR_WAIT_VMCNT(8);
+        else if (left == 1) TNR_WAIT_VMCNT(4);
+        else TNR_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();                           // step h landed everywhere; step h-1 fully consumed
+        if (h + 3 < nh) stage((h + 3) & 3, h + 3);
+        if (PROBE == 0) {
+            const char* sa = smem + (h & 3) * SLOT6 + wm * (128 * 64);
+            const char* sb = smem + (h & 3) * SLOT6 + SLOT6 / 2 + wn * (64 * 64);
+            bf16x8 af[MI], bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 1024 + foff);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 1024 + foff);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    nt_epilogue_coalesced<MI>(g, acc, smem, lut, bm, bn, wm, wn, lane);
+}
+
+// ================================================================================================
 // v4: the v3 tile as a PERSISTENT kernel: one workgroup per CU walks its XCD's run of tiles; the first two
 // K stages of the next tile are issued before the current tile's epilogue, so the epilogue's VALU work and
 // stores run under the next tile's loads instead of leaving the (binding) L2->LDS pipe idle, and no tile but
@@ -1255,6 +1336,8 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_k32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_k32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_v5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3 + LUT_N * 8);
         attr_set = true;
@@ -1267,6 +1350,10 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         int nwg = (int)(((M + 255) / 256) * (N / 128));
         if (probe) hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), RING2, st, g);
         else hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), RING2, st, g);
+    } else if (ver == 6) {
+        const int64_t t256 = ((M + 255) / 256) * (N / 256);
+        if (probe) hipLaunchKernelGGL(gemm_nt256x256_k32_kernel<1>, dim3((int)t256), dim3(512), LDS3_BYTES, st, g);
+        else hipLaunchKernelGGL(gemm_nt256x256_k32_kernel<0>, dim3((int)t256), dim3(512), LDS3_BYTES, st, g);
     } else if (ver == 5 && !probe) {
         // persistent kernel unless the 224-row tiling of the non-persistent one is the better deal for this shape
         static const char* bm_s = getenv("TNR_GEMM_BM");

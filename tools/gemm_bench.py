@@ -11,14 +11,15 @@ reps = 10
 
 
 def bench_nt(N, K, flags, name):
-    a = (torch.randn((M, K), device=dev) * 0.5).to(torch.bfloat16)
-    b = (torch.randn((N, K), device=dev) * 0.05).to(torch.bfloat16)
+    pa, pb = int(os.environ.get("PAD_A", 0)), int(os.environ.get("PAD_B", 0))     # leading-dimension padding (elements)
+    a = (torch.randn((M, K + pa), device=dev) * 0.5).to(torch.bfloat16)
+    b = (torch.randn((N, K + pb), device=dev) * 0.05).to(torch.bfloat16)
     c = torch.zeros((M, N), device=dev, dtype=torch.float32 if flags & T.EPI_OUTF32 else torch.bfloat16)
     bias = torch.randn(N, device=dev)
     res = torch.randn((M, N), device=dev).to(torch.bfloat16) if flags & T.EPI_RES else None
     aux = torch.randn((M, N), device=dev).to(torch.bfloat16) if flags & (T.EPI_AUXOUT | T.EPI_MULDGELU) else None
     def run():
-        T.call("tnr_gemm_nt", a, K, b, K, c, N, M, N, K, bias, res, N if res is not None else 0, aux, N if aux is not None else 0, flags)
+        T.call("tnr_gemm_nt", a, K + pa, b, K + pb, c, N, M, N, K, bias, res, N if res is not None else 0, aux, N if aux is not None else 0, flags)
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
