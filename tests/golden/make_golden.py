@@ -9,6 +9,7 @@ reference text are committed.
 import os
 import random
 import sys
+import types
 
 import numpy as np
 import torch
@@ -16,6 +17,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
 import hashinit  # noqa: E402
 import ref_shim  # noqa: E402
@@ -213,6 +215,7 @@ def main():
     golden_interface()
     R = ref_shim.load_reference()
     golden_stage1(R)
+    golden_convert(R)
     golden_relpos(R)
     golden_datapath(R)
     golden_amsgrad()
@@ -308,6 +311,41 @@ def golden_stage1(R):
         rec["grad_names"] = np.array(gn)
         np.savez_compressed(os.path.join(HERE, "stage1_%s.npz" % name), **rec)
         print("stage1", name, rec["total"], rec["target"], rec["distill"], rec["emb"])
+
+
+from helpers import unilm_checkpoint as _unilm_checkpoint  # noqa: E402
+
+
+def golden_convert(R):
+    """tnlrv3/convert_state_dict.py:load_model and the position-embedding resize of tnlrv3/modeling.py:90-118, run
+    from the reference: converted key set + tensors of a small unilm2-layout checkpoint (inputs are regenerated from
+    the hash seed by the test), and the resized tables for grow / grow+reuse / shrink."""
+    C = R.convert_state_dict
+    dims = dict(seed=77, H=16, n_layers=3, A=2, I=32, vocab=40, max_pos=6)
+    out = {"dims": np.array([dims[k] for k in ("seed", "H", "n_layers", "A", "I", "vocab", "max_pos")])}
+    conv = C.load_model(_unilm_checkpoint(**dims))
+    out["keys"] = np.array(sorted(conv))
+    for k, v in conv.items():
+        out["v." + k] = v.numpy()
+    import transformers.models.bert.modeling_bert as mb
+    keep = mb.BertPreTrainedModel.__dict__.get("from_pretrained")
+    mb.BertPreTrainedModel.from_pretrained = classmethod(lambda cls, *a, **k: k)      # capture what would be loaded
+    try:
+        for tag, new, reuse in (("grow", 16, None), ("grow_reuse", 16, True), ("shrink", 4, None), ("same", 6, None)):
+            cfg = types.SimpleNamespace(max_position_embeddings=new, initializer_range=0.02)
+            sd = C.load_model(_unilm_checkpoint(**dims))
+            torch.manual_seed(3)
+            k = R.modeling.TuringNLRv3PreTrainedModel.from_pretrained.__func__(
+                R.modeling.TuringNLRv3ForSequenceClassification, "unused", reuse_position_embedding=reuse, config=cfg,
+                state_dict=sd)
+            out["pos." + tag] = k["state_dict"]["bert.embeddings.position_embeddings.weight"].numpy()
+    finally:
+        if keep is None:
+            del mb.BertPreTrainedModel.from_pretrained
+        else:
+            mb.BertPreTrainedModel.from_pretrained = keep
+    np.savez_compressed(os.path.join(HERE, "convert.npz"), **out)
+    print("convert.npz:", len(conv), "keys")
 
 
 def golden_interface():

@@ -40,13 +40,21 @@ def load_reference(tree="Tiny-NewsRec"):
     for m in ("utils", "model_bert", "model_bert_2", "preprocess", "dataloader", "streaming",
               "parameters", "tnlrv3", "tnlrv3.modeling"):
         sys.modules.pop(m, None)
+    # the build's own tree mirrors the reference's module names (incl. a regular package `tnlrv3`, which would win
+    # over the reference's namespace package wherever it sits on sys.path): take it off the path while importing
+    hidden = [p for p in sys.path if os.path.basename(os.path.normpath(p)) == "tiny-newsrec_amd"]
+    saved_path = list(sys.path)
+    sys.path[:] = [p for p in sys.path if p not in hidden]
+    for m in [m for m in sys.modules if m == "tnlrv3" or m.startswith("tnlrv3.")]:
+        sys.modules.pop(m)
     sys.path.insert(0, path)
     try:
         import utils, model_bert, preprocess, dataloader, streaming  # noqa: E401
         from tnlrv3 import modeling as M
         from tnlrv3.tokenization_tnlrv3 import TuringNLRv3Tokenizer as T
+        from tnlrv3 import convert_state_dict as CSD
     finally:
-        sys.path.remove(path)
+        sys.path[:] = saved_path
     M.TuringNLRv3PreTrainedModel.init_weights = lambda self: self.apply(self._init_weights)
     # no unilm2 .bin offline; .eval() reproduces HF's post-load mode
     M.TuringNLRv3ForSequenceClassification.from_pretrained = classmethod(
@@ -58,7 +66,7 @@ def load_reference(tree="Tiny-NewsRec"):
             padding="max_length" if pad_to_max_length else False, truncation=truncation, **kw)
         T._tnr_patched = True
     return types.SimpleNamespace(utils=utils, model_bert=model_bert, preprocess=preprocess,
-                                 dataloader=dataloader, streaming=streaming, modeling=M,
+                                 dataloader=dataloader, streaming=streaming, modeling=M, convert_state_dict=CSD,
                                  tokenizer_cls=T, path=path)
 
 

@@ -87,3 +87,28 @@ def load_stage1_case(name):
     cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]])
     inp = (z["in_title"], z["in_body"], z["in_label"], [z["in_tt%d" % i] for i in range(T)], [z["in_tb%d" % i] for i in range(T)])
     return z, P, cfg, inp
+
+
+def unilm_checkpoint(seed, H, n_layers, A, I, vocab, max_pos):
+    """A checkpoint in the published unilm2 layout (fused qkv_linear, q_bias / v_bias, encoder.rel_pos_bias),
+    values from the shared hash generator."""
+    t = lambda name, shape: __import__('torch').from_numpy(hashinit.hash_normal(seed, name, shape, 0.02))
+    sd = {"bert.embeddings.word_embeddings.weight": t("we", (vocab, H)),
+          "bert.embeddings.position_embeddings.weight": t("pe", (max_pos, H)),
+          "bert.embeddings.token_type_embeddings.weight": t("te", (2, H)),
+          "bert.embeddings.LayerNorm.weight": t("elw", (H,)), "bert.embeddings.LayerNorm.bias": t("elb", (H,)),
+          "bert.encoder.rel_pos_bias.weight": t("rp", (A, 32)),
+          "bert.pooler.dense.weight": t("pw", (H, H)), "bert.pooler.dense.bias": t("pb", (H,)),
+          "cls.predictions.bias": t("cls", (vocab,))}
+    for l in range(n_layers):
+        p = "bert.encoder.layer.%d." % l
+        sd[p + "attention.self.qkv_linear.weight"] = t(p + "qkv", (3 * H, H))
+        sd[p + "attention.self.q_bias"] = t(p + "qb", (1, 1, H))
+        sd[p + "attention.self.v_bias"] = t(p + "vb", (1, 1, H))
+        for n, shp in (("attention.output.dense.weight", (H, H)), ("attention.output.dense.bias", (H,)),
+                       ("attention.output.LayerNorm.weight", (H,)), ("attention.output.LayerNorm.bias", (H,)),
+                       ("intermediate.dense.weight", (I, H)), ("intermediate.dense.bias", (I,)),
+                       ("output.dense.weight", (H, I)), ("output.dense.bias", (H,)),
+                       ("output.LayerNorm.weight", (H,)), ("output.LayerNorm.bias", (H,))):
+            sd[p + n] = t(p + n, shp)
+    return sd

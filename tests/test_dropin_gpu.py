@@ -85,3 +85,57 @@ def test_bench_dp_path_under_torchrun_single_rank():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
+
+
+def test_construction_time_init_and_pretrained_import(tmp_path):
+    """Model(args) starts from the reference's construction-time distributions, and --model_name pointing at a
+    unilm2-layout checkpoint fills the student's encoder like from_pretrained does (model_bert.py:109-114,
+    tnlrv3/convert_state_dict.py, tnlrv3/modeling.py:90-118): first num_student_layers layers, fused qkv split,
+    position table fitted.  The imported encoder is then checked end to end against the oracle."""
+    import model_bert
+    from helpers import unilm_checkpoint
+    from oracle import newsrec_oracle as O
+    from tnlrv3 import convert_state_dict as C
+    H, A, I, vocab, L, D = 768, 12, 3072, 600, 30, 64
+    cfgp = tmp_path / "config.json"
+    cfgp.write_text(json.dumps(dict(hidden_size=H, num_attention_heads=A, intermediate_size=I, vocab_size=vocab,
+                                    max_position_embeddings=48, type_vocab_size=2, layer_norm_eps=1e-12)))
+    raw = unilm_checkpoint(5, H, 3, A, I, vocab, 32)          # 3 layers and 32 positions in the checkpoint
+    ck = tmp_path / "unilm2-tiny.bin"
+    torch.save(raw, ck)
+    args = types.SimpleNamespace(
+        config_name=str(cfgp), model_name=str(ck), pooling="att", model="NAML", num_teacher_layers=12, num_student_layers=2,
+        bert_trainable_layer=[1], news_dim=D, news_query_vector_dim=200, user_query_vector_dim=200, num_teachers=1,
+        user_log_length=4, npratio=1, num_words_title=L, user_log_mask=False, temperature=1.0, coef=0.2, batch_size=2)
+    torch.cuda.set_device(0)
+    model = model_bert.Model(args)
+    missing, unexpected = model.pretrained_report
+    assert sorted(missing) == ["student.news_encoder.bert_model.classifier.bias", "student.news_encoder.bert_model.classifier.weight"]
+    assert "cls.predictions.bias" in unexpected and any(k.startswith("bert.encoder.layer.2.") for k in unexpected)
+    sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+    pfx = "student.news_encoder.bert_model."
+    conv = C.load_model(dict(raw))
+    for k in ("bert.encoder.layer.1.attention.self.key.weight", "bert.encoder.layer.0.attention.self.value.bias",
+              "bert.rel_pos_bias.weight", "bert.embeddings.word_embeddings.weight", "bert.pooler.dense.weight"):
+        assert np.array_equal(sd[pfx + k], conv[k].numpy()), k
+    assert not sd[pfx + "bert.encoder.layer.0.attention.self.key.bias"].any()
+    pos = sd[pfx + "bert.embeddings.position_embeddings.weight"]
+    assert pos.shape == (48, H) and np.array_equal(pos[:32], raw["bert.embeddings.position_embeddings.weight"].numpy())
+    assert 0.015 < pos[32:].std() < 0.025                                  # new rows ~ N(0, 0.02)
+    # heads: nn.Linear default / pad_doc U(-1,1) / Xavier transform (none is left at zero)
+    w = sd["student.news_encoder.dense.weight"]
+    assert abs(w).max() <= 1 / np.sqrt(H) + 1e-6 and w.std() > 0.5 / np.sqrt(3 * H)
+    assert 0.4 < sd["student.user_encoder.pad_doc"].std() < 0.75
+    b = np.sqrt(6.0 / (2 * D))
+    assert abs(sd["transform_matrix.0.weight"]).max() <= b + 1e-6 and not sd["transform_matrix.0.bias"].any()
+    # encoder forward with the imported weights == oracle on the same weights
+    ids = np.zeros((6, 2 * L), dtype=np.int64)
+    rng = np.random.RandomState(0)
+    for r in range(6):
+        n = 5 + 4 * r
+        ids[r, :n] = rng.randint(1, vocab, n)
+        ids[r, L:L + n] = 1
+    got = model.engine.encode(torch.from_numpy(ids).cuda(), 6).cpu().numpy()
+    ref, _ = O.news_encoder_fwd(sd, ids, 2, A, None)
+    print("imported-encoder max|err| %.3e (|ref| max %.3e)" % (np.abs(got - ref).max(), np.abs(ref).max()))
+    assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max() + 1e-5

@@ -203,3 +203,42 @@ def test_split_file_writes_loader_format(tmp_path):
         assert len(f) == 6 and len(f[4].split()) == 1 and len(f[5].split()) == 4
     assert sorted(l.split("\t")[4] for l in lines) == ["N1", "N3", "N8"]
     assert sorted(streaming.get_stat(str(tmp_path), "behaviors_np4_*.tsv").values()) == [1, 2]
+
+
+def test_pretrained_weight_import_matches_reference():
+    """tnlrv3/convert_state_dict.py:39-71 + the position-table resize of tnlrv3/modeling.py:90-118
+    against tensors captured from the reference's own functions (tests/golden/convert.npz)."""
+    import torch
+    from helpers import unilm_checkpoint
+    from tnlrv3 import convert_state_dict as C
+    z = np.load(os.path.join(GOLDEN, "convert.npz"))
+    seed, H, nl, A, I, vocab, max_pos = [int(x) for x in z["dims"]]
+    raw = unilm_checkpoint(seed, H, nl, A, I, vocab, max_pos)
+    conv = C.load_model(dict(raw))
+    assert sorted(conv) == [str(k) for k in z["keys"]]
+    for k, v in conv.items():
+        ref = z["v." + k]
+        assert tuple(v.shape) == ref.shape and np.array_equal(v.numpy(), ref), k
+    assert C.state_dict_convert["tnlrv3"] is C.load_model
+    pos = conv[C.POS_KEY]
+    g = C.resize_position_embeddings(pos, 16, 0.02, None)
+    ref = z["pos.grow"]
+    assert np.array_equal(g[:max_pos].numpy(), ref[:max_pos])                     # old rows kept
+    assert not np.array_equal(g[max_pos:].numpy(), np.zeros_like(ref[max_pos:]))  # new rows drawn N(0, 0.02)
+    assert abs(float(g[max_pos:].std()) - 0.02) < 0.006 and abs(float(ref[max_pos:].std()) - 0.02) < 0.006
+    assert np.array_equal(C.resize_position_embeddings(pos, 16, 0.02, True).numpy(), z["pos.grow_reuse"])   # tiled: exact
+    assert np.array_equal(C.resize_position_embeddings(pos, 4, 0.02, None).numpy(), z["pos.shrink"])
+    assert np.array_equal(C.resize_position_embeddings(pos, max_pos, 0.02, None).numpy(), z["pos.same"])
+
+    # what from_pretrained leaves in a 2-layer student: converted keys under the module prefix, extra layer dropped
+    wanted = {"student.news_encoder.bert_model." + k: tuple(v.shape) for k, v in conv.items()
+              if not k.startswith("bert.encoder.layer.2.") and not k.startswith("cls.")}
+    wanted["student.news_encoder.bert_model.bert.embeddings.position_embeddings.weight"] = (12, H)
+    wanted["student.news_encoder.bert_model.classifier.weight"] = (2, H)
+    state, missing, unexpected = C.student_state_from_pretrained(raw, wanted, 2, 12, reuse_position_embedding=True)
+    assert missing == ["student.news_encoder.bert_model.classifier.weight"]
+    assert "cls.predictions.bias" in unexpected and any(k.startswith("bert.encoder.layer.2.") for k in unexpected)
+    assert set(state) == set(wanted) - set(missing)
+    assert state["student.news_encoder.bert_model.bert.embeddings.position_embeddings.weight"].shape == (12, H)
+    with pytest.raises(ValueError):
+        C.student_state_from_pretrained(raw, dict(wanted, **{"student.news_encoder.bert_model.bert.pooler.dense.bias": (H + 1,)}), 2, 12)
