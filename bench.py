@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--teachers", type=int, default=4)
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit activation type (same MFMA rate)")
     ap.add_argument("--force-dp", action="store_true", help="run the RCCL broadcast / bucketed all-reduce path even at world size 1")
+    ap.add_argument("--dedup", choices=["off", "also", "only"], default="also",
+                    help="in-batch news de-duplication (dedup.py): 'also' times it in a second loop and reports it beside "
+                         "the headline (which stays un-deduplicated), 'only' makes it the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -119,9 +122,20 @@ def main():
                                synth.impressions(seed + 1 + rank, (K + W) * B, N_NEWS, cfg.U, cfg.C)]
     gs = D.GradSync(eng.flat_g, eng.bucket_ranges(), world, force=a.force_dp)
 
+    plans = None
+    if a.dedup != "off":
+        from dedup import build_plan
+        hn, cn = hidx.cpu().numpy(), cidx.cpu().numpy()
+        plans = [build_plan(hn[i * B:(i + 1) * B], cn[i * B:(i + 1) * B]) for i in range(K + W)]
+        distinct = float(np.mean([p.n_unique / p.n_slots if p is not None else 1.0 for p in plans]))
+        encoded = float(np.mean([p.n_enc / p.n_slots if p is not None else 1.0 for p in plans]))
+        plans = [p.to(dev) if p is not None else None for p in plans]
+    use_plan = [a.dedup == "only"]
+
     def one_step(i):
         s = slice(i * B, (i + 1) * B)
-        eng.forward_indexed(comb, hidx[s], mask[s], cidx[s], label[s], tables if a.teachers else None)
+        eng.forward_indexed(comb, hidx[s], mask[s], cidx[s], label[s], tables if a.teachers else None,
+                            plans[i] if use_plan[0] else None)
         eng.backward(after_bucket=gs.launch if (world > 1 or a.force_dp) else None)
         gs.wait()
         eng.step(lr=1e-4, grad_scale=gs.scale)
@@ -142,6 +156,21 @@ def main():
     dt = float(D.all_reduce_max(dt).item())
     loss = float(eng.total_loss().item())
     rec = T.TIMED.pop("tnr_gemm_nt_ex_f16", None) or T.TIMED.pop("tnr_gemm_nt_ex", None)
+    dt_dedup = None
+    if a.dedup == "also":
+        # second loop, same batches and weights path, each distinct news of a batch encoded once
+        use_plan[0] = True
+        for i in range(W):
+            one_step(i)
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(W, W + K):
+            one_step(i)
+        torch.cuda.synchronize()
+        D.barrier()
+        dt_dedup = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dt_dedup = float(D.all_reduce_max(dt_dedup).item())
 
     if rank == 0:
         value = world * B * K / dt
@@ -174,6 +203,12 @@ def main():
                                "algorithmic_flops_per_launch": fl / len(rec)}
         else:
             out["roofline"] = None
+        if a.dedup != "off":
+            out["dedup"] = {"in_headline": a.dedup == "only", "distinct_news_frac": round(distinct, 4),
+                            "encoded_frac": round(encoded, 4),
+                            "note": "identical outputs; FLOPs per impression above stay un-deduplicated (SURVEY 8-d)"}
+            if dt_dedup is not None:
+                out["dedup"].update(value=round(world * B * K / dt_dedup, 2), ms_per_step=round(1e3 * dt_dedup / K, 4))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_kw, seed)
         print(json.dumps(out), flush=True)

@@ -156,6 +156,14 @@ int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA, const int3
 int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, int64_t n_idx, int D, int n_model,
                     float* out, int64_t out_rows, int64_t out_row0, void* stream);
 
+/* In-batch de-duplication of news (SURVEY.md appendix iii: identical input rows encode to the same vector): the
+ * encoder runs once per distinct news id of the step, tnr_gather_rows expands the vectors to the (B*U + B*C) slots
+ * (dataloader.py:131,138 at index level) and this entry point folds the slot gradients back:
+ *   out[u,:] = sum_{j in [seg[u], seg[u+1])} src[order[j],:]      (fixed order, no atomics)
+ * order (n_slots) = slot ids grouped by distinct id, seg (n_seg+1) offsets; empty segments give zero rows. */
+int tnr_segment_sum_rows(const float* src, const int32_t* order, const int32_t* seg, int64_t n_seg, int D,
+                         float* out, void* stream);
+
 /* UserEncoder.forward (model_bert.py:155-176, model != NRMS) + scorer bmm (:204 / :286-287) for
  * `n_model` encoders at once (student and/or frozen teachers), one workgroup per (impression, model).
  * vec: (n_model, R, D) fp32 row tables ; hidx (B,U) / cidx (B,C) int32 row ids ; mask (B,U) fp32.

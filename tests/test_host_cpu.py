@@ -242,3 +242,25 @@ def test_pretrained_weight_import_matches_reference():
     assert state["student.news_encoder.bert_model.bert.embeddings.position_embeddings.weight"].shape == (12, H)
     with pytest.raises(ValueError):
         C.student_state_from_pretrained(raw, dict(wanted, **{"student.news_encoder.bert_model.bert.pooler.dense.bias": (H + 1,)}), 2, 12)
+
+
+def test_dedup_plan_is_a_bijection_onto_distinct_news():
+    """dedup.build_plan: integer-exact grouping of the B*(U+C) news slots of a batch by distinct news id."""
+    import synth
+    from dedup import build_plan
+    h, m, c, y = synth.impressions(9, 8, 300, 50, 5)
+    p = build_plan(h, c, quantum=64)
+    slots = np.concatenate([h.ravel(), c.ravel()])
+    assert p.n_slots == slots.size and p.n_unique == np.unique(slots).size and p.n_enc % 64 == 0 and p.n_enc >= p.n_unique
+    assert np.array_equal(p.uniq[p.inv], slots)                              # expansion reproduces every slot
+    assert (p.uniq[p.n_unique:] == 0).all()                                  # padding rows are the pad news
+    assert np.array_equal(np.sort(p.order), np.arange(slots.size))           # every slot in exactly one group
+    for u in range(p.n_enc):
+        grp = p.order[p.seg[u]:p.seg[u + 1]]
+        assert (p.inv[grp] == u).all() and (np.diff(grp) > 0).all()          # stable: fixed summation order
+    assert p.seg[p.n_unique] == slots.size and (p.seg[p.n_unique:] == slots.size).all()   # padding rows own no slot
+    # all-distinct batch: nothing to save -> no plan
+    assert build_plan(np.arange(1, 101).reshape(2, 50), np.arange(101, 111).reshape(2, 5)) is None
+    # empty histories (all pad) collapse to one row
+    q = build_plan(np.zeros((2, 50), np.int64), np.array([[1, 2, 3, 4, 5], [1, 2, 3, 4, 6]]))
+    assert q.n_unique == 7 and q.seg[1] == 100

@@ -195,6 +195,45 @@ __global__ void gather_rows_kernel(const float* __restrict__ tbl, int64_t R, con
         *(const f32x4*)(tbl + ((int64_t)z * R + idx[r]) * D + c);
 }
 
+
+// out[u, :] = sum over j in [seg[u], seg[u+1]) of src[order[j], :], summed in a fixed order (in-batch de-duplication:
+// the gradient of a news vector that several history / candidate slots share).  One 1024-thread workgroup per output row:
+// wave w takes entries w, w+16, ... with four independent accumulators, the 16 partial rows are added in wave order.
+__global__ __launch_bounds__(1024) void segment_sum_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ order,
+                                                                const int32_t* __restrict__ seg, int D, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [16][D]
+    const int u = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j0 = seg[u], j1 = seg[u + 1];
+    if (j1 - j0 <= 4) {                                              // common case: no exchange needed
+        if (w == 0)
+            for (int c = lane * 4; c < D; c += 256) {
+                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = j0; j < j1; ++j) a += *(const f32x4*)(src + (int64_t)order[j] * D + c);
+                *(f32x4*)(out + (int64_t)u * D + c) = a;
+            }
+        return;
+    }
+    for (int c = lane * 4; c < D; c += 256) {
+        f32x4 a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int j = j0 + w;
+        for (; j + 48 < j1; j += 64) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] += *(const f32x4*)(src + (int64_t)order[j + 16 * q] * D + c);
+        }
+        for (int q = 0; j < j1; j += 16, ++q) a[q & 3] += *(const f32x4*)(src + (int64_t)order[j] * D + c);
+        *(f32x4*)(sm + w * D + c) = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 1024) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sm[q * D + c];
+        out[(int64_t)u * D + c] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // UserEncoder (model_bert.py:155-176) + scorer (:204).  One workgroup per (impression, model).
 constexpr int MAXU = 64;
@@ -584,6 +623,16 @@ extern "C" int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, 
     hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, tbl, R, idx, n_idx, D, out, out_rows,
                        out_row0);
     TNR_CHECK_LAUNCH("tnr_gather_rows");
+    return TNR_OK;
+}
+
+extern "C" int tnr_segment_sum_rows(const float* src, const int32_t* order, const int32_t* seg, int64_t n_seg, int D,
+                                    float* out, void* stream) {
+    TNR_CHECK_ARG(src && order && seg && out && n_seg >= 1 && D >= 4 && (D % 4) == 0 && D <= 2048,
+                  "tnr_segment_sum_rows: bad argument");
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((unsigned)n_seg), dim3(1024), 16 * D * sizeof(float),
+                       (hipStream_t)stream, src, order, seg, D, out);
+    TNR_CHECK_LAUNCH("tnr_segment_sum_rows");
     return TNR_OK;
 }
 

@@ -23,7 +23,7 @@ _END = object()
 
 
 class IndexBatch(tuple):
-    """(hist_idx, log_mask, cand_idx, label) in resident mode."""
+    """(hist_idx, log_mask, cand_idx, label[, dedup plan or None]) in resident mode."""
 
 
 class DataLoaderTrain:
@@ -38,6 +38,7 @@ class DataLoaderTrain:
         self.num_teachers = args.num_teachers
         self.teacher_embs, self.news_combined, self.news_index = teacher_embs, news_combined, news_index
         self.resident = enable_gpu if resident is None else resident
+        self.dedup = bool(getattr(args, "dedup_news", False))
         self.epoch = -1
         self.sampler = None
         self.dev_tables = None
@@ -78,8 +79,13 @@ class DataLoaderTrain:
         h, m, c, y = self.decode(batch)
         if self.resident and self.enable_gpu:
             dev = self.dev_news.device
+            plan = None
+            if self.dedup:
+                from dedup import build_plan
+                plan = build_plan(h, c)
+                plan = plan.to(dev) if plan is not None else None
             return IndexBatch((torch.from_numpy(h.astype(np.int32)).to(dev, non_blocking=True), torch.from_numpy(m).to(dev),
-                               torch.from_numpy(c.astype(np.int32)).to(dev), torch.from_numpy(y).to(dev)))
+                               torch.from_numpy(c.astype(np.int32)).to(dev), torch.from_numpy(y).to(dev), plan))
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
         out = [t(self.news_combined[h].astype(np.int64)), t(m), t(self.news_combined[c].astype(np.int64)), t(y),
                [t(np.asarray(te)[h].astype(np.float32)) for te in self.teacher_embs[:self.num_teachers]],

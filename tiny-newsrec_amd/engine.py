@@ -375,6 +375,8 @@ class Engine:
         self.Rt = Rt
         self.S = f(Rt, D)                 # student rows: [B*U history | B*C candidate | B user]
         self.dS = f(Rt, D)
+        self.Sv, self.dSv = f(N, D), f(N, D)      # vectors / gradients per DISTINCT news of the step (dedup.py)
+        self.plan = None
         T_ = max(cfg.T, 1)
         self.X = f(T_, Rt, D)             # teacher rows, same layout
         self.Pm = f(T_, Rt, D)
@@ -533,15 +535,15 @@ class Engine:
         if B != self.B_alloc:
             self._alloc_workspace(B)
 
-    def forward_indexed(self, news_combined, hist_idx, history_mask, cand_idx, label, teacher_tables):
+    def forward_indexed(self, news_combined, hist_idx, history_mask, cand_idx, label, teacher_tables, plan=None):
         """The same step fed the way the resident-table loader feeds it: news_combined (n+1, 2L) int32 and
         teacher_tables (T, n+1, D) fp32 stay in HBM; per step only hist_idx (B,U), cand_idx (B,C) int32 news
         indices, the mask and the labels arrive (dataloader.py:129-149 at index level)."""
         return self.forward(None, history_mask, None, label, teacher_tables=teacher_tables, t_hidx=hist_idx,
-                            t_cidx=cand_idx, news_combined=news_combined)
+                            t_cidx=cand_idx, news_combined=news_combined, plan=plan)
 
     def forward(self, history, history_mask, candidate, label, teacher_hist=None, teacher_cand=None,
-                teacher_tables=None, t_hidx=None, t_cidx=None, news_combined=None):
+                teacher_tables=None, t_hidx=None, t_cidx=None, news_combined=None, plan=None):
         """Model.forward model_bert.py:262-305.  Teacher embeddings either as the reference's lists of
         (B,U,D)/(B,C,D) tensors, or as resident tables (T,R,D) + int32 row ids (B,U)/(B,C).
         Returns the device tensor [distill, target, emb, -] and student_score (B,C)."""
@@ -556,9 +558,17 @@ class Engine:
         self.label = label.to(torch.int64).contiguous()
         if news_combined is not None:
             self.nidx = torch.cat([t_hidx.reshape(-1), t_cidx.reshape(-1)]).to(torch.int32)
-            self.encode(news_combined, N, nidx=self.nidx)
+            self.plan = plan
+            if plan is None:
+                self.encode(news_combined, N, nidx=self.nidx)
+            else:
+                # encode each distinct news once, expand to the slots (dedup.py); everything downstream is unchanged
+                assert plan.n_slots == N and plan.n_enc <= self.N_alloc
+                self.encode(news_combined, plan.n_enc, nidx=plan.uniq, out=self.Sv)
+                T.call("tnr_gather_rows", self.Sv, plan.n_enc, plan.inv, N, D, 1, self.S, self.S.shape[0], 0)
         else:
             assert history.shape[1:] == (U, 2 * L) and candidate.shape[1:] == (C, 2 * L)
+            self.plan = None
             tok = self.tok[:N]
             tok[:B * U].copy_(history.reshape(B * U, 2 * L))
             tok[B * U:].copy_(candidate.reshape(B * C, 2 * L))
@@ -633,9 +643,14 @@ class Engine:
                g(ue + "attn.att_fc2.weight"), int(cfg.user_log_mask), dS[N:], self.e_u, self.alpha_u, self.den_u, dS,
                self.user_part, B, U, D, cfg.Qu)
         ps = self.user_part.shape[1]
-        rb = self.red.setdefault(("heads", 0), _ReduceBatch(self.dev))
+        rb = self.red.setdefault(("heads", 0, N if self.plan is None else self.plan.n_enc), _ReduceBatch(self.dev))
         rb.add(self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.weight", ps, (ps,), grad=True))
-        self.backward_encoder(dS[:N], N, after_bucket=after_bucket)
+        if self.plan is None:
+            self.backward_encoder(dS[:N], N, after_bucket=after_bucket)
+        else:
+            p = self.plan
+            T.call("tnr_segment_sum_rows", dS, p.order, p.seg, p.n_enc, D, self.dSv)
+            self.backward_encoder(self.dSv, p.n_enc, after_bucket=after_bucket)
 
     def _transform_grads(self, Rt):
         """dW_i = dP_i^T X_i ; db_i = colsum(dP_i)   (transform_matrix, model_bert.py:278,283)"""
@@ -653,7 +668,7 @@ class Engine:
         L, D, H, I = cfg.L, cfg.D, cfg.H, cfg.I
         M = N * L
         g, gr = self.p, self.grads
-        rb = self.red.setdefault(("heads", acc), _ReduceBatch(self.dev))
+        rb = self.red.setdefault(("heads", acc, N), _ReduceBatch(self.dev))
         # dense + pooling of the news encoder
         wd = g(PFX + "dense.weight")
         self._sgemm(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N, ksplit=self.KS,
@@ -681,7 +696,7 @@ class Engine:
             x_in = self.x_in[l]
             # bias gradients ride along: dx column sums from LayerNorm backward, the dgrad epilogue, attention backward;
             # all partial sums of the layer are reduced by one launch at the end (fixed order)
-            rb = self.red.setdefault((l, acc), _ReduceBatch(self.dev)) if tr else None
+            rb = self.red.setdefault((l, acc, N), _ReduceBatch(self.dev)) if tr else None
             nblk = (M + 127) // 128
             self._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None,
                     self.ln_part if tr else None, M, H)
@@ -692,7 +707,7 @@ class Engine:
             self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if tr else 0),
                        colsum=self.gcs_part if tr else None)
             if tr:
-                rb.add(self.gcs_part, self.gcs_part.shape[0], I, I, gr[names[11]], acc)
+                rb.add(self.gcs_part, self._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], acc)
                 self._wgrad(self.du, a["h1"], gr[names[10]], M, acc)
             self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
             self._c("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, None, None, None,

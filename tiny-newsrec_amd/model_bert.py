@@ -162,8 +162,9 @@ class Model(_Shell):
                                     list(teacher_candidate_embs))
         return self._pack(losses, score)
 
-    def forward_indexed(self, news_combined, hist_idx, history_mask, cand_idx, label, teacher_tables):
-        losses, score = self.engine.forward_indexed(news_combined, hist_idx, history_mask, cand_idx, label, teacher_tables)
+    def forward_indexed(self, news_combined, hist_idx, history_mask, cand_idx, label, teacher_tables, plan=None):
+        losses, score = self.engine.forward_indexed(news_combined, hist_idx, history_mask, cand_idx, label, teacher_tables,
+                                                    plan)
         return self._pack(losses, score)
 
     def _pack(self, losses, score):

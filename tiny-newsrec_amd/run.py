@@ -74,8 +74,14 @@ def train(args):
         B = args.batch_size
         dev_news = torch.from_numpy(news_combined).cuda()
         dev_tab = torch.from_numpy(np.stack(teacher_embs, 0)).cuda() if teacher_embs else None
+        plans = [None] * steps
+        if args.dedup_news:
+            from dedup import build_plan
+            hn, cn = hidx.cpu().numpy(), cidx.cpu().numpy()
+            plans = [build_plan(hn[i * B:(i + 1) * B], cn[i * B:(i + 1) * B]) for i in range(steps)]
+            plans = [p.to("cuda") if p is not None else None for p in plans]
         batches = lambda: (IndexBatch((hidx[i * B:(i + 1) * B], mask[i * B:(i + 1) * B], cidx[i * B:(i + 1) * B],
-                                       label[i * B:(i + 1) * B])) for i in range(steps))
+                                       label[i * B:(i + 1) * B], plans[i])) for i in range(steps))
     else:
         stat = get_stat(args.train_data_dir, args.filename_pat)
         paths = get_worker_files(args.train_data_dir, rank, size, args.filename_pat, args.enable_shuffle, 0)
@@ -95,8 +101,8 @@ def train(args):
             if cnt > args.max_steps_per_epoch:
                 break
             if isinstance(batch, IndexBatch):
-                h, m, c, y = batch
-                total, distill, emb, target, y_student = model.forward_indexed(dev_news, h, m, c, y, dev_tab)
+                h, m, c, y, plan = batch
+                total, distill, emb, target, y_student = model.forward_indexed(dev_news, h, m, c, y, dev_tab, plan)
             else:
                 h, m, c, y, th, tc = batch
                 total, distill, emb, target, y_student = model(h, m, c, y, th, tc)

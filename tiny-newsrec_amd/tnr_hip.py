@@ -39,6 +39,7 @@ _SIG = {
     "tnr_attpool_bwd": [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _I, _I, _P],
     "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _I, _P, _P],
     "tnr_gather_rows": [_P, _L, _P, _L, _I, _I, _P, _L, _L, _P],
+    "tnr_segment_sum_rows": [_P, _P, _P, _L, _I, _P, _P],
     "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tnr_user_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tnr_user_bwd_part_stride": [_I, _I],
