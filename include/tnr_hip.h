@@ -98,7 +98,8 @@ int tnr_ln_fwd(const void* x, const float* gamma, const float* beta, float eps, 
  * written and the caller reduces them (tnr_reduce_multi). */
 int tnr_ln_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream);
-int64_t tnr_ln_bwd_part_elems(int64_t M, int H);
+int64_t tnr_ln_bwd_part_elems(int64_t M, int H);   /* workspace good for every row count <= M */
+int64_t tnr_ln_bwd_blocks(int64_t M);              /* partial rows (nblk) written for exactly M rows */
 
 /* BertSelfAttention.multi_head_attention (tnlrv3/modeling.py:205-231) for L <= 32, head size 64:
  * softmax(Q K^T / 8 + mask_add + rel) V, heads merged.  qkv (N*L, 3*A*64) bf16 = [q | k | v];
@@ -174,12 +175,18 @@ int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const i
                        const float* pad, const float* w1, const float* b1, const float* w2, const float* b2,
                        int user_log_mask, const float* epre, float* user, int64_t user_stride, float* score,
                        float* e, float* alpha, float* den, int n_model, int B, int U, int C, int D, int Q, void* stream);
-/* backward of the student's user encoder: duser (B,D) -> dvec rows hidx (+=), and per-impression
- * partial parameter gradients part (B, Q*D + Q + Q + D + 1) laid out [w1|b1|w2|pad|b2]. */
-int tnr_user_bwd(const float* vec, const int32_t* hidx, const float* mask, const float* pad, const float* w1,
-                 const float* w2, int user_log_mask, const float* duser, const float* e, const float* alpha,
-                 const float* den, float* dvec, float* part, int B, int U, int D, int Q, void* stream);
-
+/* backward of the student's user encoder (model_bert.py:155-176), in two kernels around two fp32 GEMMs the caller
+ * issues with tnr_sgemm:
+ *   tnr_user_bwd_pre : hv (B*U, D) = blended history rows in position order ; dpre (B*U, Q) = gradient of the fc1
+ *                      pre-activation ; part (B, 2Q + D + 1) = per-impression partials [b1 | w2 | pad | b2]
+ *   caller           : dW1 (Q,D) = dpre^T hv ;  dhv (B*U, D) = dpre W1
+ *   tnr_user_bwd_post: dvec[hidx[b,u]] += (alpha * duser + dhv) * m ; fills the pad_doc partial of `part`. */
+int tnr_user_bwd_pre(const float* vec, const int32_t* hidx, const float* mask, const float* pad, const float* w2,
+                     int user_log_mask, const float* duser, const float* e, const float* alpha, float* hv,
+                     float* dpre, float* part, int B, int U, int D, int Q, void* stream);
+int tnr_user_bwd_post(const float* dhv, const float* alpha, const float* duser, const float* mask,
+                      const int32_t* hidx, int user_log_mask, float* dvec, float* part, int B, int U, int D, int Q,
+                      void* stream);
 int64_t tnr_user_bwd_part_stride(int D, int Q);
 /* backward of the scorer bmm (model_bert.py:204): dvec[cidx[b,c]] += dscore[b,c]*user[b] ;
  * duser[b] += sum_c dscore[b,c]*vec[cidx[b,c]] */

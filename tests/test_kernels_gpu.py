@@ -352,14 +352,24 @@ def test_user_score_fwd_bwd(ulm):
     dnews, G = O.user_encoder_bwd(P, "p.", duser, c)
     dvec = torch.zeros((R, D), device=DEV)
     ps = T.query("tnr_user_bwd_part_stride", D, Q)
+    assert ps == 2 * Q + D + 1
     part = torch.zeros((B, ps), device=DEV)
-    T.call("tnr_user_bwd", dev(vec[0]), dev(hidx), dev(mask), dv["pad"], dv["w1"], dv["w2"], ulm, dev(duser), e, alpha, den,
-           dvec, part, B, U, D, Q)
+    hv, dhv, dpre = torch.zeros((B * U, D), device=DEV), torch.zeros((B * U, D), device=DEV), torch.zeros((B * U, Q), device=DEV)
+    dw1 = torch.zeros((Q, D), device=DEV)
+    sg_part = torch.zeros(8 * Q * D, device=DEV)
+    w1_0 = dv["w1"][0].contiguous()
+    T.call("tnr_user_bwd_pre", dev(vec[0]), dev(hidx), dev(mask), dv["pad"], dv["w2"], ulm, dev(duser), e, alpha, hv, dpre, part,
+           B, U, D, Q)
+    T.call("tnr_sgemm", dpre, 1, Q, 0, None, hv, 1, D, 0, dw1, D, 0, None, 0, Q, D, B * U, 1, 1.0, 0.0, 8, sg_part)
+    T.call("tnr_sgemm", dpre, Q, 1, 0, None, w1_0, 1, D, 0, dhv, D, 0, None, 0, B * U, D, Q, 1, 1.0, 0.0, 1, None)
+    T.call("tnr_user_bwd_post", dhv, alpha, dev(duser), dev(mask), dev(hidx), ulm, dvec, part, B, U, D, Q)
     torch.cuda.synchronize()
+    hv_ref = vec[0][hidx] if ulm else vec[0][hidx] * mask[..., None] + pr["pad"][0][None, None] * (1.0 - mask[..., None])
+    np.testing.assert_allclose(hv.cpu().numpy().reshape(B, U, D), hv_ref, rtol=1e-6, atol=1e-7)
     want = np.zeros((R, D), np.float32)
     np.add.at(want, hidx.reshape(-1), dnews.reshape(-1, D))
     np.testing.assert_allclose(dvec.cpu().numpy(), want, rtol=1e-3, atol=1e-5)
-    p = part.sum(0).cpu().numpy()
+    p = np.concatenate([dw1.cpu().numpy().reshape(-1), part.sum(0).cpu().numpy()])
     o = 0
     for key, n in (("p.attn.att_fc1.weight", Q * D), ("p.attn.att_fc1.bias", Q), ("p.attn.att_fc2.weight", Q),
                    ("p.pad_doc", D), ("p.attn.att_fc2.bias", 1)):

@@ -288,14 +288,16 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
     load_hv<true>(hv, vec, hidx, mask, pad, user_log_mask, U, D, tid);
     __syncthreads();
     if (any_pad) {
-        for (int q = tid; q < Q; q += 256) {
+        // fc1(pad_doc): one wave per output row, lanes along D (coalesced 1 KB row reads)
+        for (int q = w; q < Q; q += 4) {
             const float* wr = w1 + (int64_t)q * D;
             float s = 0.f;
-            for (int d = 0; d < D; d += 4) {
+            for (int d = lane * 4; d < D; d += 256) {
                 f32x4 wv = *(const f32x4*)(wr + d), pv = *(const f32x4*)(pad + d);
                 s += wv[0] * pv[0] + wv[1] * pv[1] + wv[2] * pv[2] + wv[3] * pv[3];
             }
-            epad[q] = s + b1[q];
+            s = wave_sum(s);
+            if (lane == 0) epad[q] = s + b1[q];
         }
         __syncthreads();
     }
@@ -339,16 +341,21 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
     }
 }
 
-// backward of the student's user encoder; D must be <= 256*DV with DV columns per thread
-__global__ __launch_bounds__(256) void user_bwd_kernel(
+// backward of the student's user encoder, split so that its two contractions (0.33 GFLOP at B=32: the fc1 weight
+// gradient and the gradient w.r.t. the blended history vectors) run on the fp32 MFMA GEMM instead of per-thread FMA
+// chains (the single-kernel version spent 156 us on 32 workgroups):
+//   pre : hv (blended history rows, position order) ; dpre = d tanh-preactivation (B*U, Q) ; per-impression
+//         partials [b1 | w2 | pad | b2] (pad filled by post)
+//   host: dW1 = dpre^T hv (tnr_sgemm, split-K) ; dhv = dpre W1 (tnr_sgemm)
+//   post: dvec[hidx] += (alpha * duser + dhv) * m ; pad partial = sum_u (...) * (1 - m)
+__global__ __launch_bounds__(256) void user_bwd_pre_kernel(
     const float* __restrict__ vec, const int32_t* __restrict__ hidx, const float* __restrict__ mask,
-    const float* __restrict__ pad, const float* __restrict__ w1, const float* __restrict__ w2, int user_log_mask,
-    const float* __restrict__ duser, const float* __restrict__ e, const float* __restrict__ alpha,
-    float* __restrict__ dvec, float* __restrict__ part, int U, int D, int Q) {
+    const float* __restrict__ pad, const float* __restrict__ w2, int user_log_mask, const float* __restrict__ duser,
+    const float* __restrict__ e, const float* __restrict__ alpha, float* __restrict__ hv_out, float* __restrict__ dpre,
+    float* __restrict__ part, int U, int D, int Q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hv = (float*)smem;                 // [U][D]
-    float* dpt = hv + U * D;                  // [Q][MAXU]  (d tanh-preactivation, transposed)
-    float* dw = dpt + Q * MAXU;               // [MAXU]
+    float* dw = hv + U * D;                   // [MAXU]
     float* da = dw + MAXU;                    // [MAXU]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     hidx += (int64_t)b * U;
@@ -356,14 +363,14 @@ __global__ __launch_bounds__(256) void user_bwd_kernel(
     duser += (int64_t)b * D;
     e += (int64_t)b * U * Q;
     alpha += (int64_t)b * U;
-    const int64_t pstride = (int64_t)Q * D + 2 * Q + 1 + D;
-    float* p_w1 = part + b * pstride;
-    float* p_b1 = p_w1 + (int64_t)Q * D;
+    dpre += (int64_t)b * U * Q;
+    hv_out += (int64_t)b * U * D;
+    float* p_b1 = part + (int64_t)b * (2 * Q + D + 1);
     float* p_w2 = p_b1 + Q;
-    float* p_pad = p_w2 + Q;
-    float* p_b2 = p_pad + D;
+    float* p_b2 = p_w2 + Q + D;
     load_hv<false>(hv, vec, hidx, mask, pad, user_log_mask, U, D, tid);
     __syncthreads();
+    for (int t = tid * 4; t < U * D; t += 1024) *(f32x4*)(hv_out + t) = *(const f32x4*)(hv + t);
     for (int u = w; u < U; u += 4) {
         float s = 0.f;
         for (int d = lane; d < D; d += 64) s += duser[d] * hv[u * D + d];
@@ -377,14 +384,11 @@ __global__ __launch_bounds__(256) void user_bwd_kernel(
     __syncthreads();
     for (int q = tid; q < Q; q += 256) {
         float wq = w2[q], sb1 = 0.f, sw2 = 0.f;
-        for (int u = 0; u < MAXU; ++u) {
-            float v = 0.f;
-            if (u < U) {
-                float ev = e[u * Q + q];
-                v = da[u] * wq * (1.f - ev * ev);
-                sw2 += da[u] * ev;
-            }
-            dpt[q * MAXU + u] = v;
+        for (int u = 0; u < U; ++u) {
+            float ev = e[u * Q + q];
+            float v = da[u] * wq * (1.f - ev * ev);
+            sw2 += da[u] * ev;
+            dpre[u * Q + q] = v;
             sb1 += v;
         }
         p_b1[q] = sb1;
@@ -395,37 +399,26 @@ __global__ __launch_bounds__(256) void user_bwd_kernel(
         for (int u = 0; u < U; ++u) s += da[u];
         p_b2[0] = s;
     }
-    __syncthreads();
-    for (int d = tid; d < D; d += 256) {
-        float hcol[MAXU], acc[MAXU];
-#pragma unroll
-        for (int u = 0; u < MAXU; ++u) {
-            hcol[u] = u < U ? hv[u * D + d] : 0.f;
-            acc[u] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void user_bwd_post_kernel(
+    const float* __restrict__ dhv, const float* __restrict__ alpha, const float* __restrict__ duser,
+    const float* __restrict__ mask, const int32_t* __restrict__ hidx, int user_log_mask, float* __restrict__ dvec,
+    float* __restrict__ part, int U, int D, int Q) {
+    const int b = blockIdx.x;
+    hidx += (int64_t)b * U;
+    mask += (int64_t)b * U;
+    alpha += (int64_t)b * U;
+    dhv += (int64_t)b * U * D;
+    float* p_pad = part + (int64_t)b * (2 * Q + D + 1) + 2 * Q;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float du = duser[(int64_t)b * D + d], dp_pad = 0.f;
+        for (int u = 0; u < U; ++u) {
+            float g = alpha[u] * du + dhv[u * D + d];
+            float m = user_log_mask ? 1.f : mask[u];
+            dp_pad += g * (1.f - m);
+            dvec[(int64_t)hidx[u] * D + d] += g * m;
         }
-        for (int q = 0; q < Q; ++q) {
-            float wv = w1[(int64_t)q * D + d];
-            float g = 0.f;
-#pragma unroll
-            for (int u4 = 0; u4 < MAXU; u4 += 4) {
-                f32x4 dp = *(const f32x4*)(dpt + q * MAXU + u4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    g += dp[r] * hcol[u4 + r];
-                    acc[u4 + r] += dp[r] * wv;
-                }
-            }
-            p_w1[(int64_t)q * D + d] = g;
-        }
-        float du = duser[d], dp_pad = 0.f;
-#pragma unroll
-        for (int u = 0; u < MAXU; ++u)
-            if (u < U) {
-                float g = alpha[u] * du + acc[u];
-                float m = user_log_mask ? 1.f : mask[u];
-                dp_pad += g * (1.f - m);
-                dvec[(int64_t)hidx[u] * D + d] += g * m;
-            }
         p_pad[d] = dp_pad;
     }
 }
@@ -663,24 +656,34 @@ extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hi
     return TNR_OK;
 }
 
-extern "C" int64_t tnr_user_bwd_part_stride(int D, int Q) { return (int64_t)Q * D + 2 * Q + 1 + D; }
+extern "C" int64_t tnr_user_bwd_part_stride(int D, int Q) { return 2 * (int64_t)Q + D + 1; }
 
-extern "C" int tnr_user_bwd(const float* vec, const int32_t* hidx, const float* mask, const float* pad, const float* w1,
-                            const float* w2, int user_log_mask, const float* duser, const float* e, const float* alpha,
-                            const float* den, float* dvec, float* part, int B, int U, int D, int Q, void* stream) {
-    (void)den;
-    TNR_CHECK_ARG(vec && hidx && mask && pad && w1 && w2 && duser && e && alpha && dvec && part, "tnr_user_bwd: null pointer");
-    TNR_CHECK_ARG(user_shape_ok(B, U, 0, D, Q), "tnr_user_bwd: bad shape (U <= %d)", MAXU);
-    size_t lds = sizeof(float) * ((size_t)U * D + (size_t)Q * MAXU + 2 * MAXU);
-    TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_bwd: too large for LDS");
+extern "C" int tnr_user_bwd_pre(const float* vec, const int32_t* hidx, const float* mask, const float* pad, const float* w2,
+                                int user_log_mask, const float* duser, const float* e, const float* alpha, float* hv,
+                                float* dpre, float* part, int B, int U, int D, int Q, void* stream) {
+    TNR_CHECK_ARG(vec && hidx && mask && pad && w2 && duser && e && alpha && hv && dpre && part, "tnr_user_bwd_pre: null pointer");
+    TNR_CHECK_ARG(user_shape_ok(B, U, 0, D, Q), "tnr_user_bwd_pre: bad shape (U <= %d)", MAXU);
+    size_t lds = sizeof(float) * ((size_t)U * D + 2 * MAXU);
+    TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_bwd_pre: too large for LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)user_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)user_bwd_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(user_bwd_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, vec, hidx, mask, pad, w1,
-                       w2, user_log_mask, duser, e, alpha, dvec, part, U, D, Q);
-    TNR_CHECK_LAUNCH("tnr_user_bwd");
+    hipLaunchKernelGGL(user_bwd_pre_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, vec, hidx, mask, pad, w2,
+                       user_log_mask, duser, e, alpha, hv, dpre, part, U, D, Q);
+    TNR_CHECK_LAUNCH("tnr_user_bwd_pre");
+    return TNR_OK;
+}
+
+extern "C" int tnr_user_bwd_post(const float* dhv, const float* alpha, const float* duser, const float* mask,
+                                 const int32_t* hidx, int user_log_mask, float* dvec, float* part, int B, int U, int D, int Q,
+                                 void* stream) {
+    TNR_CHECK_ARG(dhv && alpha && duser && mask && hidx && dvec && part, "tnr_user_bwd_post: null pointer");
+    TNR_CHECK_ARG(user_shape_ok(B, U, 0, D, Q), "tnr_user_bwd_post: bad shape (U <= %d)", MAXU);
+    hipLaunchKernelGGL(user_bwd_post_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dhv, alpha, duser, mask,
+                       hidx, user_log_mask, dvec, part, U, D, Q);
+    TNR_CHECK_LAUNCH("tnr_user_bwd_post");
     return TNR_OK;
 }
 

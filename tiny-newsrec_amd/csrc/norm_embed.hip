@@ -105,11 +105,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ xi
 }
 
 // dx = rstd * (dxh - mean(dxh) - xh * mean(dxh*xh)), dxh = dy*gamma ; per-block partial dgamma/dbeta
-constexpr int LNB_ROWS = 128;  // rows per block (4 waves x 32 rows)
+constexpr int LNB_ROWS = 128;  // rows per block (4 waves x 32 rows); short inputs use 32 so that every CU gets work
+static inline int lnb_rows(int64_t M) { return M >= 32768 ? LNB_ROWS : 32; }
+static inline int64_t lnb_blocks(int64_t M) { return (M + lnb_rows(M) - 1) / lnb_rows(M); }
 template <int V>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ xin,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     bf16* __restrict__ dx, float* __restrict__ part, int64_t M) {
+                                                     bf16* __restrict__ dx, float* __restrict__ part, int64_t M,
+                                                     int rows_per_block) {
     const int H = 256 * V;
     __shared__ float red[4][3][256 * V];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             dxs[v][r] = 0.f;
         }
     }
-    for (int it = 0; it < LNB_ROWS / 4; ++it) {
-        int64_t m = (int64_t)blockIdx.x * LNB_ROWS + it * 4 + w;
+    for (int it = 0; it < rows_per_block / 4; ++it) {
+        int64_t m = (int64_t)blockIdx.x * rows_per_block + it * 4 + w;
         if (m >= M) break;
         float mean = stats[m * 2], rstd = stats[m * 2 + 1];
         float xh[V][4], g[V][4];
@@ -381,7 +384,12 @@ extern "C" int TNR_NAME(tnr_ln_fwd)(const void* x, const float* gamma, const flo
 }
 
 #ifndef TNR_BUILD_F16
-extern "C" int64_t tnr_ln_bwd_part_elems(int64_t M, int H) { return ((M + LNB_ROWS - 1) / LNB_ROWS) * 3 * H; }
+// workspace for any row count up to M (short inputs use smaller blocks, i.e. more partial rows)
+extern "C" int64_t tnr_ln_bwd_part_elems(int64_t M, int H) {
+    int64_t nb = lnb_blocks(M), nb_short = lnb_blocks(M < 32767 ? M : 32767);
+    return (nb > nb_short ? nb : nb_short) * 3 * H;
+}
+extern "C" int64_t tnr_ln_bwd_blocks(int64_t M) { return lnb_blocks(M); }
 
 extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, float* out, int accumulate,
                                void* stream) {
@@ -429,11 +437,12 @@ extern "C" int TNR_NAME(tnr_ln_bwd)(const void* dy, const void* x, const float* 
     TNR_CHECK_ARG(dy && x && stats && gamma && dx && M >= 1, "tnr_ln_bwd: null pointer");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_ln_bwd: H must be 256/512/768/1024");
     TNR_CHECK_ARG(!(dgamma || dbeta || dxsum) || part, "tnr_ln_bwd: part workspace required for dgamma/dbeta/dxsum");
-    int64_t nblk = (M + LNB_ROWS - 1) / LNB_ROWS;
+    int64_t nblk = lnb_blocks(M);
+    const int rows = lnb_rows(M);
     dim3 grid((unsigned)nblk), blk(256);
     hipStream_t st = (hipStream_t)stream;
     float* p = part;
-#define LAUNCH(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, blk, 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, p, M)
+#define LAUNCH(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, blk, 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, p, M, rows)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     TNR_CHECK_LAUNCH("tnr_ln_bwd");

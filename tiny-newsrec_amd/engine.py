@@ -195,7 +195,7 @@ class Engine:
     def _groups(self):
         """Storage groups: members are contiguous (no padding inside), every group starts 64-float aligned.
         Stacks that kernels read as one array: per-teacher params, q/k/v weights and biases, the student
-        user-encoder block (= tnr_user_bwd's partial layout [w1|b1|w2|pad|b2]), transform matrices."""
+        user-encoder block (w1, then tnr_user_bwd_pre/post's partial layout [b1|w2|pad|b2]), transform matrices."""
         cfg = self.cfg
         T_ = cfg.T
         tstack = lambda suffix: ["teachers.%d.%s" % (i, suffix) for i in range(T_)]
@@ -391,7 +391,8 @@ class Engine:
         self.tw = f(B, T_)
         self.losses = f(4)
         self.kd_part = f(Rt)
-        self.user_part = f(B, T.query("tnr_user_bwd_part_stride", D, cfg.Qu))
+        self.user_part = f(B, T.query("tnr_user_bwd_part_stride", D, cfg.Qu))     # [b1 | w2 | pad | b2] per impression
+        self.hv_u, self.dhv_u, self.dpre_u = f(B * cfg.U, D), f(B * cfg.U, D), f(B * cfg.U, cfg.Qu)
         # backward buffers
         self.dnv = f(N, H)
         self.dy, self.dy2 = z(Mp, H), z(Mp, H)
@@ -639,12 +640,19 @@ class Engine:
         # scorer + user encoder
         T.call("tnr_score_bwd", S, cidx, S[N:], self.dscore, dS, dS[N:], B, C, D)
         ue = "student.user_encoder."
-        T.call("tnr_user_bwd", S, hidx, self.mask, g(ue + "pad_doc"), g(ue + "attn.att_fc1.weight"),
-               g(ue + "attn.att_fc2.weight"), int(cfg.user_log_mask), dS[N:], self.e_u, self.alpha_u, self.den_u, dS,
-               self.user_part, B, U, D, cfg.Qu)
+        Qu = cfg.Qu
+        w1u = g(ue + "attn.att_fc1.weight")
+        T.call("tnr_user_bwd_pre", S, hidx, self.mask, g(ue + "pad_doc"), g(ue + "attn.att_fc2.weight"),
+               int(cfg.user_log_mask), dS[N:], self.e_u, self.alpha_u, self.hv_u, self.dpre_u, self.user_part, B, U, D, Qu)
+        # dW1 = dpre^T hv (straight into the gradient) ; dhv = dpre W1      -- fp32 MFMA GEMMs
+        self._sgemm(self.dpre_u, 1, Qu, 0, self.hv_u, 1, D, 0, self.grads[ue + "attn.att_fc1.weight"], D, 0, None, 0,
+                    Qu, D, B * U, ksplit=self.KS)
+        self._sgemm(self.dpre_u, Qu, 1, 0, w1u, 1, D, 0, self.dhv_u, D, 0, None, 0, B * U, D, Qu)
+        T.call("tnr_user_bwd_post", self.dhv_u, self.alpha_u, dS[N:], self.mask, hidx, int(cfg.user_log_mask), dS,
+               self.user_part, B, U, D, Qu)
         ps = self.user_part.shape[1]
         rb = self.red.setdefault(("heads", 0, N if self.plan is None else self.plan.n_enc), _ReduceBatch(self.dev))
-        rb.add(self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.weight", ps, (ps,), grad=True))
+        rb.add(self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.bias", ps, (ps,), grad=True))
         if self.plan is None:
             self.backward_encoder(dS[:N], N, after_bucket=after_bucket)
         else:
@@ -697,7 +705,7 @@ class Engine:
             # bias gradients ride along: dx column sums from LayerNorm backward, the dgrad epilogue, attention backward;
             # all partial sums of the layer are reduced by one launch at the end (fixed order)
             rb = self.red.setdefault((l, acc, N), _ReduceBatch(self.dev)) if tr else None
-            nblk = (M + 127) // 128
+            nblk = T.query("tnr_ln_bwd_blocks", M)
             self._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None,
                     self.ln_part if tr else None, M, H)
             if tr:

@@ -28,6 +28,7 @@ _SIG = {
     "tnr_ln_fwd": [_P, _P, _P, _F, _P, _P, _L, _I, _P],
     "tnr_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "tnr_ln_bwd_part_elems": [_L, _I],
+    "tnr_ln_bwd_blocks": [_L],
     "tnr_attn_l32_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "tnr_attn_l32_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "tnr_attn_long_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
@@ -41,7 +42,8 @@ _SIG = {
     "tnr_gather_rows": [_P, _L, _P, _L, _I, _I, _P, _L, _L, _P],
     "tnr_segment_sum_rows": [_P, _P, _P, _L, _I, _P, _P],
     "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "tnr_user_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "tnr_user_bwd_pre": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "tnr_user_bwd_post": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "tnr_user_bwd_part_stride": [_I, _I],
     "tnr_score_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "tnr_kd_score_loss": [_P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _P],
@@ -60,7 +62,7 @@ TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gem
          "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32"]
 for _n in TYPED:
     _SIG[_n + "_f16"] = _SIG[_n]
-_RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_gemm_tn_ws_elems_f16": _L, "tnr_gemm_colsum_rows_f16": _L, "tnr_gemm_colsum_rows": _L, "tnr_ln_bwd_part_elems": _L, "tnr_colsum_part_elems": _L,
+_RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_gemm_tn_ws_elems_f16": _L, "tnr_gemm_colsum_rows_f16": _L, "tnr_gemm_colsum_rows": _L, "tnr_ln_bwd_part_elems": _L, "tnr_ln_bwd_blocks": _L, "tnr_colsum_part_elems": _L,
         "tnr_user_bwd_part_stride": _L}
 EXPORTS = sorted(_SIG) + ["tnr_last_error"]
 
