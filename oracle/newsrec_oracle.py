@@ -257,14 +257,21 @@ def encoder_fwd(P, ids, mask, n_layers, A, keep_from=None):
     return x, caches, hidden
 
 
-def news_encoder_fwd(P, x2l, n_layers, A, keep_from=None):
-    """NewsEncoder.forward model_bert.py:119-137, pooling == 'att' (no mask), then dense."""
+def news_encoder_fwd(P, x2l, n_layers, A, keep_from=None, pooling="att"):
+    """NewsEncoder.forward model_bert.py:119-137: pooling 'att' (additive attention, no mask) | 'cls' (token 0) |
+    anything else = mean over ALL L positions (padding included, :135), then dense."""
     ids, mask = split_tokens(x2l)
     h, caches, hidden = encoder_fwd(P, ids, mask, n_layers, A, keep_from)
-    nv, pc = att_pool_fwd(h, P[PFX + "attn.att_fc1.weight"], P[PFX + "attn.att_fc1.bias"],
-                          P[PFX + "attn.att_fc2.weight"], P[PFX + "attn.att_fc2.bias"])
+    pc = None
+    if pooling == "att":
+        nv, pc = att_pool_fwd(h, P[PFX + "attn.att_fc1.weight"], P[PFX + "attn.att_fc1.bias"],
+                              P[PFX + "attn.att_fc2.weight"], P[PFX + "attn.att_fc2.bias"])
+    elif pooling == "cls":
+        nv = h[:, 0, :].astype(F32)
+    else:
+        nv = h.mean(1, dtype=F32)
     out = linear(nv, P[PFX + "dense.weight"], P[PFX + "dense.bias"]).astype(F32)
-    return out, dict(layers=caches, pool=pc, nv=nv, hidden=hidden)
+    return out, dict(layers=caches, pool=pc, nv=nv, hidden=hidden, pooling=pooling, L=h.shape[1])
 
 
 def news_encoder_bwd(P, dout, c, A, trainable_layers):
@@ -272,10 +279,17 @@ def news_encoder_bwd(P, dout, c, A, trainable_layers):
     G[PFX + "dense.weight"] = (dout.T @ c["nv"]).astype(F32)
     G[PFX + "dense.bias"] = dout.sum(0).astype(F32)
     dnv = dout @ P[PFX + "dense.weight"]
-    dh, g1, gb1, g2, gb2 = att_pool_bwd(dnv, c["pool"], P[PFX + "attn.att_fc1.weight"],
-                                        P[PFX + "attn.att_fc2.weight"])
-    G[PFX + "attn.att_fc1.weight"], G[PFX + "attn.att_fc1.bias"] = g1, gb1
-    G[PFX + "attn.att_fc2.weight"], G[PFX + "attn.att_fc2.bias"] = g2, gb2
+    pooling, L = c.get("pooling", "att"), c.get("L")
+    if pooling == "att":
+        dh, g1, gb1, g2, gb2 = att_pool_bwd(dnv, c["pool"], P[PFX + "attn.att_fc1.weight"],
+                                            P[PFX + "attn.att_fc2.weight"])
+        G[PFX + "attn.att_fc1.weight"], G[PFX + "attn.att_fc1.bias"] = g1, gb1
+        G[PFX + "attn.att_fc2.weight"], G[PFX + "attn.att_fc2.bias"] = g2, gb2
+    elif pooling == "cls":
+        dh = np.zeros((dnv.shape[0], L, dnv.shape[1]), F32)
+        dh[:, 0, :] = dnv
+    else:
+        dh = np.repeat((dnv / F32(L))[:, None, :], L, 1).astype(F32)
     if trainable_layers:
         lo = min(trainable_layers)
         for l in sorted(c["layers"].keys(), reverse=True):
@@ -285,18 +299,69 @@ def news_encoder_bwd(P, dout, c, A, trainable_layers):
     return G
 
 
-def user_encoder_fwd(P, pfx, news_vecs, log_mask, user_log_mask):
-    """UserEncoder.forward model_bert.py:155-176, model != 'NRMS'."""
+# --------------------------------------------------------------------------- #
+# NRMS user encoder: MultiHeadSelfAttention over the clicked-news vectors (model_bert.py:37-100), d_k = d_v = 16
+# --------------------------------------------------------------------------- #
+NRMS_DK = 16
+
+
+def mhsa_fwd(x, wq, bq, wk, bk, wv, bv, n_heads, mask=None):
+    """x (B,U,D) -> (B,U,n_heads*16).  scores = exp(QK^T / 4) [* mask over keys] / (sum + 1e-8): raw exp, no
+    max-subtraction (model_bert.py:51-58)."""
+    B, U, _ = x.shape
+    dk = NRMS_DK
+    sp = lambda t: t.reshape(B, U, n_heads, dk).transpose(0, 2, 1, 3)
+    q, k, v = sp(linear(x, wq, bq)), sp(linear(x, wk, bk)), sp(linear(x, wv, bv))
+    sc = np.exp(np.einsum("bhid,bhjd->bhij", q, k).astype(F32) / F32(np.sqrt(dk))).astype(F32)
+    if mask is not None:
+        sc = sc * mask[:, None, None, :].astype(F32)
+    den = sc.sum(-1, keepdims=True) + F32(1e-8)
+    attn = (sc / den).astype(F32)
+    ctx = np.einsum("bhij,bhjd->bhid", attn, v).astype(F32)
+    out = ctx.transpose(0, 2, 1, 3).reshape(B, U, n_heads * dk)
+    return out.astype(F32), dict(x=x, q=q, k=k, v=v, attn=attn, den=den, sc=sc, H=n_heads)
+
+
+def mhsa_bwd(dout, c, wq, wk, wv):
+    """-> dx, {W_Q,W_K,W_V}.{weight,bias} gradients."""
+    x, q, k, v, attn, den, nh = c["x"], c["q"], c["k"], c["v"], c["attn"], c["den"], c["H"]
+    B, U, D = x.shape
+    dk = NRMS_DK
+    dctx = dout.reshape(B, U, nh, dk).transpose(0, 2, 1, 3)
+    dattn = np.einsum("bhid,bhjd->bhij", dctx, v)
+    dv = np.einsum("bhij,bhid->bhjd", attn, dctx)
+    # attn = sc / den, den = sum_j sc + eps  ->  dsc = (dattn - sum_j dattn * attn) / den ; the mask factor is part of sc
+    dsc = (dattn - (dattn * attn).sum(-1, keepdims=True)) / den
+    ds = dsc * c["sc"] / F32(np.sqrt(dk))            # d exp(s) = exp(s) (already masked) ds
+    dq = np.einsum("bhij,bhjd->bhid", ds, k)
+    dkk = np.einsum("bhij,bhid->bhjd", ds, q)
+    mg = lambda t: t.transpose(0, 2, 1, 3).reshape(B * U, nh * dk).astype(F32)
+    dq2, dk2, dv2 = mg(dq), mg(dkk), mg(dv)
+    x2 = x.reshape(B * U, D)
+    G = {"W_Q.weight": dq2.T @ x2, "W_Q.bias": dq2.sum(0), "W_K.weight": dk2.T @ x2, "W_K.bias": dk2.sum(0),
+         "W_V.weight": dv2.T @ x2, "W_V.bias": dv2.sum(0)}
+    dx = (dq2 @ wq + dk2 @ wk + dv2 @ wv).reshape(B, U, D)
+    return dx.astype(F32), {n: g.astype(F32) for n, g in G.items()}
+
+
+def user_encoder_fwd(P, pfx, news_vecs, log_mask, user_log_mask, nrms_heads=0):
+    """UserEncoder.forward model_bert.py:155-176.  nrms_heads > 0: args.model == 'NRMS' (self-attention over the
+    clicked news before the additive pooling, :162-163 / :171-172)."""
     w1, b1 = P[pfx + "attn.att_fc1.weight"], P[pfx + "attn.att_fc1.bias"]
     w2, b2 = P[pfx + "attn.att_fc2.weight"], P[pfx + "attn.att_fc2.bias"]
+    mh = pfx + "multi_head_self_attn."
+    sa = lambda x, m: mhsa_fwd(x, P[mh + "W_Q.weight"], P[mh + "W_Q.bias"], P[mh + "W_K.weight"], P[mh + "W_K.bias"],
+                               P[mh + "W_V.weight"], P[mh + "W_V.bias"], nrms_heads, m)
     if user_log_mask:
-        out, c = att_pool_fwd(news_vecs, w1, b1, w2, b2, mask=log_mask)
-        c["blend"] = False
+        x, sc = (sa(news_vecs.astype(F32), log_mask) if nrms_heads else (news_vecs, None))
+        out, c = att_pool_fwd(x, w1, b1, w2, b2, mask=log_mask)
+        c["blend"], c["sa"] = False, sc
         return out, c
     m = log_mask[..., None]
     hv = (news_vecs * m + P[pfx + "pad_doc"][None] * (1.0 - m)).astype(F32)
-    out, c = att_pool_fwd(hv, w1, b1, w2, b2)
-    c["blend"] = True
+    x, sc = (sa(hv, None) if nrms_heads else (hv, None))
+    out, c = att_pool_fwd(x, w1, b1, w2, b2)
+    c["blend"], c["sa"] = True, sc
     c["m"] = m
     return out, c
 
@@ -305,6 +370,11 @@ def user_encoder_bwd(P, pfx, dout, c):
     dhv, g1, gb1, g2, gb2 = att_pool_bwd(dout, c, P[pfx + "attn.att_fc1.weight"], P[pfx + "attn.att_fc2.weight"])
     G = {pfx + "attn.att_fc1.weight": g1, pfx + "attn.att_fc1.bias": gb1,
          pfx + "attn.att_fc2.weight": g2, pfx + "attn.att_fc2.bias": gb2}
+    if c.get("sa") is not None:
+        mh = pfx + "multi_head_self_attn."
+        dhv, gs = mhsa_bwd(dhv, c["sa"], P[mh + "W_Q.weight"], P[mh + "W_K.weight"], P[mh + "W_V.weight"])
+        for n, g in gs.items():
+            G[mh + n] = g
     if c["blend"]:
         m = c["m"]
         G[pfx + "pad_doc"] = (dhv * (1.0 - m)).sum((0, 1))[None].astype(F32)
@@ -327,7 +397,8 @@ def cross_entropy_rows(score, label):
 def model_fwd(P, cfg, history, history_mask, candidate, label, teacher_hist, teacher_cand, keep=True):
     """Returns dict with total/distill/emb/target losses, student_score and a cache.
 
-    cfg: dict(n_layers, heads, trainable_layers, user_log_mask, temperature, coef).
+    cfg: dict(n_layers, heads, trainable_layers, user_log_mask, temperature, coef[, pooling='att'|'cls'|'mean',
+    nrms_heads=0 (args.model == 'NRMS': args.num_attention_heads)]).
     history (B,U,2L) int; history_mask (B,U) f32; candidate (B,C,2L); label (B,);
     teacher_hist / teacher_cand: lists of (B,U,D) / (B,C,D)."""
     B, U, W2 = history.shape
@@ -338,11 +409,12 @@ def model_fwd(P, cfg, history, history_mask, candidate, label, teacher_hist, tea
     # ModelBert.forward :187-205 -- candidates and history share the encoder; rows are independent,
     # so one pass over the concatenation equals the reference's two calls.
     allx = np.concatenate([history.reshape(B * U, W2), candidate.reshape(B * C, W2)], 0)
-    vec, nc = news_encoder_fwd(P, allx, nl, A, keep_from)
+    vec, nc = news_encoder_fwd(P, allx, nl, A, keep_from, cfg.get("pooling", "att"))
+    nrms = int(cfg.get("nrms_heads", 0))
     D = vec.shape[1]
     hist = vec[:B * U].reshape(B, U, D)
     cand = vec[B * U:].reshape(B, C, D)
-    user, uc = user_encoder_fwd(P, "student.user_encoder.", hist, history_mask, cfg["user_log_mask"])
+    user, uc = user_encoder_fwd(P, "student.user_encoder.", hist, history_mask, cfg["user_log_mask"], nrms)
     score = np.einsum("bcd,bd->bc", cand, user).astype(F32)
     S = np.concatenate([hist, cand], 1)                              # :270
     target = cross_entropy_rows(score, label).mean(dtype=F32)         # :271
@@ -354,7 +426,7 @@ def model_fwd(P, cfg, history, history_mask, candidate, label, teacher_hist, tea
         pr = linear(tn, W, b).astype(F32)                                           # :278
         NE.append(((S - pr) ** 2).mean(-1).mean(-1))                                # :279-280
         tu, _ = user_encoder_fwd(P, "teachers.%d." % i, teacher_hist[i].astype(F32), history_mask,
-                                 cfg["user_log_mask"])                              # :282
+                                 cfg["user_log_mask"], nrms)                        # :282
         tup = linear(tu, W, b).astype(F32)                                          # :283
         UE.append(((user - tup) ** 2).mean(-1))                                     # :284
         ts = np.einsum("bcd,bd->bc", teacher_cand[i].astype(F32), tu).astype(F32)   # :286-287

@@ -124,6 +124,7 @@ def run_model(R, cfg_json, args_over, trainable, seed, B, T, full_grads):
                             cfg_json["num_attention_heads"], a.num_student_layers])
     rec["trainable"] = np.array(sorted(trainable))
     rec["flags"] = np.array([float(a.user_log_mask), a.temperature, a.coef])
+    rec["variant"] = np.array([a.pooling, a.model, str(a.num_attention_heads if a.model == "NRMS" else 0)])
     return rec, P
 
 
@@ -236,6 +237,26 @@ def main():
                            trainable, seed=seed, B=2, T=T, full_grads=False)
         np.savez_compressed(os.path.join(HERE, "full_model_%d.npz" % k), **rec)
         print("full", k, rec["total"], rec["distill"], rec["emb"], rec["target"])
+    golden_variants(R)
+
+
+def golden_variants(R):
+    """pooling in {cls, mean} (model_bert.py:130-135) and the NRMS user encoder (:37-100, :145-148)."""
+    tiny = [("cls", "NAML", False), ("mean", "NAML", True), ("att", "NRMS", False), ("att", "NRMS", True),
+            ("mean", "NRMS", False)]
+    for k, (pool, model, ulm) in enumerate(tiny):
+        over = dict(TINY_ARGS, num_student_layers=2, user_log_mask=ulm, temperature=1.0, coef=0.2, pooling=pool,
+                    model=model, num_attention_heads=2)
+        rec, _ = run_model(R, TINY_CFG, over, (0, 1), seed=200 + k, B=4, T=2, full_grads=True)
+        np.savez_compressed(os.path.join(HERE, "tiny_model_%d.npz" % (8 + k)), **rec)
+        print("tiny variant", 8 + k, pool, model, ulm, rec["total"])
+    full = [("mean", "NRMS", False, 31), ("cls", "NRMS", True, 32)]
+    for k, (pool, model, ulm, seed) in enumerate(full):
+        cfg = dict(ref_shim.BASE_CFG, num_hidden_layers=2)
+        rec, _ = run_model(R, cfg, dict(num_student_layers=2, user_log_mask=ulm, temperature=1.0, coef=0.2, pooling=pool,
+                                        model=model, num_attention_heads=16), (0, 1), seed=seed, B=2, T=2, full_grads=False)
+        np.savez_compressed(os.path.join(HERE, "full_model_%d.npz" % (3 + k)), **rec)
+        print("full variant", 3 + k, pool, model, ulm, rec["total"], rec["distill"], rec["emb"], rec["target"])
 
 
 

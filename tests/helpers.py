@@ -11,13 +11,23 @@ TINY = dict(H=64, A=4, I=256, vocab=128, max_pos=64, Q=16)
 FULL = dict(H=768, A=12, I=3072, vocab=30522, max_pos=512, Q=200)
 
 
-def state_shapes(dims, n_layers, D, T):
-    """state_dict key schema of model_bert.Model."""
+def _nrms_shapes(s, pfx, D, heads):
+    for n in ("W_Q", "W_K", "W_V"):
+        s[pfx + "multi_head_self_attn.%s.weight" % n] = (heads * 16, D)
+        s[pfx + "multi_head_self_attn.%s.bias" % n] = (heads * 16,)
+
+
+def state_shapes(dims, n_layers, D, T, pooling="att", nrms_heads=0):
+    """state_dict key schema of model_bert.Model; pooling != 'att' drops the news encoder's
+    additive attention, nrms_heads > 0 (args.model == 'NRMS') adds the user encoders' self-attention."""
     H, I, Q = dims["H"], dims["I"], dims["Q"]
+    Du = nrms_heads * 16 if nrms_heads else D
     s = {}
     for i in range(T):
+        if nrms_heads:
+            _nrms_shapes(s, "teachers.%d." % i, D, nrms_heads)
         s["teachers.%d.pad_doc" % i] = (1, D)
-        s["teachers.%d.attn.att_fc1.weight" % i] = (Q, D)
+        s["teachers.%d.attn.att_fc1.weight" % i] = (Q, Du)
         s["teachers.%d.attn.att_fc1.bias" % i] = (Q,)
         s["teachers.%d.attn.att_fc2.weight" % i] = (1, Q)
         s["teachers.%d.attn.att_fc2.bias" % i] = (1,)
@@ -47,14 +57,17 @@ def state_shapes(dims, n_layers, D, T):
     s[b + "rel_pos_bias.weight"] = (dims["A"], 32)
     s["student.news_encoder.bert_model.classifier.weight"] = (2, H)
     s["student.news_encoder.bert_model.classifier.bias"] = (2,)
-    s["student.news_encoder.attn.att_fc1.weight"] = (Q, H)
-    s["student.news_encoder.attn.att_fc1.bias"] = (Q,)
-    s["student.news_encoder.attn.att_fc2.weight"] = (1, Q)
-    s["student.news_encoder.attn.att_fc2.bias"] = (1,)
+    if pooling == "att":
+        s["student.news_encoder.attn.att_fc1.weight"] = (Q, H)
+        s["student.news_encoder.attn.att_fc1.bias"] = (Q,)
+        s["student.news_encoder.attn.att_fc2.weight"] = (1, Q)
+        s["student.news_encoder.attn.att_fc2.bias"] = (1,)
     s["student.news_encoder.dense.weight"] = (D, H)
     s["student.news_encoder.dense.bias"] = (D,)
+    if nrms_heads:
+        _nrms_shapes(s, "student.user_encoder.", D, nrms_heads)
     s["student.user_encoder.pad_doc"] = (1, D)
-    s["student.user_encoder.attn.att_fc1.weight"] = (Q, D)
+    s["student.user_encoder.attn.att_fc1.weight"] = (Q, Du)
     s["student.user_encoder.attn.att_fc1.bias"] = (Q,)
     s["student.user_encoder.attn.att_fc2.weight"] = (1, Q)
     s["student.user_encoder.attn.att_fc2.bias"] = (1,)
@@ -69,10 +82,11 @@ def load_case(name):
     z = np.load(os.path.join(GOLDEN, name))
     seed, B, T, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
     dims = TINY if name.startswith("tiny") else FULL
-    P = hashinit.init_state_dict(seed, state_shapes(dims, nl, D, T))
+    pooling, model, nh = [str(x) for x in z["variant"]] if "variant" in z.files else ("att", "NAML", "0")
+    P = hashinit.init_state_dict(seed, state_shapes(dims, nl, D, T, pooling, int(nh)))
     ulm, tau, coef = [float(x) for x in z["flags"]]
     cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]],
-               user_log_mask=bool(ulm), temperature=tau, coef=coef)
+               user_log_mask=bool(ulm), temperature=tau, coef=coef, pooling=pooling, nrms_heads=int(nh))
     inp = (z["in_hist"], z["in_mask"], z["in_cand"], z["in_label"],
            [z["in_th%d" % i] for i in range(T)], [z["in_tc%d" % i] for i in range(T)])
     return z, P, cfg, inp

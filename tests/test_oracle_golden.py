@@ -86,23 +86,30 @@ def _check_model(name, full_grads):
     G = O.model_bwd(P, cfg, out)
     names = [str(n) for n in z["grad_names"]]
     assert set(G.keys()) >= set(names), set(names) - set(G.keys())
+    ref_of = lambda n: z["grad." + n] if full_grads else z["gval." + n]
+    # Mathematical no-ops: a key bias adds a per-query constant that the softmax / the NRMS
+    # normaliser removes, the fc2 bias of an additive pooling cancels in its normaliser.  The reference's gradient for
+    # them is pure fp32 rounding noise, which makes them a measurement of the autograd noise floor of their block
+    # (large for the NRMS user encoder, whose true gradients are tiny next to its activations).
+    noop = lambda n: n.endswith("self.key.bias") or n.endswith("att_fc2.bias") or n.endswith("W_K.bias")
+    block = lambda n: "user" if n.startswith("student.user_encoder.") else "news"
+    floor = {"user": 0.0, "news": 0.0}
+    for n in names:
+        if noop(n):
+            floor[block(n)] = max(floor[block(n)], float(np.abs(ref_of(n)).max()))
     for n in names:
         g = G[n]
         ref_norm = float(z["gnorm." + n])
-        if n.endswith("self.key.bias") or n.endswith("att_fc2.bias"):
-            # mathematical no-ops (a per-query / per-row constant that softmax / the pooling normaliser
-            # removes): the reference's gradient is rounding noise
-            assert np.sqrt((g.astype(np.float64) ** 2).sum()) < 1e-4 and ref_norm < 1e-4
+        nf = 4.0 * floor[block(n)]
+        if noop(n):
+            assert np.sqrt((g.astype(np.float64) ** 2).sum()) < 1e-4 + nf * np.sqrt(g.size) and ref_norm < 1e-4
             continue
-        np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), ref_norm, rtol=1e-3, atol=1e-9,
-                                   err_msg=n)      # atol: fp32 cancellation noise floor of O(1) operands
+        np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), ref_norm, rtol=1e-3,
+                                   atol=1e-9 + nf * np.sqrt(g.size), err_msg=n)
         scale = ref_norm / np.sqrt(g.size) + 1e-12
-        scale = max(scale, float(np.abs(z["grad." + n] if full_grads else z["gval." + n]).max()))
-        if full_grads:
-            np.testing.assert_allclose(g, z["grad." + n], rtol=2e-3, atol=2e-3 * scale + 1e-10, err_msg=n)
-        else:
-            np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], z["gval." + n], rtol=2e-3,
-                                       atol=2e-3 * scale + 1e-10, err_msg=n)
+        scale = max(scale, float(np.abs(ref_of(n)).max()))
+        got = g if full_grads else g.reshape(-1)[z["gidx." + n]]
+        np.testing.assert_allclose(got, ref_of(n), rtol=2e-3, atol=2e-3 * scale + 1e-10 + nf, err_msg=n)
     # parameters outside the trainable set receive no gradient in the reference either
     lo = "encoder.layer.%d." % min(cfg["trainable_layers"])
     assert not any("embeddings" in k or "rel_pos" in k for k in G)
@@ -141,3 +148,35 @@ def test_stage1_distill_forward_backward(name):
         else:
             ref = z["gval." + n]
             np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-10, err_msg=n)
+
+
+def test_nrms_self_attention_backward_matches_finite_differences():
+    """The NRMS goldens carry little gradient through the user encoder (see the noise-floor note above), so the
+    hand-derived backward of model_bert.py:37-100 is also checked against central differences of its own forward."""
+    rs = np.random.RandomState(0)
+    B, U, D, nh = 2, 5, 32, 2
+    x = rs.randn(B, U, D).astype(np.float32) * 0.5
+    W = {k: (rs.randn(nh * 16, D) * 0.3).astype(np.float32) for k in "qkv"}
+    b = {k: (rs.randn(nh * 16) * 0.1).astype(np.float32) for k in "qkv"}
+    mask = np.array([[1, 1, 0, 1, 1], [0, 1, 1, 1, 0]], np.float32)
+    R = rs.randn(B, U, nh * 16).astype(np.float32)
+    for m in (None, mask):
+        f = lambda x_, W_, b_: float((O.mhsa_fwd(x_, W_["q"], b_["q"], W_["k"], b_["k"], W_["v"], b_["v"], nh, m)[0].astype(np.float64) * R).sum())
+        out, c = O.mhsa_fwd(x, W["q"], b["q"], W["k"], b["k"], W["v"], b["v"], nh, m)
+        dx, G = O.mhsa_bwd(R, c, W["q"], W["k"], W["v"])
+        eps = 2e-2
+
+        def fd(arr, idx, rebuild):
+            old = arr[idx]
+            arr[idx] = old + eps
+            hi = rebuild()
+            arr[idx] = old - eps
+            lo = rebuild()
+            arr[idx] = old
+            return (hi - lo) / (2 * eps)
+        for idx in [(0, 1, 3), (1, 4, 31), (1, 2, 7)]:
+            np.testing.assert_allclose(dx[idx], fd(x, idx, lambda: f(x, W, b)), rtol=3e-2, atol=3e-3)
+        for key, name in (("q", "W_Q"), ("k", "W_K"), ("v", "W_V")):
+            for idx in [(0, 0), (17, 5), (31, 31)]:
+                np.testing.assert_allclose(G[name + ".weight"][idx], fd(W[key], idx, lambda: f(x, W, b)), rtol=3e-2, atol=3e-3)
+            np.testing.assert_allclose(G[name + ".bias"][3], fd(b[key], 3, lambda: f(x, W, b)), rtol=3e-2, atol=3e-3)

@@ -81,6 +81,9 @@ _RULES = [
     ("att_fc2.bias", "normal", (0.05, 0.0)),
     ("pad_doc", "uniform", (-1.0, 1.0)),
     ("news_encoder.dense.weight", "normal", (0.005, 0.0)),
+    ("multi_head_self_attn.W_Q.weight", "fan", (2.0, 0.0)),        # NRMS: std = 2/sqrt(fan_in): attention far enough from
+    ("multi_head_self_attn.W_K.weight", "fan", (2.0, 0.0)),        # uniform to carry gradient, raw exp() still tame
+    ("multi_head_self_attn.W_V.weight", "fan", (1.0, 0.0)),
     (".bias", "normal", (0.05, 0.0)),
     (".weight", "normal", (0.05, 0.0)),
 ]
@@ -92,6 +95,8 @@ def init_tensor(seed, name, shape):
         if name.endswith(suffix):
             if kind == "uniform":
                 return hash_uniform(seed, name, shape, prm[0], prm[1])
+            if kind == "fan":
+                return hash_normal(seed, name, shape, std=prm[0] / float(shape[-1]) ** 0.5, mean=prm[1])
             return hash_normal(seed, name, shape, std=prm[0], mean=prm[1])
     return hash_normal(seed, name, shape, std=0.05)
 
