@@ -142,6 +142,11 @@ int tnr_attpool_bwd(const void* y, const float* e, int64_t lde, const float* w2,
                     const float* alpha, const float* den, void* dy_direct, void* dpre, int64_t lddpre,
                     float* dw2_part, float* db2_part, float* db1_part, int64_t n_seq, int L, int H, void* stream);
 
+/* NewsEncoder pooling 'cls' (mean = 0: hidden state of token 0) or mean over all L positions (mean = 1), model_bert.py:
+ * 130-135: y (n_seq*L, H) 16-bit -> nv (n_seq, H) fp32 ; backward dnv -> dy (every row written). */
+int tnr_pool_fwd(const void* y, float* nv, int64_t n_seq, int L, int H, int mean, void* stream);
+int tnr_pool_bwd(const float* dnv, void* dy, int64_t n_seq, int L, int H, int mean, void* stream);
+
 /* small fp32 GEMM on the f32 MFMA (exact fp32):  for z in [0,batch):
  *   C_z[m,n] = alpha * sum_k A_z(m,k) B_z(n,k) + bias_z[n] + beta * C_z[m,n]
  * A_z(m,k) = A[z*sA + m*a_rs + k*a_cs] (a_idx must be NULL), likewise B.  ksplit > 1 splits K over workgroups
@@ -188,6 +193,22 @@ int tnr_user_bwd_post(const float* dhv, const float* alpha, const float* duser, 
                       const int32_t* hidx, int user_log_mask, float* dvec, float* part, int B, int U, int D, int Q,
                       void* stream);
 int64_t tnr_user_bwd_part_stride(int D, int Q);
+/* NRMS user encoder (args.model == 'NRMS': model_bert.py:37-100, 145-148, 162-164, 171-173), d_k = d_v = 16, for
+ * `n_model` encoders at once (student and/or frozen teachers); fp32.
+ *   tnr_user_blend_fwd : hv (n_model, B*U, D) = vec[hidx] * m + pad * (1-m) (user_log_mask 0) | vec[hidx] (1)
+ *   caller             : qkv (n_model, B*U, 3*Dh) = hv [W_Q;W_K;W_V]^T + b   (tnr_sgemm), Dh = n_heads*16
+ *   tnr_nrms_attn_fwd  : ctx (n_model, B*U, Dh) ; sc = exp(q.k/4) [* mask_j if use_mask] / (sum + 1e-8), raw exp (:51-58)
+ *   tnr_nrms_attn_bwd  : dctx (B*U, Dh) -> dqkv (B*U, 3*Dh) for one model, recomputing sc (two fixed-order phases)
+ *   tnr_user_blend_bwd : dvec[hidx] += dhv * m ; pad_part[b*part_stride + d] = sum_u dhv * (1-m) */
+int tnr_user_blend_fwd(const float* vec, int64_t R, const int32_t* hidx, const float* mask, const float* pad,
+                       int user_log_mask, float* hv, int n_model, int B, int U, int D, void* stream);
+int tnr_user_blend_bwd(const float* dhv, const float* mask, const int32_t* hidx, int user_log_mask, float* dvec,
+                       float* pad_part, int64_t part_stride, int B, int U, int D, void* stream);
+int tnr_nrms_attn_fwd(const float* qkv, const float* mask, int use_mask, float* ctx, int64_t ctx_rows, int n_model,
+                      int B, int U, int n_heads, void* stream);   /* ctx rows of model z start at z*ctx_rows (>= B*U) */
+int tnr_nrms_attn_bwd(const float* qkv, const float* mask, int use_mask, const float* dctx, float* dqkv, int B,
+                      int U, int n_heads, void* stream);
+
 /* backward of the scorer bmm (model_bert.py:204): dvec[cidx[b,c]] += dscore[b,c]*user[b] ;
  * duser[b] += sum_c dscore[b,c]*vec[cidx[b,c]] */
 int tnr_score_bwd(const float* vec, const int32_t* cidx, const float* user, const float* dscore, float* dvec,
@@ -256,6 +277,8 @@ int tnr_ln_fwd_f16(const void* x, const float* gamma, const float* beta, float e
                int64_t M, int H, void* stream);
 int tnr_ln_bwd_f16(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream);
+int tnr_pool_fwd_f16(const void* y, float* nv, int64_t n_seq, int L, int H, int mean, void* stream);
+int tnr_pool_bwd_f16(const float* dnv, void* dy, int64_t n_seq, int L, int H, int mean, void* stream);
 int tnr_attn_long_fwd_f16(const void* qkv, const float* mask_add, const float* rel, void* ctx, float* lse,
                           int64_t n_seq, int L, int A, void* stream);
 int tnr_attn_long_bwd_f16(const void* qkv, const float* mask_add, const float* rel, const void* ctx, const void* dctx,

@@ -22,7 +22,8 @@ def _engine_for(cfg, z, T_, dtype="bf16"):
     seed, B, _, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
     ec = E.EngineConfig(n_layers=nl, trainable_layers=cfg["trainable_layers"], num_teachers=T_, user_log_length=U,
                         npratio=C - 1, num_words=L, news_dim=D, user_log_mask=cfg["user_log_mask"],
-                        temperature=cfg["temperature"], coef=cfg["coef"])
+                        temperature=cfg["temperature"], coef=cfg["coef"], pooling=cfg.get("pooling", "att"),
+                        nrms_heads=cfg.get("nrms_heads", 0))
     return E.Engine(ec, DEV, max_batch=B, dtype=dtype), B
 
 
@@ -38,7 +39,8 @@ GTOL = {"bf16": 6e-2, "fp16": 1.5e-2}
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("name", ["full_model_0.npz", "full_model_1.npz", "full_model_2.npz"])
+@pytest.mark.parametrize("name", ["full_model_0.npz", "full_model_1.npz", "full_model_2.npz",
+                                  "full_model_3.npz", "full_model_4.npz"])       # 3: mean pooling + NRMS, 4: cls + NRMS (masked)
 def test_training_step_matches_reference_and_oracle(name, dtype):
     LOGIT_TOL = TOL[dtype]
     z, P, cfg, inp = load_case(name)
@@ -55,7 +57,13 @@ def test_training_step_matches_reference_and_oracle(name, dtype):
     for k in got:
         print("   %s: got %.6f ref %.6f err %.2e" % (k, got[k], float(z[k]), abs(got[k] - float(z[k]))))
         assert abs(got[k] - float(z[k])) <= LOGIT_TOL * max(1.0, abs(float(z[k]))), k
-    assert np.abs(sc - z["score"]).max() <= LOGIT_TOL * max(1.0, np.abs(z["score"]).max())
+    score_tol = LOGIT_TOL * max(1.0, np.abs(z["score"]).max())
+    if cfg.get("nrms_heads"):
+        # NRMS user vectors are not convex combinations of news vectors (|user|_2 ~ 8 here): a 16-bit rounding error eps in
+        # the candidate vectors alone moves a logit by ~ eps * |user|_2.  The oracle shows the same sensitivity to inputs
+        # perturbed by eps (3-6e-3 at eps = 5e-4), so the bound scales with that conditioning instead of with |logit|.
+        score_tol = max(score_tol, 2.0 * LOGIT_TOL * max(1.0, np.abs(z["cand_vec"]).max()) * np.sqrt((z["user_vec"] ** 2).sum(-1)).max())
+    assert np.abs(sc - z["score"]).max() <= score_tol
     N = B * (eng.cfg.U + eng.cfg.C)
     vec = eng.S[:N].cpu().numpy()
     ref_vec = np.concatenate([z["hist_vec"].reshape(-1, eng.cfg.D), z["cand_vec"].reshape(-1, eng.cfg.D)], 0)
@@ -69,21 +77,27 @@ def test_training_step_matches_reference_and_oracle(name, dtype):
     out = O.model_fwd(P, cfg, *inp)
     G = O.model_bwd(P, cfg, out)
     worst = 0.0
+    # mean pooling hands every one of the L token rows the same 16-bit-rounded gradient (no averaging of the rounding
+    # over rows as under attention pooling): bf16 gets 8e-2 there
+    gtol = 8e-2 if (dtype == "bf16" and cfg.get("pooling") == "mean") else GTOL[dtype]
     for k in eng.grads:
         ref = G[k]
         got_g = eng.grad(k).cpu().numpy()
         rn = np.sqrt((ref.astype(np.float64) ** 2).sum())
-        if k.endswith("self.key.bias") or k.endswith("att_fc2.bias"):
+        if k.endswith("self.key.bias") or k.endswith("att_fc2.bias") or k.endswith("W_K.bias"):
             assert np.abs(got_g).max() < 1e-3          # mathematical no-ops: rounding noise only
             continue
         if "gnorm." + k not in z.files:                # reference leaves .grad None (pad_doc under user_log_mask)
             assert np.abs(got_g).max() == 0.0 and np.abs(ref).max() == 0.0, k
             continue
+        if rn < 2e-5:                                  # NRMS pooling head: true gradient below the fp32 noise floor of the
+            assert np.sqrt(((got_g - ref).astype(np.float64) ** 2).sum()) < 2e-5, k      # reference itself (test_oracle_golden)
+            continue
         err = np.sqrt(((got_g - ref).astype(np.float64) ** 2).sum()) / (rn + 1e-12)
         worst = max(worst, err)
-        assert err < GTOL[dtype], "%s: relative L2 error %.3e (norm %.3e)" % (k, err, rn)
+        assert err < gtol, "%s: relative L2 error %.3e (norm %.3e)" % (k, err, rn)
         # golden reference norms (fp32 autograd of the imported reference)
-        assert abs(np.sqrt((got_g.astype(np.float64) ** 2).sum()) - float(z["gnorm." + k])) <= GTOL[dtype] * float(z["gnorm." + k]) + 1e-7, k
+        assert abs(np.sqrt((got_g.astype(np.float64) ** 2).sum()) - float(z["gnorm." + k])) <= gtol * float(z["gnorm." + k]) + 1e-7, k
     print("   worst gradient relative L2 error %.3e" % worst)
 
     # ---- optimiser step: AMSGrad on the flat buffer + bf16 copies refreshed

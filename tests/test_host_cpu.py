@@ -264,3 +264,23 @@ def test_dedup_plan_is_a_bijection_onto_distinct_news():
     # empty histories (all pad) collapse to one row
     q = build_plan(np.zeros((2, 50), np.int64), np.array([[1, 2, 3, 4, 5], [1, 2, 3, 4, 6]]))
     assert q.n_unique == 7 and q.seg[1] == 100
+
+
+@pytest.mark.parametrize("pooling,heads", [("cls", 0), ("mean", 16), ("att", 16)])
+def test_state_dict_schema_of_pooling_and_nrms_variants(pooling, heads):
+    """the engine's parameter schema for args.pooling in {cls, mean} / args.model == 'NRMS' equals the
+    key set the reference instantiates (helpers.state_shapes is what the golden harness loaded into the reference)."""
+    import engine as E
+    from helpers import FULL, state_shapes
+    cfg = E.EngineConfig(n_layers=2, trainable_layers=(0, 1), num_teachers=2, pooling=pooling, nrms_heads=heads)
+    want = state_shapes(FULL, 2, 256, 2, pooling, heads)
+    got = E.param_shapes(cfg)
+    assert {k: tuple(v) for k, v in got.items()} == {k: tuple(v) for k, v in want.items()}
+    eng = E.Engine(cfg, device="cpu", max_batch=1)
+    assert all(E.is_trainable(cfg, k) for k in got if "multi_head_self_attn" in k and k.startswith("student."))
+    if heads:   # [W_Q; W_K; W_V] of every encoder are one contiguous (3D, D) block, teachers back to back
+        q, k_ = "student.user_encoder.multi_head_self_attn.W_Q.weight", "student.user_encoder.multi_head_self_attn.W_K.weight"
+        assert eng.off(k_) == eng.off(q) + 256 * 256
+        assert eng.off("teachers.1.multi_head_self_attn.W_Q.weight") == eng.off("teachers.0.multi_head_self_attn.W_Q.weight") + 3 * 256 * 256
+    br = sorted(eng.bucket_ranges())
+    assert br[0][0] == 0 and br[-1][1] == eng.n_train and all(a[1] == b[0] for a, b in zip(br, br[1:]))

@@ -596,3 +596,77 @@ def test_attention_long_fwd_bwd(N, L, A):
     want_d = np.concatenate([back(ds @ k / 8.0), back(ds.transpose(0, 1, 3, 2) @ q / 8.0), back(dv)], 1)
     got = dqkv.float().cpu().numpy()
     np.testing.assert_allclose(got, want_d, rtol=3e-2, atol=3e-2 * np.abs(want_d).max())
+
+
+@pytest.mark.parametrize("use_mask", [0, 1])
+def test_nrms_self_attention_fwd_bwd(use_mask):
+    """tnr_user_blend_fwd/bwd + tnr_nrms_attn_fwd/bwd against the oracle's MultiHeadSelfAttention (model_bert.py:37-100)."""
+    nm, B, U, D, NH, R = 2, 3, 50, 256, 16, 200
+    rs = np.random.RandomState(3 + use_mask)
+    vec = rnd((nm, R, D), 1, 0.5)
+    hidx = rs.permutation(R)[:B * U].reshape(B, U).astype(np.int32)
+    mask = (rs.rand(B, U) > 0.4).astype(np.float32)
+    mask[0] = 1
+    pad = rnd((nm, D), 2)
+    W = rnd((nm, 3 * D, D), 3, 2.0 / np.sqrt(D))
+    bq = rnd((nm, 3 * D), 4, 0.1)
+    hv = torch.zeros((nm, B * U, D), device=DEV)
+    T.call("tnr_user_blend_fwd", dev(vec), R, dev(hidx), dev(mask), dev(pad), use_mask, hv, nm, B, U, D)
+    hv_ref = np.stack([vec[z][hidx] if use_mask else vec[z][hidx] * mask[..., None] + pad[z][None, None] * (1 - mask[..., None])
+                       for z in range(nm)], 0).astype(np.float32)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(hv.cpu().numpy().reshape(nm, B, U, D), hv_ref, rtol=1e-6, atol=1e-7)
+    qkv = np.einsum("zrd,zjd->zrj", hv_ref.reshape(nm, B * U, D), W) + bq[:, None, :]
+    ctx_rows = B * U + 7
+    ctx = torch.zeros((nm, ctx_rows, D), device=DEV)
+    T.call("tnr_nrms_attn_fwd", dev(qkv.astype(np.float32)), dev(mask), use_mask, ctx, ctx_rows, nm, B, U, NH)
+    torch.cuda.synchronize()
+    caches = []
+    for z in range(nm):
+        ref, c = O.mhsa_fwd(hv_ref[z], W[z][:D], bq[z][:D], W[z][D:2 * D], bq[z][D:2 * D], W[z][2 * D:], bq[z][2 * D:], NH,
+                            mask if use_mask else None)
+        caches.append(c)
+        np.testing.assert_allclose(ctx[z, :B * U].cpu().numpy().reshape(B, U, D), ref, rtol=2e-4, atol=2e-5)
+    assert float(ctx[:, B * U:].abs().max()) == 0.0
+    # backward of model 0
+    dctx = rnd((B, U, D), 9)
+    dx_ref, G = O.mhsa_bwd(dctx, caches[0], W[0][:D], W[0][D:2 * D], W[0][2 * D:])
+    dqkv = torch.zeros((B * U, 3 * D), device=DEV)
+    T.call("tnr_nrms_attn_bwd", dev(qkv[0].astype(np.float32)), dev(mask), use_mask, dev(dctx.reshape(B * U, D)), dqkv, B, U, NH)
+    torch.cuda.synchronize()
+    dq = dqkv.cpu().numpy()
+    x2 = hv_ref[0].reshape(B * U, D)
+    for i, n in enumerate(("W_Q", "W_K", "W_V")):
+        blk = dq[:, i * D:(i + 1) * D]
+        np.testing.assert_allclose(blk.T @ x2, G[n + ".weight"], rtol=2e-3, atol=2e-3 * np.abs(G[n + ".weight"]).max(), err_msg=n)
+        if n != "W_K":     # the key bias is a mathematical no-op
+            np.testing.assert_allclose(blk.sum(0), G[n + ".bias"], rtol=2e-3, atol=2e-3 * np.abs(G[n + ".bias"]).max())
+    np.testing.assert_allclose(dq @ W[0], dx_ref.reshape(B * U, D), rtol=2e-3, atol=2e-3 * np.abs(dx_ref).max())
+    # blend backward
+    dvec = torch.zeros((R, D), device=DEV)
+    part = torch.zeros((B, D + 5), device=DEV)
+    T.call("tnr_user_blend_bwd", dev(dx_ref.reshape(B * U, D)), dev(mask), dev(hidx), use_mask, dvec, part[:, 5:], D + 5, B, U, D)
+    torch.cuda.synchronize()
+    m = np.ones_like(mask)[..., None] if use_mask else mask[..., None]
+    want = np.zeros((R, D), np.float32)
+    np.add.at(want, hidx.reshape(-1), (dx_ref * m).reshape(-1, D))
+    np.testing.assert_allclose(dvec.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(part[:, 5:].sum(0).cpu().numpy(), (dx_ref * (1 - m)).sum((0, 1)), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("mean", [0, 1])
+def test_cls_and_mean_pooling(mean):
+    n_seq, L, H = 37, 30, 768
+    y = rnd((n_seq * L, H), 1)
+    yb = dev(y, torch.bfloat16)
+    nv = torch.zeros((n_seq, H), device=DEV)
+    T.call("tnr_pool_fwd", yb, nv, n_seq, L, H, mean)
+    yf = yb.float().cpu().numpy().reshape(n_seq, L, H)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nv.cpu().numpy(), yf.mean(1) if mean else yf[:, 0], rtol=1e-5, atol=1e-6)
+    dnv = rnd((n_seq, H), 2)
+    dy = torch.full((n_seq * L, H), 7.0, device=DEV, dtype=torch.bfloat16)
+    T.call("tnr_pool_bwd", dev(dnv), dy, n_seq, L, H, mean)
+    torch.cuda.synchronize()
+    want = np.repeat(dnv[:, None, :] / L, L, 1) if mean else np.concatenate([dnv[:, None, :], np.zeros((n_seq, L - 1, H), np.float32)], 1)
+    np.testing.assert_allclose(dy.float().cpu().numpy().reshape(n_seq, L, H), want, rtol=1e-2, atol=1e-3)

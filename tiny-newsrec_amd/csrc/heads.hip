@@ -424,6 +424,213 @@ __global__ __launch_bounds__(256) void user_bwd_post_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// NRMS user encoder (args.model == 'NRMS', model_bert.py:37-100, 145-148, 162-164, 171-173): a multi-head
+// self-attention (d_k = d_v = 16) over the U clicked-news vectors in front of the additive pooling.
+//   blend : hv[z, b*U+u] = vec[z, hidx[b,u]] * m + pad[z] * (1 - m)   (user_log_mask False) | vec row (True)
+//   qkv   = hv [W_Q; W_K; W_V]^T + b     (tnr_sgemm, batched over the models)
+//   attn  : ctx_i = sum_j sc_ij v_j / (sum_j sc_ij + 1e-8), sc_ij = exp(q_i.k_j / 4) [* m_j]   -- raw exp (:51-58)
+// Backward (student only) recomputes sc from q, k in two deterministic phases (rows, then columns; no atomics).
+constexpr int NRMS_DK = 16;
+
+__global__ __launch_bounds__(256) void user_blend_fwd_kernel(const float* __restrict__ vec, int64_t R,
+                                                             const int32_t* __restrict__ hidx, const float* __restrict__ mask,
+                                                             const float* __restrict__ pad, int user_log_mask,
+                                                             float* __restrict__ hv, int B, int U, int D) {
+    const int z = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int d4 = D / 4;
+    if (t >= (int64_t)B * U * d4) return;
+    const int64_t r = t / d4;
+    const int c = (int)(t - r * d4) * 4;
+    f32x4 v = *(const f32x4*)(vec + ((int64_t)z * R + hidx[r]) * D + c);
+    if (!user_log_mask) {
+        float m = mask[r];
+        f32x4 p = *(const f32x4*)(pad + (int64_t)z * D + c);
+        v = v * m + p * (1.f - m);
+    }
+    *(f32x4*)(hv + ((int64_t)z * B * U + r) * D + c) = v;
+}
+
+// dvec[hidx[b,u]] += dhv * m ; pad partial (per impression) = sum_u dhv * (1 - m)        (user_log_mask False)
+// dvec[hidx[b,u]] += dhv                                                                   (user_log_mask True)
+__global__ __launch_bounds__(256) void user_blend_bwd_kernel(const float* __restrict__ dhv, const float* __restrict__ mask,
+                                                             const int32_t* __restrict__ hidx, int user_log_mask,
+                                                             float* __restrict__ dvec, float* __restrict__ pad_part,
+                                                             int64_t part_stride, int U, int D) {
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float dp = 0.f;
+        for (int u = 0; u < U; ++u) {
+            float g = dhv[((int64_t)b * U + u) * D + d];
+            float m = user_log_mask ? 1.f : mask[(int64_t)b * U + u];
+            dp += g * (1.f - m);
+            dvec[(int64_t)hidx[(int64_t)b * U + u] * D + d] += g * m;
+        }
+        pad_part[(int64_t)b * part_stride + d] = dp;
+    }
+}
+
+// one workgroup per (impression, model): K and V of every head in LDS, one thread per (query i, head h)
+__global__ __launch_bounds__(256) void nrms_attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+                                                            int use_mask, float* __restrict__ ctx, int64_t ctx_rows, int B,
+                                                            int U, int NH) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Dh = NH * NRMS_DK;
+    float* Ks = sm;                     // [U][Dh]
+    float* Vs = sm + U * Dh;            // [U][Dh]
+    const int b = blockIdx.x, z = blockIdx.y;
+    const float* base = qkv + ((int64_t)z * B + b) * U * 3 * Dh;
+    for (int t = threadIdx.x * 4; t < U * Dh; t += 1024) {
+        int u = t / Dh, c = t - u * Dh;
+        *(f32x4*)(Ks + t) = *(const f32x4*)(base + (int64_t)u * 3 * Dh + Dh + c);
+        *(f32x4*)(Vs + t) = *(const f32x4*)(base + (int64_t)u * 3 * Dh + 2 * Dh + c);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < U * NH; p += 256) {
+        const int i = p / NH, h = p - i * NH;
+        float q[NRMS_DK], acc[NRMS_DK];
+#pragma unroll
+        for (int d = 0; d < NRMS_DK; ++d) {
+            q[d] = base[(int64_t)i * 3 * Dh + h * NRMS_DK + d] * 0.25f;       // 1 / sqrt(16)
+            acc[d] = 0.f;
+        }
+        float den = 0.f;
+        for (int j = 0; j < U; ++j) {
+            const float* kj = Ks + j * Dh + h * NRMS_DK;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < NRMS_DK; ++d) s += q[d] * kj[d];
+            float e = __expf(s);
+            if (use_mask) e *= mask[(int64_t)b * U + j];
+            den += e;
+            const float* vj = Vs + j * Dh + h * NRMS_DK;
+#pragma unroll
+            for (int d = 0; d < NRMS_DK; ++d) acc[d] += e * vj[d];
+        }
+        const float inv = 1.f / (den + 1e-8f);
+        float* o = ctx + ((int64_t)z * ctx_rows + (int64_t)b * U + i) * Dh + h * NRMS_DK;
+#pragma unroll
+        for (int d = 0; d < NRMS_DK; ++d) o[d] = acc[d] * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void nrms_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ mask,
+                                                            int use_mask, const float* __restrict__ dctx,
+                                                            float* __restrict__ dqkv, int U, int NH) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Dh = NH * NRMS_DK;
+    float* A0 = sm;                     // phase A: K        phase B: Q * 0.25
+    float* A1 = sm + U * Dh;            // phase A: V        phase B: dctx
+    float* dens = A1 + U * Dh;          // [U][NH]  sum_j sc_ij + 1e-8
+    float* rs = dens + U * NH;          // [U][NH]  sum_j attn_ij * (dctx_i . v_j)
+    const int b = blockIdx.x;
+    const float* base = qkv + (int64_t)b * U * 3 * Dh;
+    const float* dcb = dctx + (int64_t)b * U * Dh;
+    float* dbase = dqkv + (int64_t)b * U * 3 * Dh;
+    for (int t = threadIdx.x * 4; t < U * Dh; t += 1024) {
+        int u = t / Dh, c = t - u * Dh;
+        *(f32x4*)(A0 + t) = *(const f32x4*)(base + (int64_t)u * 3 * Dh + Dh + c);
+        *(f32x4*)(A1 + t) = *(const f32x4*)(base + (int64_t)u * 3 * Dh + 2 * Dh + c);
+    }
+    __syncthreads();
+    // phase A: per query row -- den_i, r_i, dq_i
+    for (int p = threadIdx.x; p < U * NH; p += 256) {
+        const int i = p / NH, h = p - i * NH;
+        float q[NRMS_DK], dc[NRMS_DK], dq[NRMS_DK];
+#pragma unroll
+        for (int d = 0; d < NRMS_DK; ++d) {
+            q[d] = base[(int64_t)i * 3 * Dh + h * NRMS_DK + d] * 0.25f;
+            dc[d] = dcb[(int64_t)i * Dh + h * NRMS_DK + d];
+            dq[d] = 0.f;
+        }
+        float den = 0.f, t1 = 0.f;
+        for (int j = 0; j < U; ++j) {
+            const float* kj = A0 + j * Dh + h * NRMS_DK;
+            const float* vj = A1 + j * Dh + h * NRMS_DK;
+            float s = 0.f, da = 0.f;
+#pragma unroll
+            for (int d = 0; d < NRMS_DK; ++d) {
+                s += q[d] * kj[d];
+                da += dc[d] * vj[d];
+            }
+            float e = __expf(s);
+            if (use_mask) e *= mask[(int64_t)b * U + j];
+            den += e;
+            t1 += e * da;
+        }
+        den += 1e-8f;
+        const float r = t1 / den;
+        dens[p] = den;
+        rs[p] = r;
+        for (int j = 0; j < U; ++j) {
+            const float* kj = A0 + j * Dh + h * NRMS_DK;
+            const float* vj = A1 + j * Dh + h * NRMS_DK;
+            float s = 0.f, da = 0.f;
+#pragma unroll
+            for (int d = 0; d < NRMS_DK; ++d) {
+                s += q[d] * kj[d];
+                da += dc[d] * vj[d];
+            }
+            float e = __expf(s);
+            if (use_mask) e *= mask[(int64_t)b * U + j];
+            const float ds = (da - r) / den * e * 0.25f;
+#pragma unroll
+            for (int d = 0; d < NRMS_DK; ++d) dq[d] += ds * kj[d];
+        }
+        float* o = dbase + (int64_t)i * 3 * Dh + h * NRMS_DK;
+#pragma unroll
+        for (int d = 0; d < NRMS_DK; ++d) o[d] = dq[d];
+    }
+    __syncthreads();
+    // phase B: per key column -- dk_j, dv_j
+    for (int t = threadIdx.x * 4; t < U * Dh; t += 1024) {
+        int u = t / Dh, c = t - u * Dh;
+        f32x4 qv = *(const f32x4*)(base + (int64_t)u * 3 * Dh + c);
+        *(f32x4*)(A0 + t) = qv * 0.25f;
+        *(f32x4*)(A1 + t) = *(const f32x4*)(dcb + (int64_t)u * Dh + c);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < U * NH; p += 256) {
+        const int j = p / NH, h = p - j * NH;
+        float k[NRMS_DK], v[NRMS_DK], dk[NRMS_DK], dv[NRMS_DK];
+#pragma unroll
+        for (int d = 0; d < NRMS_DK; ++d) {
+            k[d] = base[(int64_t)j * 3 * Dh + Dh + h * NRMS_DK + d];
+            v[d] = base[(int64_t)j * 3 * Dh + 2 * Dh + h * NRMS_DK + d];
+            dk[d] = 0.f;
+            dv[d] = 0.f;
+        }
+        const float mj = use_mask ? mask[(int64_t)b * U + j] : 1.f;
+        for (int i = 0; i < U; ++i) {
+            const float* qi = A0 + i * Dh + h * NRMS_DK;
+            const float* di = A1 + i * Dh + h * NRMS_DK;
+            float s = 0.f, da = 0.f;
+#pragma unroll
+            for (int d = 0; d < NRMS_DK; ++d) {
+                s += qi[d] * k[d];
+                da += di[d] * v[d];
+            }
+            const float e = __expf(s) * mj;
+            const float den = dens[i * NH + h];
+            const float a = e / den;
+            const float ds = (da - rs[i * NH + h]) / den * e;       // d score (before the 1/4): qi already carries 1/4
+#pragma unroll
+            for (int d = 0; d < NRMS_DK; ++d) {
+                dk[d] += ds * qi[d];
+                dv[d] += a * di[d];
+            }
+        }
+        float* ok = dbase + (int64_t)j * 3 * Dh + Dh + h * NRMS_DK;
+        float* ov = dbase + (int64_t)j * 3 * Dh + 2 * Dh + h * NRMS_DK;
+#pragma unroll
+        for (int d = 0; d < NRMS_DK; ++d) {
+            ok[d] = dk[d];
+            ov[d] = dv[d];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // score-level KD losses (model_bert.py:271, 286-298): one thread per impression, fixed-order block sum
 __global__ __launch_bounds__(256) void kd_score_loss_kernel(const float* __restrict__ s_score,
                                                             const float* __restrict__ t_score,
@@ -684,6 +891,65 @@ extern "C" int tnr_user_bwd_post(const float* dhv, const float* alpha, const flo
     hipLaunchKernelGGL(user_bwd_post_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dhv, alpha, duser, mask,
                        hidx, user_log_mask, dvec, part, U, D, Q);
     TNR_CHECK_LAUNCH("tnr_user_bwd_post");
+    return TNR_OK;
+}
+
+extern "C" int tnr_user_blend_fwd(const float* vec, int64_t R, const int32_t* hidx, const float* mask, const float* pad,
+                                  int user_log_mask, float* hv, int n_model, int B, int U, int D, void* stream) {
+    TNR_CHECK_ARG(vec && hidx && mask && pad && hv && n_model >= 1 && B >= 1 && U >= 1 && D >= 4 && (D % 4) == 0,
+                  "tnr_user_blend_fwd: bad argument");
+    int64_t total = (int64_t)B * U * (D / 4);
+    hipLaunchKernelGGL(user_blend_fwd_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)n_model), dim3(256), 0,
+                       (hipStream_t)stream, vec, R, hidx, mask, pad, user_log_mask, hv, B, U, D);
+    TNR_CHECK_LAUNCH("tnr_user_blend_fwd");
+    return TNR_OK;
+}
+
+extern "C" int tnr_user_blend_bwd(const float* dhv, const float* mask, const int32_t* hidx, int user_log_mask, float* dvec,
+                                  float* pad_part, int64_t part_stride, int B, int U, int D, void* stream) {
+    TNR_CHECK_ARG(dhv && mask && hidx && dvec && pad_part && B >= 1 && U >= 1 && D >= 1 && part_stride >= D,
+                  "tnr_user_blend_bwd: bad argument");
+    hipLaunchKernelGGL(user_blend_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dhv, mask, hidx,
+                       user_log_mask, dvec, pad_part, part_stride, U, D);
+    TNR_CHECK_LAUNCH("tnr_user_blend_bwd");
+    return TNR_OK;
+}
+
+static int nrms_lds_ok(int U, int NH, size_t* lds, bool bwd) {
+    *lds = sizeof(float) * ((size_t)2 * U * NH * NRMS_DK + (bwd ? (size_t)2 * U * NH : 0));
+    return U >= 1 && NH >= 1 && *lds <= 160 * 1024;
+}
+
+extern "C" int tnr_nrms_attn_fwd(const float* qkv, const float* mask, int use_mask, float* ctx, int64_t ctx_rows, int n_model,
+                                 int B, int U, int n_heads, void* stream) {
+    size_t lds;
+    TNR_CHECK_ARG(qkv && ctx && (!use_mask || mask) && n_model >= 1 && B >= 1 && ctx_rows >= (int64_t)B * U,
+                  "tnr_nrms_attn_fwd: bad argument");
+    TNR_CHECK_ARG(nrms_lds_ok(U, n_heads, &lds, false), "tnr_nrms_attn_fwd: U * heads * 16 too large for LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)nrms_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nrms_attn_fwd_kernel, dim3((unsigned)B, (unsigned)n_model), dim3(256), lds, (hipStream_t)stream, qkv,
+                       mask, use_mask, ctx, ctx_rows, B, U, n_heads);
+    TNR_CHECK_LAUNCH("tnr_nrms_attn_fwd");
+    return TNR_OK;
+}
+
+extern "C" int tnr_nrms_attn_bwd(const float* qkv, const float* mask, int use_mask, const float* dctx, float* dqkv, int B,
+                                 int U, int n_heads, void* stream) {
+    size_t lds;
+    TNR_CHECK_ARG(qkv && dctx && dqkv && (!use_mask || mask) && B >= 1, "tnr_nrms_attn_bwd: bad argument");
+    TNR_CHECK_ARG(nrms_lds_ok(U, n_heads, &lds, true), "tnr_nrms_attn_bwd: U * heads * 16 too large for LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)nrms_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nrms_attn_bwd_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, qkv, mask, use_mask, dctx,
+                       dqkv, U, n_heads);
+    TNR_CHECK_LAUNCH("tnr_nrms_attn_bwd");
     return TNR_OK;
 }
 

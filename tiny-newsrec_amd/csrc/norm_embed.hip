@@ -323,6 +323,36 @@ __global__ void cast_b2f_kernel(const bf16* __restrict__ s, float* __restrict__ 
     if (i < n) d[i] = (float)s[i];
 }
 
+
+// NewsEncoder pooling other than 'att' (model_bert.py:130-135): 'cls' = hidden state of token 0, otherwise the mean
+// over ALL L positions (padding included, as torch.mean(word_vecs, dim=1)).  One workgroup per sequence.
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16* __restrict__ y, float* __restrict__ nv, int L, int H,
+                                                       int mean) {
+    const int64_t n = blockIdx.x;
+    for (int c = threadIdx.x * 4; c < H; c += 1024) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int rows = mean ? L : 1;
+        for (int i = 0; i < rows; ++i) {
+            bf16x4 v = *(const bf16x4*)(y + (n * L + i) * H + c);
+            a += (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        }
+        if (mean) a *= 1.0f / (float)L;
+        *(f32x4*)(nv + n * H + c) = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dnv, bf16* __restrict__ dy, int L, int H,
+                                                       int mean) {
+    const int64_t n = blockIdx.x;
+    for (int c = threadIdx.x * 4; c < H; c += 1024) {
+        f32x4 g = *(const f32x4*)(dnv + n * H + c);
+        if (mean) g *= 1.0f / (float)L;
+        bf16x4 o = (bf16x4){(bf16)g[0], (bf16)g[1], (bf16)g[2], (bf16)g[3]};
+        bf16x4 zero = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        for (int i = 0; i < L; ++i) *(bf16x4*)(dy + (n * L + i) * H + c) = (mean || i == 0) ? o : zero;
+    }
+}
+
 }  // namespace
 
 #ifndef TNR_BUILD_F16
@@ -367,6 +397,21 @@ extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed)(const int32_t* news_combined, 
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     TNR_CHECK_LAUNCH("tnr_embed_ln_fwd_indexed");
+    return TNR_OK;
+}
+
+extern "C" int TNR_NAME(tnr_pool_fwd)(const void* y, float* nv, int64_t n_seq, int L, int H, int mean, void* stream) {
+    TNR_CHECK_ARG(y && nv && n_seq >= 1 && L >= 1 && H >= 4 && (H % 4) == 0, "tnr_pool_fwd: bad argument");
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, nv, L, H,
+                       mean);
+    TNR_CHECK_LAUNCH("tnr_pool_fwd");
+    return TNR_OK;
+}
+
+extern "C" int TNR_NAME(tnr_pool_bwd)(const float* dnv, void* dy, int64_t n_seq, int L, int H, int mean, void* stream) {
+    TNR_CHECK_ARG(dnv && dy && n_seq >= 1 && L >= 1 && H >= 4 && (H % 4) == 0, "tnr_pool_bwd: bad argument");
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, dnv, (bf16*)dy, L, H, mean);
+    TNR_CHECK_LAUNCH("tnr_pool_bwd");
     return TNR_OK;
 }
 

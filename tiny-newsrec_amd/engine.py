@@ -29,10 +29,15 @@ class EngineConfig:
     def __init__(self, n_layers=4, trainable_layers=(2, 3), hidden=768, heads=12, inter=3072, news_dim=256,
                  news_query=200, user_query=200, num_teachers=4, user_log_length=50, npratio=4, num_words=30,
                  user_log_mask=False, temperature=1.0, coef=0.2, vocab=30522, max_pos=512, type_vocab=2,
-                 ln_eps=1e-12, stage1=False):
+                 ln_eps=1e-12, stage1=False, pooling="att", nrms_heads=0):
         """stage1=True: the DistillModel of Post-train_KD.ipynb (no user encoders: parameters are
         student.news_encoder.* and transform_matrix.* only; user_log_length is 0, npratio+1 titles per body)."""
         self.stage1 = stage1
+        # args.pooling (model_bert.py:130-135): 'att' | 'cls' | anything else = mean ; args.model == 'NRMS' puts a
+        # nrms_heads x 16 self-attention in front of every user encoder's pooling (model_bert.py:145-148)
+        self.pooling = pooling if pooling in ("att", "cls") else "mean"
+        self.nrms_heads = int(nrms_heads)
+        assert not self.nrms_heads or self.nrms_heads * 16 == news_dim, "NRMS: num_attention_heads * 16 must equal news_dim (scorer bmm)"
         self.n_layers, self.trainable_layers = n_layers, tuple(sorted(trainable_layers))
         self.H, self.A, self.I, self.D = hidden, heads, inter, news_dim
         self.Qn, self.Qu, self.T = news_query, user_query, num_teachers
@@ -43,6 +48,10 @@ class EngineConfig:
         assert hidden % 256 == 0 and inter % 128 == 0 and news_dim % 4 == 0 and news_query <= QPAD
         assert 1 <= num_words <= 512, "attention kernels cover sequences of up to 512 tokens"
         assert all(0 <= l < n_layers for l in self.trainable_layers)
+
+
+NRMS_W = ["multi_head_self_attn.W_%s.weight" % n for n in "QKV"]      # stacked [W_Q; W_K; W_V] (3D, D) per encoder
+NRMS_B = ["multi_head_self_attn.W_%s.bias" % n for n in "QKV"]
 
 
 def layer_param_order(l):
@@ -60,6 +69,13 @@ def param_shapes(cfg):
     """state_dict schema of model_bert.Model, in the engine's storage order."""
     H, I, D, T_ = cfg.H, cfg.I, cfg.D, cfg.T
     s = {}
+    if cfg.nrms_heads and not cfg.stage1:
+        for i in range(T_):
+            for n in NRMS_W:
+                s["teachers.%d.%s" % (i, n)] = (D, D)
+        for i in range(T_):
+            for n in NRMS_B:
+                s["teachers.%d.%s" % (i, n)] = (D,)
     for i in range(0 if cfg.stage1 else T_):
         s["teachers.%d.attn.att_fc1.weight" % i] = (cfg.Qu, D)
     for i in range(0 if cfg.stage1 else T_):
@@ -93,12 +109,18 @@ def param_shapes(cfg):
     s[PFX + "bert_model.classifier.weight"] = (2, H)
     s[PFX + "bert_model.classifier.bias"] = (2,)
     # heads: order = order in which their gradients complete / are laid out by the kernels
-    s[PFX + "attn.att_fc1.weight"] = (cfg.Qn, H)
-    s[PFX + "attn.att_fc1.bias"] = (cfg.Qn,)
-    s[PFX + "attn.att_fc2.weight"] = (1, cfg.Qn)
-    s[PFX + "attn.att_fc2.bias"] = (1,)
+    if cfg.pooling == "att":
+        s[PFX + "attn.att_fc1.weight"] = (cfg.Qn, H)
+        s[PFX + "attn.att_fc1.bias"] = (cfg.Qn,)
+        s[PFX + "attn.att_fc2.weight"] = (1, cfg.Qn)
+        s[PFX + "attn.att_fc2.bias"] = (1,)
     s[PFX + "dense.weight"] = (D, H)
     s[PFX + "dense.bias"] = (D,)
+    if cfg.nrms_heads and not cfg.stage1:
+        for n in NRMS_W:
+            s["student.user_encoder." + n] = (D, D)
+        for n in NRMS_B:
+            s["student.user_encoder." + n] = (D,)
     if not cfg.stage1:
         s["student.user_encoder.attn.att_fc1.weight"] = (cfg.Qu, D)
         s["student.user_encoder.attn.att_fc1.bias"] = (cfg.Qu,)
@@ -200,6 +222,9 @@ class Engine:
         T_ = cfg.T
         tstack = lambda suffix: ["teachers.%d.%s" % (i, suffix) for i in range(T_)]
         groups = []
+        if T_ and cfg.nrms_heads and not cfg.stage1:
+            groups.append((["teachers.%d.%s" % (i, n) for i in range(T_) for n in NRMS_W], None))
+            groups.append((["teachers.%d.%s" % (i, n) for i in range(T_) for n in NRMS_B], None))
         if T_ and not cfg.stage1:
             for suffix in ("attn.att_fc1.weight", "attn.att_fc1.bias", "attn.att_fc2.weight", "pad_doc", "attn.att_fc2.bias"):
                 groups.append((tstack(suffix), None))
@@ -215,11 +240,17 @@ class Engine:
         for k in (BERT + "pooler.dense.weight", BERT + "pooler.dense.bias", BERT + "rel_pos_bias.weight",
                   PFX + "bert_model.classifier.weight", PFX + "bert_model.classifier.bias"):
             groups.append(([k], None))
-        groups.append(([PFX + "attn.att_fc1.weight"], QPAD * cfg.H))     # rows Qn..QPAD stay zero
-        groups.append(([PFX + "attn.att_fc1.bias"], QPAD))
-        for k in ("attn.att_fc2.weight", "attn.att_fc2.bias", "dense.weight", "dense.bias"):
+        if cfg.pooling == "att":
+            groups.append(([PFX + "attn.att_fc1.weight"], QPAD * cfg.H))     # rows Qn..QPAD stay zero
+            groups.append(([PFX + "attn.att_fc1.bias"], QPAD))
+            for k in ("attn.att_fc2.weight", "attn.att_fc2.bias"):
+                groups.append(([PFX + k], None))
+        for k in ("dense.weight", "dense.bias"):
             groups.append(([PFX + k], None))
         ue = "student.user_encoder."
+        if cfg.nrms_heads and not cfg.stage1:
+            groups.append(([ue + n for n in NRMS_W], None))
+            groups.append(([ue + n for n in NRMS_B], None))
         if not cfg.stage1:
             groups.append(([ue + "attn.att_fc1.weight", ue + "attn.att_fc1.bias", ue + "attn.att_fc2.weight", ue + "pad_doc",
                             ue + "attn.att_fc2.bias"], None))
@@ -310,7 +341,7 @@ class Engine:
             self.sh.append(d)
         self.sh_a1 = torch.zeros((QPAD, H), device=dev, dtype=bf)
         self.sh_a1T = torch.zeros((H, QPAD), device=dev, dtype=bf)
-        self.b_a1 = self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,))
+        self.b_a1 = self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,)) if cfg.pooling == "att" else None
 
         def table(layers, with_heads):
             rows = []
@@ -321,7 +352,7 @@ class Engine:
                 rows.append((self.p(names[6]), H, H, d["o"], H, d.get("oT"), H))
                 rows.append((self.p(names[10]), I, H, d["w1"], H, d.get("w1T"), I))
                 rows.append((self.p(names[12]), H, I, d["w2"], I, d.get("w2T"), H))
-            if with_heads:
+            if with_heads and cfg.pooling == "att":
                 rows.append((self.p(PFX + "attn.att_fc1.weight"), cfg.Qn, H, self.sh_a1, H, self.sh_a1T, QPAD))
             desc, start, tot = [], [0], 0
             for src, r, c, dst, ld, dstT, ldT in rows:
@@ -393,6 +424,14 @@ class Engine:
         self.kd_part = f(Rt)
         self.user_part = f(B, T.query("tnr_user_bwd_part_stride", D, cfg.Qu))     # [b1 | w2 | pad | b2] per impression
         self.hv_u, self.dhv_u, self.dpre_u = f(B * cfg.U, D), f(B * cfg.U, D), f(B * cfg.U, cfg.Qu)
+        if cfg.nrms_heads:
+            BU, BC = B * cfg.U, B * cfg.C
+            mk = lambda nm: (f(nm, BU, D), f(nm, BU, 3 * D), f(nm, BU + BC, D))          # blended rows, q|k|v, [ctx | candidates]
+            self.nr_s, self.nr_t = mk(1), mk(T_)
+            self.nr_dctx, self.nr_dqkv, self.nr_dhv = f(BU, D), f(BU, 3 * D), f(BU, D)
+            self.ones_mask = torch.ones((B, cfg.U), device=dev)
+            self.hpos = torch.arange(BU, device=dev, dtype=torch.int32).view(B, cfg.U)
+            self.cpos = (BU + torch.arange(max(BC, 1), device=dev, dtype=torch.int32))[:BC].view(B, cfg.C)
         # backward buffers
         self.dnv = f(N, H)
         self.dy, self.dy2 = z(Mp, H), z(Mp, H)
@@ -405,6 +444,7 @@ class Engine:
         self.ln_part1 = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
         self.red = {}                                                      # gradient bucket -> _ReduceBatch
         self.cs_part = f(max(T.query("tnr_colsum_part_elems", Mp, 3 * H if L > 32 else QPAD),
+                             T.query("tnr_colsum_part_elems", max(B * cfg.U, 1), 3 * D),
                              T_ * T.query("tnr_colsum_part_elems", Rt, D)))
         self.gcs_part = f(T.query("tnr_gemm_colsum_rows", Mp), I)        # b1 gradient partials from the dgrad epilogue
         self.qkvb_part = f(N, 3 * H)                                       # q/k/v bias gradient partials from attention bwd
@@ -412,7 +452,7 @@ class Engine:
         self.epre_u = f(B * cfg.U, cfg.Qu)
         self.epre_t = f(T_, B * cfg.U, cfg.Qu)
         self.KS = 8                                                        # split-K of the long-K small GEMMs
-        self.sg_part = f(self.KS * max(T_ * D * D, D * H))
+        self.sg_part = f(self.KS * max(T_ * D * D, D * H, 3 * D * D))
         self.ws = f(max(self._wgrad_splits(n_, k_)[1] for n_, k_ in ((3 * H, H), (H, H), (I, H), (H, I), (QPAD, H))))
         self._rel_stale = True       # filled by the first encode() (no kernel launch at construction time)
 
@@ -485,10 +525,13 @@ class Engine:
             self._c("tnr_ln_fwd", a["ypre"], g(names[14]), g(names[15]), cfg.ln_eps, y, a["st2"], M, H)
             x = y
         self.y_last = x
-        # AttentionPooling (no mask) + dense  model_bert.py:133-136
-        self._gemm(x, self.sh_a1, self.e, M, bias=self.b_a1, flags=T.EPI_BIAS | T.EPI_TANH | T.EPI_OUTF32)
-        self._c("tnr_attpool_fwd", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
-               self.nv, self.alpha, self.den, n_seq, L, H)
+        # pooling (model_bert.py:130-135: AttentionPooling without mask | token 0 | mean) + dense (:136)
+        if cfg.pooling == "att":
+            self._gemm(x, self.sh_a1, self.e, M, bias=self.b_a1, flags=T.EPI_BIAS | T.EPI_TANH | T.EPI_OUTF32)
+            self._c("tnr_attpool_fwd", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
+                   self.nv, self.alpha, self.den, n_seq, L, H)
+        else:
+            self._c("tnr_pool_fwd", x, self.nv, n_seq, L, H, int(cfg.pooling == "mean"))
         wd = g(PFX + "dense.weight")
         dst = self.S if out is None else out
         self._sgemm(self.nv, H, 1, 0, wd, H, 1, 0, dst, cfg.D, 0, g(PFX + "dense.bias"), 0, n_seq, cfg.D, H)
@@ -519,14 +562,10 @@ class Engine:
         rows = self.X[0, :B * U]                                   # scratch: gathered history rows
         T.call("tnr_gather_rows", news_scoring, news_scoring.shape[0], hist_idx.reshape(-1).contiguous(), B * U, D, 1, rows,
                B * U, 0)
-        self._sgemm(rows, D, 1, 0, g(ue + "attn.att_fc1.weight"), D, 1, 0, self.epre_u, Qu, 0, g(ue + "attn.att_fc1.bias"), 0,
-                    B * U, Qu, D)
         hidx = self.hidx[:B]
         mask = history_mask.to(torch.float32).contiguous()
-        T.call("tnr_user_score_fwd", rows, B * U, hidx, hidx, mask, g(ue + "pad_doc"), g(ue + "attn.att_fc1.weight"),
-               g(ue + "attn.att_fc1.bias"), g(ue + "attn.att_fc2.weight"), g(ue + "attn.att_fc2.bias"),
-               int(cfg.user_log_mask), self.epre_u, self.dS, B * D, self.score, self.e_u, self.alpha_u, self.den_u, 1, B, U, 0,
-               D, Qu)
+        self._user_forward(rows, B * U, 1, self._user_params(ue, 1), hidx, hidx, mask, self.epre_u, self.dS, B * D, self.score,
+                           self.e_u, self.alpha_u, self.den_u, B, 0, getattr(self, "nr_s", None))
         return self.dS[:B].clone()
 
     def _prepare(self, B):
@@ -576,15 +615,10 @@ class Engine:
             self.encode(tok, N)
         S = self.S[:Rt]
         hidx, cidx = self._idx(B)
-        ue = "student.user_encoder."
         g = self.p
         Qu = cfg.Qu
-        self._sgemm(S, D, 1, 0, g(ue + "attn.att_fc1.weight"), D, 1, 0, self.epre_u, Qu, 0, g(ue + "attn.att_fc1.bias"), 0,
-                    B * U, Qu, D)
-        T.call("tnr_user_score_fwd", S, Rt, hidx, cidx, self.mask, g(ue + "pad_doc"), g(ue + "attn.att_fc1.weight"),
-               g(ue + "attn.att_fc1.bias"), g(ue + "attn.att_fc2.weight"), g(ue + "attn.att_fc2.bias"),
-               int(cfg.user_log_mask), self.epre_u, S[N:], B * D, self.score, self.e_u, self.alpha_u, self.den_u, 1, B, U, C,
-               D, Qu)
+        self._user_forward(S, Rt, 1, self._user_params("student.user_encoder.", 1), hidx, cidx, self.mask, self.epre_u, S[N:],
+                           B * D, self.score, self.e_u, self.alpha_u, self.den_u, B, C, getattr(self, "nr_s", None))
         if T_ > 0:
             X = self.X[:, :Rt]
             if teacher_tables is not None:
@@ -594,15 +628,9 @@ class Engine:
                 for i in range(T_):
                     self.X[i, :B * U].copy_(teacher_hist[i].reshape(B * U, D))
                     self.X[i, B * U:N].copy_(teacher_cand[i].reshape(B * C, D))
-            w1 = self._view("teachers.0.attn.att_fc1.weight", T_ * Qu * D, (T_, Qu, D))
-            b1 = self._view("teachers.0.attn.att_fc1.bias", T_ * Qu, (T_, Qu))
-            self._sgemm(self.X, D, 1, self.X.stride(0), w1, D, 1, Qu * D, self.epre_t, Qu, B * U * Qu, b1, Qu, B * U, Qu, D,
-                        batch=T_)
-            T.call("tnr_user_score_fwd", self.X, self.X.shape[1], hidx, cidx, self.mask,
-                   self._view("teachers.0.pad_doc", T_ * D, (T_, D)), w1, b1,
-                   self._view("teachers.0.attn.att_fc2.weight", T_ * Qu, (T_, Qu)),
-                   self._view("teachers.0.attn.att_fc2.bias", T_, (T_,)), int(cfg.user_log_mask), self.epre_t,
-                   self.X[0, N:], self.X.stride(0), self.t_score, self.e_t, self.alpha_t, self.den_t, T_, B, U, C, D, Qu)
+            self._user_forward(self.X, self.X.shape[1], T_, self._user_params("teachers.0.", T_), hidx, cidx, self.mask,
+                               self.epre_t, self.X[0, N:], self.X.stride(0), self.t_score, self.e_t, self.alpha_t, self.den_t,
+                               B, C, getattr(self, "nr_t", None))
         T.call("tnr_kd_score_loss", self.score, self.t_score if T_ else None, self.label, cfg.temperature, cfg.coef,
                self.tw if T_ else None, self.dscore, self.losses, B, C, T_)
         if T_ > 0:
@@ -615,6 +643,43 @@ class Engine:
             self.dS[:Rt].zero_()
             self.losses[2:3].zero_()
         return self.losses, self.score[:B]
+
+    def _user_params(self, first, nm):
+        """Stacked parameter views of `nm` user encoders whose first member has prefix `first`."""
+        cfg = self.cfg
+        D, Qu = cfg.D, cfg.Qu
+        v = lambda suffix, per, shape: self._view(first + suffix, nm * per, (nm,) + shape)
+        p = dict(pad=v("pad_doc", D, (D,)), w1=v("attn.att_fc1.weight", Qu * D, (Qu, D)), b1=v("attn.att_fc1.bias", Qu, (Qu,)),
+                 w2=v("attn.att_fc2.weight", Qu, (Qu,)), b2=v("attn.att_fc2.bias", 1, ()))
+        if cfg.nrms_heads:
+            p["wqkv"] = v(NRMS_W[0], 3 * D * D, (3 * D, D))
+            p["bqkv"] = v(NRMS_B[0], 3 * D, (3 * D,))
+        return p
+
+    def _user_forward(self, vec, R, nm, p, hidx, cidx, mask, epre, user, user_stride, score, e, alpha, den, B, C, nr):
+        """UserEncoder.forward (model_bert.py:155-176) + scorer bmm for `nm` stacked encoders over the row tables
+        vec (nm, R, D): history rows hidx (B,U), candidate rows cidx (B,C)."""
+        cfg = self.cfg
+        U, D, Qu, ulm = cfg.U, cfg.D, cfg.Qu, int(cfg.user_log_mask)
+        if not cfg.nrms_heads:
+            sv = vec.stride(0) if vec.dim() == 3 else 0
+            self._sgemm(vec, D, 1, sv, p["w1"], D, 1, Qu * D, epre, Qu, B * U * Qu, p["b1"], Qu, B * U, Qu, D, batch=nm)
+            T.call("tnr_user_score_fwd", vec, R, hidx, cidx, mask, p["pad"], p["w1"], p["b1"], p["w2"], p["b2"], ulm, epre,
+                   user, user_stride, score, e, alpha, den, nm, B, U, C, D, Qu)
+            return
+        # NRMS (:162-164, :171-173): blend -> self-attention over the clicked news -> additive pooling of its output
+        hv, qkv, ctx = nr
+        BU = B * U
+        T.call("tnr_user_blend_fwd", vec, R, hidx, mask, p["pad"], ulm, hv, nm, B, U, D)
+        self._sgemm(hv, D, 1, hv.stride(0), p["wqkv"], D, 1, 3 * D * D, qkv, 3 * D, qkv.stride(0), p["bqkv"], 3 * D, BU, 3 * D, D,
+                    batch=nm)
+        T.call("tnr_nrms_attn_fwd", qkv, mask, ulm, ctx, ctx.shape[1], nm, B, U, cfg.nrms_heads)
+        if C:
+            T.call("tnr_gather_rows", vec, R, cidx.reshape(-1), B * C, D, nm, ctx, ctx.shape[1], BU)
+        self._sgemm(ctx, D, 1, ctx.stride(0), p["w1"], D, 1, Qu * D, epre, Qu, BU * Qu, p["b1"], Qu, BU, Qu, D, batch=nm)
+        # the pooling sees the attention output as it is: no blend (done above), mask only under user_log_mask
+        T.call("tnr_user_score_fwd", ctx, ctx.shape[1], self.hpos[:B], self.cpos[:B], mask if ulm else self.ones_mask[:B], p["pad"],
+               p["w1"], p["b1"], p["w2"], p["b2"], 1, epre, user, user_stride, score, e, alpha, den, nm, B, U, C, D, Qu)
 
     def _idx(self, B):
         assert B == self.B_alloc
@@ -640,16 +705,34 @@ class Engine:
         # scorer + user encoder
         T.call("tnr_score_bwd", S, cidx, S[N:], self.dscore, dS, dS[N:], B, C, D)
         ue = "student.user_encoder."
-        Qu = cfg.Qu
+        Qu, ulm = cfg.Qu, int(cfg.user_log_mask)
         w1u = g(ue + "attn.att_fc1.weight")
-        T.call("tnr_user_bwd_pre", S, hidx, self.mask, g(ue + "pad_doc"), g(ue + "attn.att_fc2.weight"),
-               int(cfg.user_log_mask), dS[N:], self.e_u, self.alpha_u, self.hv_u, self.dpre_u, self.user_part, B, U, D, Qu)
+        nrms = bool(cfg.nrms_heads)
+        # pooling backward: over the history rows themselves, or (NRMS) over the self-attention output
+        pv, ph, pm, pu, pd = (S, hidx, self.mask, ulm, dS) if not nrms else \
+            (self.nr_s[2][0], self.hpos, self.mask if ulm else self.ones_mask, 1, self.nr_dctx)
+        T.call("tnr_user_bwd_pre", pv, ph, pm, g(ue + "pad_doc"), g(ue + "attn.att_fc2.weight"), pu, dS[N:], self.e_u,
+               self.alpha_u, self.hv_u, self.dpre_u, self.user_part, B, U, D, Qu)
         # dW1 = dpre^T hv (straight into the gradient) ; dhv = dpre W1      -- fp32 MFMA GEMMs
         self._sgemm(self.dpre_u, 1, Qu, 0, self.hv_u, 1, D, 0, self.grads[ue + "attn.att_fc1.weight"], D, 0, None, 0,
                     Qu, D, B * U, ksplit=self.KS)
         self._sgemm(self.dpre_u, Qu, 1, 0, w1u, 1, D, 0, self.dhv_u, D, 0, None, 0, B * U, D, Qu)
-        T.call("tnr_user_bwd_post", self.dhv_u, self.alpha_u, dS[N:], self.mask, hidx, int(cfg.user_log_mask), dS,
-               self.user_part, B, U, D, Qu)
+        if nrms:
+            pd.zero_()
+        T.call("tnr_user_bwd_post", self.dhv_u, self.alpha_u, dS[N:], pm, ph, pu, pd, self.user_part, B, U, D, Qu)
+        if nrms:
+            # self-attention backward (model_bert.py:62-100), then the blend in front of it
+            hv, qkv, _ = self.nr_s
+            BU = B * U
+            T.call("tnr_nrms_attn_bwd", qkv, self.mask, ulm, self.nr_dctx, self.nr_dqkv, B, U, cfg.nrms_heads)
+            wqkv = self._view(ue + NRMS_W[0], 3 * D * D, (3 * D, D))
+            self._sgemm(self.nr_dqkv, 1, 3 * D, 0, hv, 1, D, 0, self._view(ue + NRMS_W[0], 3 * D * D, (3 * D, D), grad=True), D, 0,
+                        None, 0, 3 * D, D, BU, ksplit=self.KS)
+            self._c("tnr_colsum", self.nr_dqkv, 3 * D, T.F32, BU, 3 * D, self._view(ue + NRMS_B[0], 3 * D, (3 * D,), grad=True),
+                    self.cs_part, 0)
+            self._sgemm(self.nr_dqkv, 3 * D, 1, 0, wqkv, 1, D, 0, self.nr_dhv, D, 0, None, 0, BU, D, 3 * D)
+            T.call("tnr_user_blend_bwd", self.nr_dhv, self.mask, hidx, ulm, dS, self.user_part[:, 2 * Qu:], self.user_part.shape[1],
+                   B, U, D)
         ps = self.user_part.shape[1]
         rb = self.red.setdefault(("heads", 0, N if self.plan is None else self.plan.n_enc), _ReduceBatch(self.dev))
         rb.add(self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.bias", ps, (ps,), grad=True))
@@ -684,18 +767,23 @@ class Engine:
         self._c("tnr_colsum", dvec, D, T.F32, N, D, gr[PFX + "dense.bias"], self.cs_part, acc)
         self._sgemm(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D, alpha=self.gscale)   # loss scale enters here
         y = self.y_last
-        self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
-               self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
-        rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], acc)
-        rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], acc)
-        rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), acc)
+        if cfg.pooling == "att":
+            self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
+                   self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
+            rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], acc)
+            rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], acc)
+            rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), acc)
         rb.flush()
-        self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M, acc)
+        if cfg.pooling == "att":
+            self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M, acc)
         if after_bucket:
             after_bucket(0)
         if not cfg.trainable_layers:
             return
-        self._gemm(self.dpre, self.sh_a1T, self.dy, M, res=self.dy2, flags=T.EPI_RES)
+        if cfg.pooling == "att":
+            self._gemm(self.dpre, self.sh_a1T, self.dy, M, res=self.dy2, flags=T.EPI_RES)
+        else:
+            self._c("tnr_pool_bwd", self.dnv, self.dy, N, L, H, int(cfg.pooling == "mean"))
         dy = self.dy
         bucket = 1
         for l in range(cfg.n_layers - 1, self.lo - 1, -1):
@@ -755,7 +843,7 @@ class Engine:
 
     def bucket_ranges(self):
         """Contiguous [start, end) slices of flat_g in the order their gradients complete."""
-        out = [(self.off(PFX + "attn.att_fc1.weight"), self.n_train)]
+        out = [(self.off(PFX + ("attn.att_fc1.weight" if self.cfg.pooling == "att" else "dense.weight")), self.n_train)]
         for l in sorted(self.cfg.trainable_layers, reverse=True):
             names = layer_param_order(l)
             s = self.off(names[0])

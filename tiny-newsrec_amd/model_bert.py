@@ -24,9 +24,6 @@ def engine_config_from_args(args, num_teachers=None, is_teacher=False):
             cfg = json.load(f)
     except (OSError, TypeError, ValueError):
         pass
-    if getattr(args, "pooling", "att") != "att" or getattr(args, "model", "NAML") == "NRMS":
-        raise NotImplementedError("HIP path covers pooling='att' and the NAML user encoder (demo.sh); "
-                                  "cls/mean pooling and NRMS are SURVEY section 8-f N4")
     nl = args.num_teacher_layers if is_teacher else args.num_student_layers
     T_ = args.num_teachers if num_teachers is None else num_teachers
     return E.EngineConfig(
@@ -36,7 +33,8 @@ def engine_config_from_args(args, num_teachers=None, is_teacher=False):
         num_teachers=T_, user_log_length=args.user_log_length, npratio=args.npratio, num_words=args.num_words_title,
         user_log_mask=args.user_log_mask, temperature=args.temperature, coef=args.coef, vocab=cfg.get("vocab_size", 30522),
         max_pos=cfg.get("max_position_embeddings", 512), type_vocab=cfg.get("type_vocab_size", 2),
-        ln_eps=cfg.get("layer_norm_eps", 1e-12))
+        ln_eps=cfg.get("layer_norm_eps", 1e-12), pooling=getattr(args, "pooling", "att"),
+        nrms_heads=getattr(args, "num_attention_heads", 0) if getattr(args, "model", "NAML") == "NRMS" else 0)
 
 
 class _Backward(torch.autograd.Function):
@@ -108,10 +106,10 @@ class Model(_Shell):
                     t.normal_(0.0, 0.02, generator=gen)
             elif k.endswith("pad_doc"):
                 t.uniform_(-1.0, 1.0, generator=gen)
-            elif k.startswith("transform_matrix."):
-                if k.endswith("bias"):
+            elif k.startswith("transform_matrix.") or ("multi_head_self_attn" in k and k.endswith("weight")):
+                if k.endswith("bias"):                         # transform_matrix only (:260); MHSA biases keep the default
                     t.zero_()
-                else:
+                else:                                          # Xavier-uniform (:81, :259)
                     b = (6.0 / (p.shape[0] + p.shape[1])) ** 0.5
                     t.uniform_(-b, b, generator=gen)
             else:                                              # nn.Linear default; the bias uses its weight's fan_in

@@ -29,6 +29,8 @@ _SIG = {
     "tnr_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "tnr_ln_bwd_part_elems": [_L, _I],
     "tnr_ln_bwd_blocks": [_L],
+    "tnr_pool_fwd": [_P, _P, _L, _I, _I, _I, _P],
+    "tnr_pool_bwd": [_P, _P, _L, _I, _I, _I, _P],
     "tnr_attn_l32_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "tnr_attn_l32_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "tnr_attn_long_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
@@ -45,6 +47,10 @@ _SIG = {
     "tnr_user_bwd_pre": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tnr_user_bwd_post": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "tnr_user_bwd_part_stride": [_I, _I],
+    "tnr_user_blend_fwd": [_P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "tnr_user_blend_bwd": [_P, _P, _P, _I, _P, _P, _L, _I, _I, _I, _P],
+    "tnr_nrms_attn_fwd": [_P, _P, _I, _P, _L, _I, _I, _I, _I, _P],
+    "tnr_nrms_attn_bwd": [_P, _P, _I, _P, _P, _I, _I, _I, _P],
     "tnr_score_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "tnr_kd_score_loss": [_P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _P],
     "tnr_kd_embed_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -59,7 +65,7 @@ _SIG = {
 TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_colsum_rows",
          "tnr_gemm_tn_wgrad", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd",
          "tnr_colsum", "tnr_colsum_batched", "tnr_attpool_fwd", "tnr_attpool_bwd", "tnr_refresh_shadows",
-         "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32"]
+         "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32", "tnr_pool_fwd", "tnr_pool_bwd"]
 for _n in TYPED:
     _SIG[_n + "_f16"] = _SIG[_n]
 _RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_gemm_tn_ws_elems_f16": _L, "tnr_gemm_colsum_rows_f16": _L, "tnr_gemm_colsum_rows": _L, "tnr_ln_bwd_part_elems": _L, "tnr_ln_bwd_blocks": _L, "tnr_colsum_part_elems": _L,
