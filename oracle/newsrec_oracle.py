@@ -433,13 +433,17 @@ def model_fwd(P, cfg, history, history_mask, candidate, label, teacher_hist, tea
         t_scores.append(ts)
         t_losses.append(cross_entropy_rows(ts, label))                              # :288
         projs.append(pr); tus.append(tu); tups.append(tup); Tcat.append(tn)
-    tw = softmax(-np.stack(t_losses, -1), -1)                                       # :292-293
-    ts_mix = np.einsum("bct,bt->bc", np.stack(t_scores, -1), tw).astype(F32)        # :295-297
     tau = F32(cfg["temperature"])
-    pT = softmax(ts_mix / tau, -1)
-    distill = (-(pT * log_softmax(score / tau, -1)).sum(-1)).mean(dtype=F32)        # :208-219
-    NEs, UEs = np.stack(NE, -1), np.stack(UE, -1)
-    emb = (NEs * tw).sum(-1).mean(dtype=F32) + (UEs * tw).sum(-1).mean(dtype=F32)   # :300-303
+    if T:
+        tw = softmax(-np.stack(t_losses, -1), -1)                                       # :292-293
+        ts_mix = np.einsum("bct,bt->bc", np.stack(t_scores, -1), tw).astype(F32)        # :295-297
+        pT = softmax(ts_mix / tau, -1)
+        distill = (-(pT * log_softmax(score / tau, -1)).sum(-1)).mean(dtype=F32)        # :208-219
+        NEs, UEs = np.stack(NE, -1), np.stack(UE, -1)
+        emb = (NEs * tw).sum(-1).mean(dtype=F32) + (UEs * tw).sum(-1).mean(dtype=F32)   # :300-303
+    else:       # no teachers: the PLM-NR objective (PLM-NR/model_bert.py:206), total = coef * CE
+        tw, ts_mix, pT = np.zeros((B, 0), F32), np.zeros_like(score), None
+        distill = emb = F32(0.0)
     total = distill + F32(cfg["coef"]) * target + emb                               # :305
     out = dict(total_loss=F32(total), distill_loss=F32(distill), emb_loss=F32(emb), target_loss=F32(target),
                student_score=score, hist=hist, cand=cand, user=user, teacher_weights=tw,
@@ -462,7 +466,9 @@ def model_bwd(P, cfg, out):
     G = {}
     onehot = np.zeros_like(score)
     onehot[np.arange(B), label] = 1.0
-    dscore = ((softmax(score / tau, -1) - c["pT"]) / tau + coef * (softmax(score, -1) - onehot)) / F32(B)
+    dscore = coef * (softmax(score, -1) - onehot) / F32(B)
+    if c["pT"] is not None:
+        dscore = dscore + (softmax(score / tau, -1) - c["pT"]) / tau / F32(B)
     dS = np.zeros_like(S)
     duser = np.zeros_like(user)
     npos = S.shape[1]
@@ -556,10 +562,17 @@ def distill_bwd(P, cfg, out):
 # --------------------------------------------------------------------------- #
 # PLM-NR ModelBert.forward  (PLM-NR/model_bert.py:187-207): same encoders + CE
 # --------------------------------------------------------------------------- #
-def plmnr_fwd(P, cfg, history, history_mask, candidate, label):
+def plmnr_fwd(P, cfg, history, history_mask, candidate, label, keep=False):
+    """-> (loss, score[, full output incl. cache when keep]).  P uses the Tiny-NewsRec key names (student. prefix):
+    PLM-NR's ModelBert is the same module tree without it."""
     z = model_fwd(P, dict(cfg, temperature=1.0, coef=1.0), history, history_mask, candidate, label, [], [],
-                  keep=False)
-    return z["target_loss"], z["student_score"]
+                  keep=keep)
+    return (z["target_loss"], z["student_score"], z) if keep else (z["target_loss"], z["student_score"])
+
+
+def plmnr_bwd(P, cfg, out):
+    """Gradients of the PLM-NR loss w.r.t. its trainable parameters (PLM-NR/run.py:84-91 freeze policy = A17)."""
+    return model_bwd(P, dict(cfg, temperature=1.0, coef=1.0), out)
 
 
 # --------------------------------------------------------------------------- #

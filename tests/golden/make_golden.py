@@ -238,6 +238,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, "full_model_%d.npz" % k), **rec)
         print("full", k, rec["total"], rec["distill"], rec["emb"], rec["target"])
     golden_variants(R)
+    golden_plmnr()
 
 
 def golden_variants(R):
@@ -367,6 +368,61 @@ def golden_convert(R):
             mb.BertPreTrainedModel.from_pretrained = keep
     np.savez_compressed(os.path.join(HERE, "convert.npz"), **out)
     print("convert.npz:", len(conv), "keys")
+
+
+def golden_plmnr():
+    """BASELINE.json configs[0]/[1]: PLM-NR's ModelBert (PLM-NR/model_bert.py:178-207: same encoders, plain CE) with the
+    freeze policy and the two-learning-rate AMSGrad of PLM-NR/run.py:84-106, two optimiser steps."""
+    R = ref_shim.load_reference("PLM-NR")
+    seed, B, nl, trainable = 41, 2, 2, (0, 1)
+    cfg_json = dict(ref_shim.BASE_CFG, num_hidden_layers=nl)
+    a = ref_shim.make_args(config_name=ref_shim.write_config(cfg_json), num_hidden_layers=nl, batch_size=B)
+    model = R.model_bert.ModelBert(a)
+    sd = model.state_dict()
+    with torch.no_grad():     # same hash weights as the Tiny-NewsRec cases: keys differ by the "student." prefix only
+        for k, v in sd.items():
+            v.copy_(torch.from_numpy(hashinit.init_tensor(seed, "student." + k, tuple(v.shape))))
+    for p in model.news_encoder.bert_model.parameters():
+        p.requires_grad = False
+    for i, layer in enumerate(model.news_encoder.bert_model.bert.encoder.layer):
+        if i in trainable:
+            for p in layer.parameters():
+                p.requires_grad = True
+    inp = make_inputs(seed, B, a.user_log_length, a.npratio + 1, a.num_words_title, cfg_json["vocab_size"], 0, a.news_dim)
+    hist, mask, cand, label = inp[:4]
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    bert = [p for n, p in model.named_parameters() if ".bert_model." in n]
+    rest = [p for n, p in model.named_parameters() if ".bert_model." not in n]
+    lr_bert, lr = 1e-5, 1e-4
+    opt = torch.optim.Adam([{"params": bert, "lr": lr_bert}, {"params": rest, "lr": lr}], amsgrad=True)
+    rec = dict(in_hist=hist, in_mask=mask, in_cand=cand, in_label=label, lrs=np.array([lr_bert, lr]),
+               meta=np.array([seed, B, 0, a.user_log_length, a.npratio + 1, a.num_words_title, a.news_dim,
+                              cfg_json["num_attention_heads"], nl]), trainable=np.array(trainable))
+    names = []
+    for step in range(2):
+        opt.zero_grad()
+        loss, score = model(tt(hist), tt(mask), tt(cand), tt(label))
+        loss.backward()
+        rec["loss%d" % step] = loss.item()
+        rec["score%d" % step] = score.detach().numpy()
+        if step == 0:
+            for n, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                g = p.grad.numpy()
+                names.append(n)
+                rec["gnorm." + n] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                idx, val = grad_samples(seed, n, g)
+                rec["gidx." + n], rec["gval." + n] = idx, val
+        opt.step()
+    rec["grad_names"] = np.array(names)
+    for n in ("news_encoder.dense.weight", "news_encoder.bert_model.bert.encoder.layer.1.output.dense.weight",
+              "user_encoder.attn.att_fc1.weight"):
+        w = dict(model.named_parameters())[n].detach().numpy()
+        idx, val = grad_samples(seed, "w." + n, w)
+        rec["widx." + n], rec["wval." + n] = idx, val            # parameter samples after the two steps
+    np.savez_compressed(os.path.join(HERE, "plmnr_full_0.npz"), **rec)
+    print("plmnr", rec["loss0"], rec["loss1"])
 
 
 def golden_interface():

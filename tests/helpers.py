@@ -126,3 +126,13 @@ def unilm_checkpoint(seed, H, n_layers, A, I, vocab, max_pos):
                        ("output.LayerNorm.weight", (H,)), ("output.LayerNorm.bias", (H,))):
             sd[p + n] = t(p + n, shp)
     return sd
+
+
+def load_plmnr_case(name="plmnr_full_0.npz"):
+    """PLM-NR golden (ModelBert + CE, two-lr AMSGrad) -> (z, P with Tiny-NewsRec key names, cfg, inputs)."""
+    z = np.load(os.path.join(GOLDEN, name))
+    seed, B, T, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
+    P = hashinit.init_state_dict(seed, state_shapes(FULL, nl, D, 0))
+    cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]], user_log_mask=False,
+               temperature=1.0, coef=1.0)
+    return z, P, cfg, (z["in_hist"], z["in_mask"], z["in_cand"], z["in_label"])

@@ -139,3 +139,33 @@ def test_construction_time_init_and_pretrained_import(tmp_path):
     ref, _ = O.news_encoder_fwd(sd, ids, 2, A, None)
     print("imported-encoder max|err| %.3e (|ref| max %.3e)" % (np.abs(got - ref).max(), np.abs(ref).max()))
     assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max() + 1e-5
+
+
+def test_plmnr_modelbert_surface():
+    """PLM-NR/model_bert.py:178-207 + run.py:104-106 on the engine: ModelBert(args)(history, mask, candidate, label) ->
+    (loss, score), keys without the 'student.' prefix, two learning rates."""
+    import model_bert
+    from helpers import load_plmnr_case
+    z, P, cfg, inp = load_plmnr_case()
+    seed, B, _, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
+    args = types.SimpleNamespace(
+        config_name=None, model_name=None, pooling="att", model="NAML", num_hidden_layers=nl, num_teacher_layers=12,
+        num_student_layers=4, bert_trainable_layer=[0, 1], news_dim=D, news_query_vector_dim=200, user_query_vector_dim=200,
+        num_teachers=4, user_log_length=U, npratio=C - 1, num_words_title=L, user_log_mask=False, temperature=1.0, coef=0.2,
+        batch_size=B, num_attention_heads=16)
+    torch.cuda.set_device(0)
+    model = model_bert.ModelBert(args)
+    sd = model.state_dict()
+    assert all(not k.startswith("student.") and not k.startswith("teachers.") for k in sd)
+    assert "news_encoder.bert_model.bert.encoder.layer.1.output.dense.weight" in sd and "user_encoder.pad_doc" in sd
+    model.load_state_dict({k[len("student."):]: torch.from_numpy(v) for k, v in P.items()})
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    opt = model_bert.TnrAdam(model, float(z["lrs"][1]), pretrain_lr=float(z["lrs"][0]))
+    for step in range(2):
+        loss, score = model(t(inp[0]), t(inp[1]), t(inp[2]), t(inp[3]))
+        assert abs(loss.item() - float(z["loss%d" % step])) < 1.6e-2 * max(1.0, float(z["loss%d" % step]))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    w = dict(model.named_parameters())
+    assert w["news_encoder.dense.weight"].grad is not None and w["news_encoder.bert_model.bert.embeddings.word_embeddings.weight"].grad is None

@@ -200,3 +200,56 @@ def test_in_batch_dedup_gives_the_same_step(dtype):
     eng.backward()
     torch.cuda.synchronize()
     assert torch.equal(l0, l2) and all(torch.equal(g0[k], eng.grad(k)) for k in g0)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_plmnr_finetune_steps(dtype):
+    """BASELINE configs[1] shape of work (PLM-NR ModelBert: CE only, no teachers, two learning rates) on the engine:
+    two full training steps against the reference's own run (plmnr_full_0.npz) and the oracle's gradients."""
+    from helpers import load_plmnr_case
+    z, P, cfg, inp = load_plmnr_case()
+    seed, B, _, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
+    ec = E.EngineConfig(n_layers=nl, trainable_layers=cfg["trainable_layers"], num_teachers=0, user_log_length=U, npratio=C - 1,
+                        num_words=L, news_dim=D, user_log_mask=False, temperature=1.0, coef=1.0)
+    eng = E.Engine(ec, DEV, max_batch=B, dtype=dtype)
+    eng.load_state_dict(P)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    hist, mask, cand, label = [t(x) for x in inp]
+    lr_bert, lr = [float(x) for x in z["lrs"]]
+    tol = TOL[dtype]
+    for step in range(2):
+        losses, score = eng.forward(hist, mask, cand, label)
+        torch.cuda.synchronize()
+        loss = float(eng.total_loss().item())
+        ref = float(z["loss%d" % step])
+        serr = np.abs(score.cpu().numpy() - z["score%d" % step]).max()
+        print("\n[plmnr %s step %d] loss %.6f ref %.6f ; score max|err| %.2e (|ref| max %.2f)" %
+              (dtype, step, loss, ref, serr, np.abs(z["score%d" % step]).max()))
+        assert float(losses[0]) == 0.0 and float(losses[2]) == 0.0            # no distillation / embedding terms
+        assert abs(loss - ref) <= tol * max(1.0, abs(ref))
+        assert serr <= tol * max(1.0, np.abs(z["score%d" % step]).max())
+        eng.backward()
+        if step == 0:
+            _, _, out = O.plmnr_fwd(P, cfg, *inp, keep=True)
+            G = O.plmnr_bwd(P, cfg, out)
+            worst = 0.0
+            for k in eng.grads:
+                if k.endswith("self.key.bias") or k.endswith("att_fc2.bias"):
+                    continue
+                got, refg = eng.grad(k).cpu().numpy(), G[k]
+                err = np.sqrt(((got - refg).astype(np.float64) ** 2).sum()) / (np.sqrt((refg.astype(np.float64) ** 2).sum()) + 1e-12)
+                worst = max(worst, err)
+                assert err < GTOL[dtype], "%s: %.3e" % (k, err)
+            print("   worst gradient relative L2 error %.3e" % worst)
+        eng.step(lr, lr_bert=lr_bert)
+    # parameters after two AMSGrad steps with per-group learning rates: each element moved by ~2*lr of ITS group
+    for k in [f[5:] for f in z.files if f.startswith("widx.")]:
+        got = eng.params["student." + k].cpu().numpy().reshape(-1)[z["widx." + k]]
+        rate = lr_bert if ".bert_model." in k else lr
+        before = P["student." + k].reshape(-1)[z["widx." + k]]
+        moved_ref, moved = z["wval." + k] - before, got - before
+        assert np.abs(moved_ref).max() > 0.5 * rate
+        # same direction and size of the update for the (vast majority of) elements whose gradient sign is resolved
+        agree = np.mean(np.abs(moved - moved_ref) < 0.5 * rate)
+        print("   %s: |update| ref %.2e got %.2e ; agreement %.2f" % (k[-40:], np.abs(moved_ref).mean(), np.abs(moved).mean(), agree))
+        assert agree > 0.9, k

@@ -180,3 +180,34 @@ def test_nrms_self_attention_backward_matches_finite_differences():
             for idx in [(0, 0), (17, 5), (31, 31)]:
                 np.testing.assert_allclose(G[name + ".weight"][idx], fd(W[key], idx, lambda: f(x, W, b)), rtol=3e-2, atol=3e-3)
             np.testing.assert_allclose(G[name + ".bias"][3], fd(b[key], 3, lambda: f(x, W, b)), rtol=3e-2, atol=3e-3)
+
+
+def test_plmnr_training_steps_match_reference():
+    """BASELINE configs[0]/[1]: PLM-NR ModelBert (CE only) forward, backward and two AMSGrad steps with the two
+    learning rates of PLM-NR/run.py:104-106, against the reference's own run (tests/golden/plmnr_full_0.npz)."""
+    from helpers import load_plmnr_case
+    z, P, cfg, inp = load_plmnr_case()
+    lr_bert, lr = [float(x) for x in z["lrs"]]
+    state = {}
+    for step in range(2):
+        loss, score, out = O.plmnr_fwd(P, cfg, *inp, keep=True)
+        np.testing.assert_allclose(loss, z["loss%d" % step], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(score, z["score%d" % step], rtol=2e-4, atol=2e-4)
+        G = O.plmnr_bwd(P, cfg, out)
+        if step == 0:
+            names = [str(n) for n in z["grad_names"]]
+            assert set("student." + n for n in names) == set(G)
+            for n in names:
+                g = G["student." + n]
+                if n.endswith("self.key.bias") or n.endswith("att_fc2.bias"):
+                    continue
+                np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), float(z["gnorm." + n]), rtol=1e-3, atol=1e-9)
+                ref = z["gval." + n]
+                np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max() + 1e-10)
+        for k, g in G.items():
+            m, v, vm = state.setdefault(k, [np.zeros_like(P[k]), np.zeros_like(P[k]), np.zeros_like(P[k])])
+            O.amsgrad_step(P[k], g, m, v, vm, step + 1, lr=lr_bert if ".bert_model." in k else lr)
+    for k in [f[5:] for f in z.files if f.startswith("widx.")]:
+        got = P["student." + k].reshape(-1)[z["widx." + k]]
+        # Adam normalises the update to ~lr per element, so parameter samples pin the optimiser semantics tightly
+        np.testing.assert_allclose(got, z["wval." + k], rtol=0, atol=2e-6, err_msg=k)

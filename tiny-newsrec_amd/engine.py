@@ -852,11 +852,17 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ optimiser
-    def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
-        """torch.optim.Adam(amsgrad=True).step() (run.py:134,195) + refresh of the bf16 weight copies."""
+    def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, lr_bert=None):
+        """torch.optim.Adam(amsgrad=True).step() (run.py:134,195) + refresh of the 16-bit weight copies.
+        lr_bert: learning rate of the encoder layers when it differs (PLM-NR/run.py:104-106: {'params': pretrained,
+        'lr': pretrain_lr}, {'params': rest, 'lr': lr})."""
         self.step_count += 1
+        head0 = self.off(PFX + ("attn.att_fc1.weight" if self.cfg.pooling == "att" else "dense.weight"))   # end of the BERT layers
         cut = self.off(PFX + "dense.weight")     # [0, cut): encoder layers + pooling head = gradients carrying the loss scale
-        for lo_, hi_, sc in ((0, cut, grad_scale / self.gscale), (cut, self.n_train, grad_scale)):
-            T.call("tnr_amsgrad_step", self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_],
-                   self.adam_v[lo_:hi_], self.adam_vmax[lo_:hi_], hi_ - lo_, self.step_count, lr, beta1, beta2, eps, sc)
+        lb = lr if lr_bert is None else lr_bert
+        for lo_, hi_, sc, rate in ((0, head0, grad_scale / self.gscale, lb), (head0, cut, grad_scale / self.gscale, lr),
+                                   (cut, self.n_train, grad_scale, lr)):
+            if hi_ > lo_:
+                T.call("tnr_amsgrad_step", self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_],
+                       self.adam_v[lo_:hi_], self.adam_vmax[lo_:hi_], hi_ - lo_, self.step_count, rate, beta1, beta2, eps, sc)
         self.refresh_shadows(all_layers=False)

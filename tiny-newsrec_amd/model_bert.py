@@ -113,7 +113,7 @@ class Model(_Shell):
                     b = (6.0 / (p.shape[0] + p.shape[1])) ** 0.5
                     t.uniform_(-b, b, generator=gen)
             else:                                              # nn.Linear default; the bias uses its weight's fan_in
-                fan_in = p.shape[1] if p.dim() == 2 else self.engine.params[k[:-len("bias")] + "weight"].shape[1]
+                fan_in = p.shape[1] if p.dim() == 2 else self.engine.params[self._engine_key(k[:-len("bias")] + "weight")].shape[1]
                 b = 1.0 / fan_in ** 0.5
                 t.uniform_(-b, b, generator=gen)
             p.copy_(t)
@@ -138,6 +138,9 @@ class Model(_Shell):
         self.engine.refresh_shadows(all_layers=True)
         return missing, unexpected
 
+    def _engine_key(self, name):
+        return name
+
     # reference-compatible views --------------------------------------------------------------------
     def named_trainable(self):
         return [(k, p) for k, p in self.named_parameters() if p.requires_grad]
@@ -145,7 +148,7 @@ class Model(_Shell):
     def _bind_grads(self):
         for k, p in self.named_parameters():
             if p.requires_grad and p.grad is None:
-                p.grad = self.engine.grads[k]      # NB fp16 mode: encoder/pooling grads carry engine.gscale until step()
+                p.grad = self.engine.grads[self._engine_key(k)]      # NB fp16 mode: encoder/pooling grads carry engine.gscale until step()
 
     def load_state_dict(self, sd, strict=True):
         out = super().load_state_dict(sd, strict=strict)
@@ -170,12 +173,45 @@ class Model(_Shell):
         return total, losses[0], losses[2], losses[1], score
 
 
+class ModelBert(Model):
+    """PLM-NR/model_bert.py:178-207 (BASELINE configs[0]/[1]: the teacher / baseline fine-tuning tree): the same news and
+    user encoders with a plain cross-entropy objective,
+        ModelBert(args).forward(history, history_mask, candidate, label) -> (loss, score)
+    and state_dict keys without the "student." prefix (news_encoder.*, user_encoder.*), so PLM-NR checkpoints load
+    directly and what it saves is what Tiny-NewsRec's get_teacher_emb / teacher_ckpts read (run.py:61-70, 382-460).
+    args.num_hidden_layers sizes the encoder (PLM-NR/model_bert.py:109-111)."""
+
+    def __init__(self, args, device=None, max_batch=None):
+        import types
+        a = types.SimpleNamespace(**vars(args))
+        a.num_student_layers = getattr(args, "num_hidden_layers", getattr(args, "num_student_layers", 12))
+        a.num_teachers, a.temperature, a.coef = 0, 1.0, 1.0
+        super().__init__(a, device, max_batch)
+
+    def _adopt(self, engine, prefix):
+        super()._adopt(engine, "student.")           # module tree / parameter names drop the prefix
+
+    def _engine_key(self, name):
+        return "student." + name
+
+    def forward(self, history, history_mask, candidate, label):
+        losses, score = self.engine.forward(history, history_mask, candidate, label)
+        total = _Backward.apply(self._anchor, self, self.engine.total_loss())
+        return total, score
+
+    def forward_indexed(self, news_combined, hist_idx, history_mask, cand_idx, label, plan=None):
+        losses, score = self.engine.forward_indexed(news_combined, hist_idx, history_mask, cand_idx, label, None, plan)
+        total = _Backward.apply(self._anchor, self, self.engine.total_loss())
+        return total, score
+
+
 class TnrAdam:
     """optim.Adam(model.parameters(), lr, amsgrad=True) of run.py:134 on the engine's flat buffers
     (one fused kernel + bf16-copy refresh); zero_grad / step keep the reference's call order (run.py:193-195)."""
 
-    def __init__(self, model, lr, grad_sync=None):
-        self.model, self.lr, self.grad_sync = model, lr, grad_sync
+    def __init__(self, model, lr, grad_sync=None, pretrain_lr=None):
+        """pretrain_lr: PLM-NR/run.py:104-106 - the encoder ("pretrained") parameters step with their own rate."""
+        self.model, self.lr, self.grad_sync, self.pretrain_lr = model, lr, grad_sync, pretrain_lr
 
     def zero_grad(self):
         pass                      # every backward overwrites the whole flat gradient buffer
@@ -185,4 +221,4 @@ class TnrAdam:
         if self.grad_sync is not None:
             self.grad_sync.wait()
             scale = self.grad_sync.scale
-        self.model.engine.step(self.lr, grad_scale=scale)
+        self.model.engine.step(self.lr, grad_scale=scale, lr_bert=self.pretrain_lr)
