@@ -55,30 +55,30 @@ __device__ __forceinline__ void tile_coords(int wg, int nbm, int nbn, int GM, in
     bn = local / gsz;
 }
 
-// erf-GELU / its derivative by linear interpolation in an LDS table over [-8, 8), step 1/128 (2049 nodes, exact
-// values at the nodes; interpolation error <= max|f''| h^2 / 8 ~ 6e-6, the bf16 output rounding is 4e-3 relative).
-// The closed form costs ~35 VALU issue slots per element and made the FFN epilogues VALU-bound (13 us per
-// 256x256 tile); the table costs ~12 slots + one ds_read2_b32.
+// erf-GELU / its derivative from an LDS table over [-8, 8), step 1/128 (2048 intervals), linear interpolation between
+// exact node values.  The table holds the SATURATING factor -- Phi(x) for GELU(x) = x Phi(x), and GELU'(x) itself for
+// the derivative -- so clamping the index is the whole range handling (Phi(-8) = 6e-16, Phi(8) = 1 - 6e-16) and an
+// evaluation is fma, med3, fract, cvt, one 8-byte LDS gather, fma (+ mul): 7 VALU slots.  Interpolation error
+// <= max|Phi''| h^2 / 8 = 1.8e-6 (x |x| <= 8 for GELU), the bf16 output rounding is 4e-3 relative.  The closed form cost
+// ~35 slots per element and made the FFN epilogues VALU-bound (13 us per 256x256 tile).
 constexpr int LUT_N = 2048;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 // node i holds {f(x_i), f(x_i+1) - f(x_i)}: ONE 8-byte gather per element on the 64-bank ds_read_b64 path
 __device__ __forceinline__ void lut_build(f32x2* lut, bool grad) {
     for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
         float x0 = (float)(i - LUT_N / 2) * (1.0f / 128.0f), x1 = (float)(i + 1 - LUT_N / 2) * (1.0f / 128.0f);
-        float a = grad ? gelu_erf_grad(x0) : gelu_erf(x0);
-        float b = grad ? gelu_erf_grad(x1) : gelu_erf(x1);
+        float e;
+        float a = grad ? gelu_erf_grad(x0) : 0.5f * (1.0f + erf_as(x0 * 0.70710678118654752f, e));
+        float b = grad ? gelu_erf_grad(x1) : 0.5f * (1.0f + erf_as(x1 * 0.70710678118654752f, e));
         lut[i] = (f32x2){a, b - a};
     }
 }
 template <bool GRAD>
 __device__ __forceinline__ float lut_eval(const f32x2* lut, float x) {
-    float t = fminf(fmaxf(fmaf(x, 128.0f, (float)(LUT_N / 2)), 0.0f), (float)LUT_N - 0.001f);
-    int i = (int)t;
-    float fr = t - (float)i;
-    f32x2 e = lut[i];
-    float y = fmaf(fr, e[1], e[0]);
-    const float hi = GRAD ? 1.0f : x;           // |x| >= 8: Phi is 0 or 1 to fp32 precision
-    return x >= 8.0f ? hi : (x <= -8.0f ? 0.0f : y);
+    float t = __builtin_amdgcn_fmed3f(fmaf(x, 128.0f, (float)(LUT_N / 2)), 0.0f, (float)LUT_N - 0.001f);
+    f32x2 e = lut[(int)t];
+    float p = fmaf(__builtin_amdgcn_fractf(t), e[1], e[0]);
+    return GRAD ? p : x * p;
 }
 
 // epilogue shared by the NT kernels: lane holds C[m_base + 16 i][n_base + 16 j + r], r = 0..3.
@@ -583,6 +583,28 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
     float cs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    // The residual / pre-activation rows are HBM reads the arithmetic below waits for (an extra 16-bit M x N operand
+    // cost +50 us per 52800x3072 launch with the loads issued where they are used): pass 0's are issued before the
+    // accumulators are staged, pass 1's while pass 0 is being processed.
+    // One prefetched operand per launch (the engine never combines RES with MULDGELU; if both are set the residual
+    // is read where it is used).
+    const bool pre_aux = (flags & TNR_EPI_MULDGELU) != 0;
+    const bool pre_res = !pre_aux && (flags & TNR_EPI_RES) != 0;
+    bf16x8 xx[2][MI];
+    auto issue_loads = [&](int pass) {
+        const int m0 = bm * (2 * PR) + pass * PR;
+        if (pre_aux | pre_res) {
+            const bf16* src = pre_aux ? g.aux : g.res;
+            const int64_t ld = pre_aux ? g.ldaux : g.ldres;
+#pragma unroll
+            for (int it = 0; it < MI; ++it) {
+                int m = m0 + rg + 16 * it;
+                m = m < g.M ? m : g.M - 1;
+                xx[pass][it] = *(const bf16x8*)(src + (int64_t)m * ld + n);
+            }
+        }
+    };
+    issue_loads(0);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                                       // staging area free (K loop / previous pass done)
@@ -595,23 +617,7 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
         }
         __syncthreads();
         const int m0 = bm * (2 * PR) + pass * PR;
-        bf16x8 rr[MI], uu[MI];
-        if (flags & TNR_EPI_RES) {
-#pragma unroll
-            for (int it = 0; it < MI; ++it) {
-                int m = m0 + rg + 16 * it;
-                m = m < g.M ? m : g.M - 1;
-                rr[it] = *(const bf16x8*)(g.res + (int64_t)m * g.ldres + n);
-            }
-        }
-        if (flags & TNR_EPI_MULDGELU) {
-#pragma unroll
-            for (int it = 0; it < MI; ++it) {
-                int m = m0 + rg + 16 * it;
-                m = m < g.M ? m : g.M - 1;
-                uu[it] = *(const bf16x8*)(g.aux + (int64_t)m * g.ldaux + n);
-            }
-        }
+        if (pass == 0) issue_loads(1);
 #pragma unroll
         for (int it = 0; it < MI; ++it) {
             const int row = rg + 16 * it;
@@ -636,11 +642,12 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
             }
             if (flags & TNR_EPI_MULDGELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= lut_eval<true>(lut, (float)uu[it][e]);
+                for (int e = 0; e < 8; ++e) v[e] *= lut_eval<true>(lut, (float)xx[pass][it][e]);
             }
             if (flags & TNR_EPI_RES) {
+                bf16x8 r = pre_res ? xx[pass][it] : *(const bf16x8*)(g.res + (int64_t)m * g.ldres + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rr[it][e];
+                for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
             }
             if (flags & TNR_EPI_OUTF32) {
                 float* c = (float*)g.C + (int64_t)m * g.ldc + n;
