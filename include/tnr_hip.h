@@ -175,10 +175,11 @@ int tnr_segment_sum_rows(const float* src, const int32_t* order, const int32_t* 
  * vec: (n_model, R, D) fp32 row tables ; hidx (B,U) / cidx (B,C) int32 row ids ; mask (B,U) fp32.
  * params are stacked per model: pad (n_model,D), w1 (n_model,Q,D), b1 (n_model,Q), w2 (n_model,Q), b2 (n_model).
  * epre (n_model, B*U, Q) = fc1 pre-activations v W1^T + b1 of every history slot in position order (one batched
- * tnr_sgemm) ; out: user (model z at user + z*user_stride, (B,D)), score (n_model,B,C), saved e (n_model,B,U,Q), alpha (n_model,B,U), den (n_model,B). */
+ * tnr_sgemm) ; epad (n_model, Q) = fc1(pad_doc) of every model, or NULL to have each workgroup compute it ;
+ * out: user (model z at user + z*user_stride, (B,D)), score (n_model,B,C), saved e (n_model,B,U,Q), alpha (n_model,B,U), den (n_model,B). */
 int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const int32_t* cidx, const float* mask,
                        const float* pad, const float* w1, const float* b1, const float* w2, const float* b2,
-                       int user_log_mask, const float* epre, float* user, int64_t user_stride, float* score,
+                       int user_log_mask, const float* epre, const float* epad, float* user, int64_t user_stride, float* score,
                        float* e, float* alpha, float* den, int n_model, int B, int U, int C, int D, int Q, void* stream);
 /* backward of the student's user encoder (model_bert.py:155-176), in two kernels around two fp32 GEMMs the caller
  * issues with tnr_sgemm:

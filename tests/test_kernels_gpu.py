@@ -335,7 +335,8 @@ def test_user_score_fwd_bwd(ulm):
     dv = {k: dev(v) for k, v in pr.items()}
     epre = np.einsum("zrd,zqd->zrq", np.stack([vec[z][hidx.reshape(-1)] for z in range(nm)], 0), pr["w1"]) + pr["b1"][:, None, :]
     T.call("tnr_user_score_fwd", dev(vec), R, dev(hidx), dev(cidx), dev(mask), dv["pad"], dv["w1"], dv["b1"], dv["w2"],
-           dv["b2"], ulm, dev(epre.astype(np.float32)), user, B * D, score, e, alpha, den, nm, B, U, C, D, Q)
+           dv["b2"], ulm, dev(epre.astype(np.float32)), None if ulm else dev((pr["pad"][:, None, :] * pr["w1"]).sum(-1) + pr["b1"]),
+           user, B * D, score, e, alpha, den, nm, B, U, C, D, Q)
     torch.cuda.synchronize()
     caches = []
     for z in range(nm):

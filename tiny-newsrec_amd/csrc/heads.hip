@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
     const float* __restrict__ vec, int64_t R, const int32_t* __restrict__ hidx, const int32_t* __restrict__ cidx,
     const float* __restrict__ mask, const float* __restrict__ pad, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int user_log_mask,
-    const float* __restrict__ epre, float* __restrict__ user, int64_t user_stride, float* __restrict__ score,
-    float* __restrict__ e_out, float* __restrict__ alpha, float* __restrict__ den, int B, int U, int C, int D, int Q) {
+    const float* __restrict__ epre, const float* __restrict__ epad_in, float* __restrict__ user, int64_t user_stride,
+    float* __restrict__ score, float* __restrict__ e_out, float* __restrict__ alpha, float* __restrict__ den, int B, int U,
+    int C, int D, int Q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hv = (float*)smem;                 // [U][D]
     float* es = hv + U * D;                   // [U][Q]
@@ -288,16 +289,19 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
     load_hv<true>(hv, vec, hidx, mask, pad, user_log_mask, U, D, tid);
     __syncthreads();
     if (any_pad) {
-        // fc1(pad_doc): one wave per output row, lanes along D (coalesced 1 KB row reads)
-        for (int q = w; q < Q; q += 4) {
-            const float* wr = w1 + (int64_t)q * D;
-            float s = 0.f;
-            for (int d = lane * 4; d < D; d += 256) {
-                f32x4 wv = *(const f32x4*)(wr + d), pv = *(const f32x4*)(pad + d);
-                s += wv[0] * pv[0] + wv[1] * pv[1] + wv[2] * pv[2] + wv[3] * pv[3];
+        // fc1(pad_doc) depends on the model only: taken from the caller (one M=1 tnr_sgemm per step) when given
+        if (epad_in) {
+            for (int q = tid; q < Q; q += 256) epad[q] = epad_in[(int64_t)z * Q + q];
+        } else {
+            for (int q = tid; q < Q; q += 256) {
+                const float* wr = w1 + (int64_t)q * D;
+                float s = 0.f;
+                for (int d = 0; d < D; d += 4) {
+                    f32x4 wv = *(const f32x4*)(wr + d), pv = *(const f32x4*)(pad + d);
+                    s += wv[0] * pv[0] + wv[1] * pv[1] + wv[2] * pv[2] + wv[3] * pv[3];
+                }
+                epad[q] = s + b1[q];
             }
-            s = wave_sum(s);
-            if (lane == 0) epad[q] = s + b1[q];
         }
         __syncthreads();
     }
@@ -842,7 +846,8 @@ static int user_shape_ok(int B, int U, int C, int D, int Q) {
 
 extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const int32_t* cidx,
                                   const float* mask, const float* pad, const float* w1, const float* b1, const float* w2,
-                                  const float* b2, int user_log_mask, const float* epre, float* user, int64_t user_stride,
+                                  const float* b2, int user_log_mask, const float* epre, const float* epad, float* user,
+                                  int64_t user_stride,
                                   float* score, float* e, float* alpha, float* den, int n_model, int B, int U, int C, int D,
                                   int Q, void* stream) {
     TNR_CHECK_ARG(vec && hidx && cidx && mask && pad && w1 && b1 && w2 && b2 && epre && user && score && e && alpha && den,
@@ -857,7 +862,7 @@ extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hi
         attr_set = true;
     }
     hipLaunchKernelGGL(user_score_fwd_kernel, dim3((unsigned)B, (unsigned)n_model), dim3(256), lds, (hipStream_t)stream,
-                       vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, epre, user, user_stride, score, e, alpha,
+                       vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, epre, epad, user, user_stride, score, e, alpha,
                        den, B, U, C, D, Q);
     TNR_CHECK_LAUNCH("tnr_user_score_fwd");
     return TNR_OK;

@@ -450,6 +450,7 @@ class Engine:
         self.qkvb_part = f(N, 3 * H)                                       # q/k/v bias gradient partials from attention bwd
         self.db1p = f(N, QPAD)
         self.epre_u = f(B * cfg.U, cfg.Qu)
+        self.epad_buf = f(T_ + 1, cfg.Qu)
         self.epre_t = f(T_, B * cfg.U, cfg.Qu)
         self.KS = 8                                                        # split-K of the long-K small GEMMs
         self.sg_part = f(self.KS * max(T_ * D * D, D * H, 3 * D * D))
@@ -664,7 +665,11 @@ class Engine:
         if not cfg.nrms_heads:
             sv = vec.stride(0) if vec.dim() == 3 else 0
             self._sgemm(vec, D, 1, sv, p["w1"], D, 1, Qu * D, epre, Qu, B * U * Qu, p["b1"], Qu, B * U, Qu, D, batch=nm)
-            T.call("tnr_user_score_fwd", vec, R, hidx, cidx, mask, p["pad"], p["w1"], p["b1"], p["w2"], p["b2"], ulm, epre,
+            epad = None
+            if not ulm:        # fc1(pad_doc) once per model instead of once per (impression, model) workgroup
+                epad = self.epad_buf[:nm]
+                self._sgemm(p["pad"], D, 1, D, p["w1"], D, 1, Qu * D, epad, Qu, Qu, p["b1"], Qu, 1, Qu, D, batch=nm)
+            T.call("tnr_user_score_fwd", vec, R, hidx, cidx, mask, p["pad"], p["w1"], p["b1"], p["w2"], p["b2"], ulm, epre, epad,
                    user, user_stride, score, e, alpha, den, nm, B, U, C, D, Qu)
             return
         # NRMS (:162-164, :171-173): blend -> self-attention over the clicked news -> additive pooling of its output
@@ -679,7 +684,7 @@ class Engine:
         self._sgemm(ctx, D, 1, ctx.stride(0), p["w1"], D, 1, Qu * D, epre, Qu, BU * Qu, p["b1"], Qu, BU, Qu, D, batch=nm)
         # the pooling sees the attention output as it is: no blend (done above), mask only under user_log_mask
         T.call("tnr_user_score_fwd", ctx, ctx.shape[1], self.hpos[:B], self.cpos[:B], mask if ulm else self.ones_mask[:B], p["pad"],
-               p["w1"], p["b1"], p["w2"], p["b2"], 1, epre, user, user_stride, score, e, alpha, den, nm, B, U, C, D, Qu)
+               p["w1"], p["b1"], p["w2"], p["b2"], 1, epre, None, user, user_stride, score, e, alpha, den, nm, B, U, C, D, Qu)
 
     def _idx(self, B):
         assert B == self.B_alloc

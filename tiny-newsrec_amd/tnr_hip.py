@@ -43,7 +43,7 @@ _SIG = {
     "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _I, _P, _P],
     "tnr_gather_rows": [_P, _L, _P, _L, _I, _I, _P, _L, _L, _P],
     "tnr_segment_sum_rows": [_P, _P, _P, _L, _I, _P, _P],
-    "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tnr_user_bwd_pre": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tnr_user_bwd_post": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "tnr_user_bwd_part_stride": [_I, _I],
