@@ -240,7 +240,8 @@ int tnr_reduce_multi(const int64_t* desc, int n_blocks, void* stream);
 /* ---- optimiser ------------------------------------------------------------------------------- */
 
 /* torch.optim.Adam(amsgrad=True) (run.py:134) on a flat fp32 parameter buffer ; step = 1-based count.
- * grad_scale multiplies g first (1/world for the data-parallel average, run.py:145-149). */
+ * grad_scale multiplies g first (1/world for the data-parallel average, run.py:145-149).
+ * vmax == NULL: plain Adam (Post-train_KD.ipynb cell 18). */
 int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step,
                      float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 

@@ -1350,7 +1350,12 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (ver == 1 || M <= 128) {
+    // short inputs (stage-1 title / body passes, small eval batches): when the 256x256 grid would leave more than 40 % of
+    // the CUs without a tile, the 128x128 kernel (2 workgroups per CU) spreads the same work four times finer
+    const bool sparse256 = (N % 256) == 0 && ((M + 255) / 256) * (N / 256) * 10 < (int64_t)n_cu * 6 && !(flags & TNR_EPI_COLSUM);
+    static const char* fine_s = getenv("TNR_GEMM_FINE");
+    const bool allow_fine = !fine_s || fine_s[0] != '0';
+    if (ver == 1 || M <= 128 || (sparse256 && allow_fine && ver == 3 && !probe)) {
         int nwg = (int)(((M + 127) / 128) * (N / 128));
         hipLaunchKernelGGL(gemm_nt_kernel, dim3(nwg), dim3(256), 2 * BUF_BYTES, st, g);
     } else if (ver == 2 || (N % 256) != 0) {

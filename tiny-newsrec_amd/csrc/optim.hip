@@ -4,6 +4,7 @@
 
 namespace {
 
+template <bool AMS>
 __global__ __launch_bounds__(256) void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       float* __restrict__ vmax, int64_t n, float lr_c1, float inv_sqrt_c2,
@@ -14,24 +15,26 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(float* __restrict__ p, con
         f32x4 gv = *(const f32x4*)(g + i) * gscale;
         f32x4 mv = *(const f32x4*)(m + i) * b1 + (1.f - b1) * gv;
         f32x4 vv = *(const f32x4*)(v + i) * b2 + (1.f - b2) * gv * gv;
-        f32x4 vm = *(const f32x4*)(vmax + i);
+        f32x4 vm = vv;
+        if (AMS) vm = *(const f32x4*)(vmax + i);
         f32x4 pv = *(const f32x4*)(p + i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            vm[r] = fmaxf(vm[r], vv[r]);
+            if (AMS) vm[r] = fmaxf(vm[r], vv[r]);
             pv[r] -= lr_c1 * (mv[r] / (sqrtf(vm[r]) * inv_sqrt_c2 + eps));
         }
         *(f32x4*)(m + i) = mv;
         *(f32x4*)(v + i) = vv;
-        *(f32x4*)(vmax + i) = vm;
+        if (AMS) *(f32x4*)(vmax + i) = vm;
         *(f32x4*)(p + i) = pv;
     } else {
         for (; i < n; ++i) {
             float gv = g[i] * gscale;
             float mv = m[i] * b1 + (1.f - b1) * gv;
             float vv = v[i] * b2 + (1.f - b2) * gv * gv;
-            float vm = fmaxf(vmax[i], vv);
-            m[i] = mv; v[i] = vv; vmax[i] = vm;
+            float vm = AMS ? fmaxf(vmax[i], vv) : vv;
+            m[i] = mv; v[i] = vv;
+            if (AMS) vmax[i] = vm;
             p[i] -= lr_c1 * (mv / (sqrtf(vm) * inv_sqrt_c2 + eps));
         }
     }
@@ -77,14 +80,18 @@ __global__ __launch_bounds__(256) void refresh_kernel(const int64_t* __restrict_
 #ifndef TNR_BUILD_F16
 extern "C" int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step, float lr,
                                 float beta1, float beta2, float eps, float grad_scale, void* stream) {
-    TNR_CHECK_ARG(p && g && m && v && vmax && n >= 1 && step >= 1, "tnr_amsgrad_step: bad argument");
+    TNR_CHECK_ARG(p && g && m && v && n >= 1 && step >= 1, "tnr_amsgrad_step: bad argument");     // vmax NULL = plain Adam
     TNR_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                       ((uintptr_t)v % 16) == 0 && ((uintptr_t)vmax % 16) == 0, "tnr_amsgrad_step: 16-byte alignment");
     double c1 = 1.0 - pow((double)beta1, step), c2 = 1.0 - pow((double)beta2, step);
     float lr_c1 = (float)((double)lr / c1), inv_sqrt_c2 = (float)(1.0 / sqrt(c2));
     int64_t nthr = (n + 3) / 4;
-    hipLaunchKernelGGL(amsgrad_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                       vmax, n, lr_c1, inv_sqrt_c2, beta1, beta2, eps, grad_scale);
+    if (vmax)
+        hipLaunchKernelGGL(amsgrad_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                           v, vmax, n, lr_c1, inv_sqrt_c2, beta1, beta2, eps, grad_scale);
+    else      // plain Adam (Post-train_KD.ipynb cell 18: optim.Adam without amsgrad)
+        hipLaunchKernelGGL(amsgrad_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                           v, vmax, n, lr_c1, inv_sqrt_c2, beta1, beta2, eps, grad_scale);
     TNR_CHECK_LAUNCH("tnr_amsgrad_step");
     return TNR_OK;
 }

@@ -857,10 +857,10 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ optimiser
-    def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, lr_bert=None):
+    def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, lr_bert=None, amsgrad=True):
         """torch.optim.Adam(amsgrad=True).step() (run.py:134,195) + refresh of the 16-bit weight copies.
         lr_bert: learning rate of the encoder layers when it differs (PLM-NR/run.py:104-106: {'params': pretrained,
-        'lr': pretrain_lr}, {'params': rest, 'lr': lr})."""
+        'lr': pretrain_lr}, {'params': rest, 'lr': lr}).  amsgrad=False: plain Adam (Post-train_KD.ipynb cell 18)."""
         self.step_count += 1
         head0 = self.off(PFX + ("attn.att_fc1.weight" if self.cfg.pooling == "att" else "dense.weight"))   # end of the BERT layers
         cut = self.off(PFX + "dense.weight")     # [0, cut): encoder layers + pooling head = gradients carrying the loss scale
@@ -869,5 +869,6 @@ class Engine:
                                    (cut, self.n_train, grad_scale, lr)):
             if hi_ > lo_:
                 T.call("tnr_amsgrad_step", self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_],
-                       self.adam_v[lo_:hi_], self.adam_vmax[lo_:hi_], hi_ - lo_, self.step_count, rate, beta1, beta2, eps, sc)
+                       self.adam_v[lo_:hi_], self.adam_vmax[lo_:hi_] if amsgrad else None, hi_ - lo_, self.step_count, rate,
+                       beta1, beta2, eps, sc)
         self.refresh_shadows(all_layers=False)

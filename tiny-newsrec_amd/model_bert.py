@@ -37,6 +37,58 @@ def engine_config_from_args(args, num_teachers=None, is_teacher=False):
         nrms_heads=getattr(args, "num_attention_heads", 0) if getattr(args, "model", "NAML") == "NRMS" else 0)
 
 
+@torch.no_grad()
+def reference_init(engine, seed=0):
+    """The reference's construction-time distributions (not its RNG stream) for every parameter of `engine`: bert_model
+    by TuringNLRv3PreTrainedModel._init_weights (tnlrv3/modeling.py:42-52: Linear / Embedding weights N(0, 0.02),
+    LayerNorm (1, 0), Linear biases 0); heads by nn.Linear's default U(+-1/sqrt(fan_in)) for weight and bias
+    (model_bert.py:12-13, 115; UserEncoder :150); pad_doc U(-1, 1) (:151-153); transform_matrix and the NRMS
+    projections Xavier-uniform (:81, :258-260; transform bias 0)."""
+    gen = torch.Generator().manual_seed(int(seed))
+    for k, p in engine.params.items():
+        t = torch.empty(p.shape, dtype=torch.float32)
+        if ".bert_model." in k:
+            if "LayerNorm.weight" in k:
+                t.fill_(1.0)
+            elif k.endswith("bias"):
+                t.zero_()
+            else:
+                t.normal_(0.0, 0.02, generator=gen)
+        elif k.endswith("pad_doc"):
+            t.uniform_(-1.0, 1.0, generator=gen)
+        elif k.startswith("transform_matrix.") or ("multi_head_self_attn" in k and k.endswith("weight")):
+            if k.endswith("bias"):
+                t.zero_()
+            else:
+                b = (6.0 / (p.shape[0] + p.shape[1])) ** 0.5
+                t.uniform_(-b, b, generator=gen)
+        else:                                              # nn.Linear default; the bias uses its weight's fan_in
+            fan_in = p.shape[1] if p.dim() == 2 else engine.params[k[:-len("bias")] + "weight"].shape[1]
+            b = 1.0 / fan_in ** 0.5
+            t.uniform_(-b, b, generator=gen)
+        p.copy_(t)
+    engine.refresh_shadows(all_layers=True)
+
+
+def load_pretrained_into(engine, path, seed=0):
+    """model_class.from_pretrained(args.model_name, config=...) (model_bert.py:114) for the student's encoder of
+    `engine`: convert the unilm2 checkpoint (tnlrv3/convert_state_dict.py), fit the position table, keep the first
+    n_layers layers.  -> (missing, unexpected), or None when there is no checkpoint at `path`."""
+    import os
+    if not path or not os.path.exists(path):
+        return None
+    from tnlrv3 import convert_state_dict as C
+    cfg = engine.cfg
+    wanted = {k: tuple(v.shape) for k, v in engine.params.items()}
+    state, missing, unexpected = C.student_state_from_pretrained(
+        C.read_checkpoint(path), wanted, cfg.n_layers, cfg.max_pos, generator=torch.Generator().manual_seed(int(seed)))
+    with torch.no_grad():
+        for k, v in state.items():
+            engine.params[k].copy_(v)
+    engine.refresh_shadows(all_layers=True)
+    return missing, unexpected
+
+
 class _Backward(torch.autograd.Function):
     """Bridges total_loss.backward() (run.py:194) to Engine.backward()."""
 
@@ -87,56 +139,13 @@ class Model(_Shell):
         self.reset_parameters(getattr(args, "seed", 0) if getattr(args, "seed", None) is not None else 0)
         self.pretrained_report = self.load_pretrained(getattr(args, "model_name", None))
 
-    @torch.no_grad()
     def reset_parameters(self, seed=0):
-        """The reference's construction-time distributions (not its RNG stream): bert_model by
-        TuringNLRv3PreTrainedModel._init_weights (tnlrv3/modeling.py:42-52: Linear / Embedding weights N(0, 0.02),
-        LayerNorm (1, 0), Linear biases 0); heads by nn.Linear's default U(+-1/sqrt(fan_in)) for weight and bias
-        (model_bert.py:12-13, 115; UserEncoder :150); pad_doc U(-1, 1) (:151-153); transform_matrix Xavier-uniform
-        with zero bias (:258-260)."""
-        gen = torch.Generator().manual_seed(int(seed))
-        for k, p in self.named_parameters():
-            t = torch.empty(p.shape, dtype=torch.float32)
-            if ".bert_model." in k:
-                if "LayerNorm.weight" in k:
-                    t.fill_(1.0)
-                elif k.endswith("bias"):
-                    t.zero_()
-                else:
-                    t.normal_(0.0, 0.02, generator=gen)
-            elif k.endswith("pad_doc"):
-                t.uniform_(-1.0, 1.0, generator=gen)
-            elif k.startswith("transform_matrix.") or ("multi_head_self_attn" in k and k.endswith("weight")):
-                if k.endswith("bias"):                         # transform_matrix only (:260); MHSA biases keep the default
-                    t.zero_()
-                else:                                          # Xavier-uniform (:81, :259)
-                    b = (6.0 / (p.shape[0] + p.shape[1])) ** 0.5
-                    t.uniform_(-b, b, generator=gen)
-            else:                                              # nn.Linear default; the bias uses its weight's fan_in
-                fan_in = p.shape[1] if p.dim() == 2 else self.engine.params[self._engine_key(k[:-len("bias")] + "weight")].shape[1]
-                b = 1.0 / fan_in ** 0.5
-                t.uniform_(-b, b, generator=gen)
-            p.copy_(t)
-        self.engine.refresh_shadows(all_layers=True)
+        reference_init(self.engine, seed)
 
     def load_pretrained(self, path):
-        """model_class.from_pretrained(args.model_name, config=...) of model_bert.py:114 for the student's encoder:
-        convert the unilm2 checkpoint (tnlrv3/convert_state_dict.py), fit the position table, keep the first
-        num_student_layers layers.  -> (missing, unexpected) or None when there is no checkpoint at `path`
-        (synthetic / offline runs: the construction-time initialisation stays)."""
-        import os
-        if not path or not os.path.exists(path):
-            return None
-        from tnlrv3 import convert_state_dict as C
-        cfg = self.engine.cfg
-        wanted = {k: tuple(v.shape) for k, v in self.engine.params.items()}
-        state, missing, unexpected = C.student_state_from_pretrained(
-            C.read_checkpoint(path), wanted, cfg.n_layers, cfg.max_pos, generator=torch.Generator().manual_seed(0))
-        with torch.no_grad():
-            for k, v in state.items():
-                self.engine.params[k].copy_(v)
-        self.engine.refresh_shadows(all_layers=True)
-        return missing, unexpected
+        """-> (missing, unexpected) or None when there is no checkpoint at `path` (synthetic / offline runs: the
+        construction-time initialisation stays)."""
+        return load_pretrained_into(self.engine, path)
 
     def _engine_key(self, name):
         return name

@@ -14,9 +14,10 @@ weight copies and own their workspaces.  The title pass writes its gradients, th
 Student rows live in one table S = [B*(1+K) title rows | B body rows], the layout tnr_kd_embed_loss and
 tnr_score_bwd already use in stage 2 with the body vector in the "user" slot.
 
-Trainable set: the engine's (heads + encoder layers in `trainable_layers`); the notebook fine-tunes with plain
-Adam and dropout on every parameter - pass trainable_layers = all layers for its encoder setting.  Not covered yet
-(DESIGN.md "stage 1"): dropout, trainable embeddings, and the non-AMSGrad Adam variant.
+Trainable set = the notebook's (cell 17): heads + transform matrices + encoder layers 2 and 3 of the frozen UniLM
+(`trainable_layers`); optimiser = its plain Adam with two rates (cell 18: 1e-6 for bert_model, 1e-5 for the rest) via
+step(lr, lr_bert, amsgrad=False).  Not covered: the notebook runs the encoder in train() mode, i.e. with the
+UniLM config's dropout (0.1) active; this path has no dropout.
 """
 import torch
 
@@ -52,6 +53,28 @@ class Stage1Engine:
     def shapes(self):
         return self.title.shapes
 
+    def forward_indexed(self, title_table, body_table, idx, label, t_title_tables, t_body_tables):
+        """The same step fed by index (DistillDataset.__getitem__, cell 8, at index level): title_table (n, 2Lt) and
+        body_table (n, 2Lb) int32 token tables and teacher tables (T, n, D) fp32 stay in HBM; idx (B, 1+K) int32 holds the
+        positive document first, then its sampled negatives (the body is the positive's)."""
+        t, b = self.title, self.body
+        cfg = self.cfg_t
+        B = idx.shape[0]
+        C, D, T_ = cfg.C, cfg.D, cfg.T
+        assert idx.shape[1] == C
+        t._prepare(B)
+        b._prepare(B)
+        N, Rt = B * C, B * C + B
+        self.cur = (B, N, Rt)
+        t.label = label.to(torch.int64).contiguous()
+        tidx = idx.reshape(-1).to(torch.int32).contiguous()
+        bidx = idx[:, 0].to(torch.int32).contiguous()
+        b.encode(body_table, B, nidx=bidx, out=t.S[N:])
+        t.encode(title_table, N, nidx=tidx)
+        T.call("tnr_gather_rows", t_title_tables, t_title_tables.shape[1], tidx, N, D, T_, t.X, t.X.shape[1], 0)
+        T.call("tnr_gather_rows", t_body_tables, t_body_tables.shape[1], bidx, B, D, T_, t.X, t.X.shape[1], N)
+        return self._heads(B, N, Rt)
+
     def forward(self, title, body, label, teacher_titles, teacher_bodies):
         """title (B,1+K,2Lt) / body (B,2Lb) int64 [ids | mask]; label (B,); teacher_* lists of (B,1+K,D) / (B,D) fp32
         (or stacked (T,B,1+K,D) / (T,B,D)).  -> (losses [distill, target, emb, -], score (B,1+K))."""
@@ -67,15 +90,23 @@ class Stage1Engine:
         t.label = label.to(torch.int64).contiguous()
         b.tok[:B].copy_(body)
         t.tok[:N].copy_(title.reshape(N, 2 * cfg.L))
-        S = t.S[:Rt]
         b.encode(b.tok[:B], B, out=t.S[N:])                      # cell 12 encodes the bodies first
         t.encode(t.tok[:N], N)
+        for i in range(T_):
+            t.X[i, :N].copy_(teacher_titles[i].reshape(N, D))
+            t.X[i, N:Rt].copy_(teacher_bodies[i].reshape(B, D))
+        return self._heads(B, N, Rt)
+
+    def _heads(self, B, N, Rt):
+        """Scores, teacher weights and the three losses from the student rows S and the teacher rows X."""
+        t = self.title
+        cfg = self.cfg_t
+        C, D, T_ = cfg.C, cfg.D, cfg.T
+        S = t.S[:Rt]
         # score[b, c] = <title_vec[b, c], body_vec[b]>
         t._sgemm(S, D, 1, C * D, S[N:], D, 1, D, t.score, 1, C, None, 0, C, 1, D, batch=B)
         X = t.X
         for i in range(T_):
-            X[i, :N].copy_(teacher_titles[i].reshape(N, D))
-            X[i, N:Rt].copy_(teacher_bodies[i].reshape(B, D))
             t._sgemm(X[i], D, 1, C * D, X[i, N:], D, 1, D, t.t_score[i], 1, C, None, 0, C, 1, D, batch=B)
         T.call("tnr_kd_score_loss", t.score, t.t_score, t.label, 1.0, 1.0, t.tw, t.dscore, t.losses, B, C, T_)
         Wt = t._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
@@ -104,5 +135,6 @@ class Stage1Engine:
     def bucket_ranges(self):
         return self.title.bucket_ranges()
 
-    def step(self, lr, grad_scale=1.0, **kw):
-        self.title.step(lr, grad_scale, **kw)
+    def step(self, lr, grad_scale=1.0, lr_bert=None, amsgrad=False, **kw):
+        """Post-train_KD.ipynb cell 18: optim.Adam([{bert_model, 1e-6}, {rest, 1e-5}]) (plain Adam by default here)."""
+        self.title.step(lr, grad_scale, lr_bert=lr_bert, amsgrad=amsgrad, **kw)

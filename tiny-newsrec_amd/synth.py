@@ -10,8 +10,8 @@ import numpy as np
 import hashinit
 
 
-def news_table(seed, n_news, L, vocab=30522):
-    u = hashinit.hash_normal(seed, "synth.len", (n_news + 1,), std=4.0, mean=14.0)
+def news_table(seed, n_news, L, vocab=30522, mean_len=14.0, std_len=4.0):
+    u = hashinit.hash_normal(seed, "synth.len", (n_news + 1,), std=std_len, mean=mean_len)
     lens = np.clip(np.rint(u), 3, L).astype(np.int64)
     ids = hashinit.hash_randint(seed, "synth.ids", (n_news + 1, L), 1000, vocab)
     pos = np.arange(L)[None, :]
