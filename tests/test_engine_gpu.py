@@ -253,3 +253,59 @@ def test_plmnr_finetune_steps(dtype):
         agree = np.mean(np.abs(moved - moved_ref) < 0.5 * rate)
         print("   %s: |update| ref %.2e got %.2e ; agreement %.2f" % (k[-40:], np.abs(moved_ref).mean(), np.abs(moved).mean(), agree))
         assert agree > 0.9, k
+
+
+def test_frozen_layer_cache_is_bit_identical():
+    """build_frozen_cache: hidden states entering the first trainable layer, computed once per news of the resident table,
+    replace embedding + frozen layers in every step; losses, vectors and gradients must not change by a bit."""
+    import synth
+    from dedup import build_plan
+    z, P, cfg, inp = load_case("full_model_1.npz")          # 4 layers, layers 2 and 3 trainable
+    T_ = len(inp[4])
+    eng, B = _engine_for(cfg, z, T_, "bf16")
+    eng.load_state_dict(P)
+    U, C, L, D = eng.cfg.U, eng.cfg.C, eng.cfg.L, eng.cfg.D
+    n = 300
+    comb = torch.from_numpy(synth.news_table(3, n, L)).to(DEV)
+    tables = torch.from_numpy(synth.teacher_tables(3, T_, n, D)).to(DEV)
+    h, m, c, y = synth.impressions(4, B, n, U, C)
+    t = lambda x: torch.from_numpy(x).to(DEV)
+    args = (comb, t(h), t(m), t(c), t(y), tables)
+    plan = build_plan(h, c).to(DEV)
+    ref = {}
+    for tag, pl in (("plain", None), ("dedup", plan)):
+        l, s = eng.forward_indexed(*args, plan=pl)
+        eng.backward()
+        ref[tag] = (l.clone(), s.clone(), eng.S.clone(), eng.flat_g.clone())
+    assert eng.build_frozen_cache(comb) and eng.fcache[0].shape == (n + 1, L * eng.cfg.H // 2)
+    for tag, pl in (("plain", None), ("dedup", plan)):
+        l, s = eng.forward_indexed(*args, plan=pl)
+        eng.backward()
+        torch.cuda.synchronize()
+        r = ref[tag]
+        assert torch.equal(l, r[0]) and torch.equal(s, r[1]) and torch.equal(eng.S, r[2]) and torch.equal(eng.flat_g, r[3]), tag
+    # the token-level feed does not touch the cache; reloading weights drops it
+    hist, mask, cand, label, th, tc = _dev_inputs(inp)
+    eng.forward(hist, mask, cand, label, th, tc)
+    eng.load_state_dict(P)
+    assert eng.fcache is None
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_news_vectors_do_not_depend_on_the_batch_they_are_in(dtype):
+    """The invariant in-batch de-duplication and the frozen-layer cache rest on (SURVEY appendix iii, here bit-exact): a
+    news encodes to the same bits whatever else is in the pass -- across batch sizes that route the GEMMs to different
+    kernels / tile heights (128x128, 224x256, 256x256), and across positions in the batch."""
+    import synth
+    z, P, cfg, inp = load_case("full_model_1.npz")
+    eng, B = _engine_for(cfg, z, len(inp[4]), dtype)
+    eng.load_state_dict(P)
+    comb = torch.from_numpy(synth.news_table(3, 300, eng.cfg.L)).to(DEV)
+    ids = torch.arange(5, 115, dtype=torch.int32, device=DEV)
+    ref = eng.encode(comb, 110, nidx=ids).clone()
+    for m in (7, 33, 60, 109):
+        got = eng.encode(comb, m, nidx=ids[:m])
+        assert torch.equal(got[:m], ref[:m]), m
+    perm = torch.randperm(110, device=DEV)
+    got = eng.encode(comb, 110, nidx=ids[perm])
+    assert torch.equal(got[:110], ref[perm])

@@ -227,6 +227,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // the same table GELU as the 256x256 kernel: results must not depend on which kernel a launch is routed to
+    f32x2* lut = (f32x2*)(smem + 2 * BUF_BYTES);
+    const bool use_lut = (g.flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) != 0;
+    if (use_lut) lut_build(lut, (g.flags & TNR_EPI_MULDGELU) != 0);
     const int nk = g.K >> 6;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs g) {
     }
 
     nt_epilogue(g, acc, bm * 128 + wm * 64 + (lane & 15), bn * 128 + wn * 64 + (lane >> 4) * 4,
-                nt_load_bias(g, bn * 128 + wn * 64 + (lane >> 4) * 4));
+                nt_load_bias(g, bn * 128 + wn * 64 + (lane >> 4) * 4), use_lut ? lut : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1338,6 +1342,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     static const bool probe = probe_s && probe_s[0] == '1';
     static bool attr_set = false;
     if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + LUT_N * 8);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
@@ -1355,9 +1360,10 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     const bool sparse256 = (N % 256) == 0 && ((M + 255) / 256) * (N / 256) * 10 < (int64_t)n_cu * 6 && !(flags & TNR_EPI_COLSUM);
     static const char* fine_s = getenv("TNR_GEMM_FINE");
     const bool allow_fine = !fine_s || fine_s[0] != '0';
-    if (ver == 1 || M <= 128 || (sparse256 && allow_fine && ver == 3 && !probe)) {
+    const bool odd_gelu = (N % 256) != 0 && (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) && ver != 2;   // v2 has no table GELU
+    if (ver == 1 || M <= 128 || odd_gelu || (sparse256 && allow_fine && ver == 3 && !probe)) {
         int nwg = (int)(((M + 127) / 128) * (N / 128));
-        hipLaunchKernelGGL(gemm_nt_kernel, dim3(nwg), dim3(256), 2 * BUF_BYTES, st, g);
+        hipLaunchKernelGGL(gemm_nt_kernel, dim3(nwg), dim3(256), 2 * BUF_BYTES + LUT_N * 8, st, g);
     } else if (ver == 2 || (N % 256) != 0) {
         int nwg = (int)(((M + 255) / 256) * (N / 128));
         if (probe) hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), RING2, st, g);

@@ -33,6 +33,7 @@ def _flag_table():
           ("teacher_ckpts", str, [], dict(nargs="+")), ("teacher_emb_paths", str, [], dict(nargs="+")),
           # additions (defaults keep the reference behaviour)
           ("resident_tables", _B, True, dict(help="keep news_combined / teacher tables in HBM and ship indices only")),
+          ("cache_frozen_layers", _B, True, dict(help="resident mode: compute the frozen lower encoder layers once per news instead of every step (identical results)")),
           ("dedup_news", _B, True, dict(help="encode each distinct news of a batch once (resident mode; identical results)")),
           ("dtype", str, "bf16", dict(choices=["bf16", "fp16"], help="16-bit activation type of the HIP kernels")),
           ("synthetic", _B, False, dict(help="random-init weights + synthetic MIND-shaped data (no files needed)"))]

@@ -94,6 +94,9 @@ def train(args):
         dev_news, dev_tab = getattr(loader, "dev_news", None), loader.dev_tables
         batches = lambda: iter(loader)
 
+    if args.cache_frozen_layers and dev_news is not None and eng.build_frozen_cache(dev_news):
+        logging.info("[%d] frozen layers 0..%d cached for %d news (%.2f GB)" % (
+            rank, eng.lo - 1, dev_news.shape[0], eng.fcache[0].numel() * 4 / 1e9))
     logging.info("Training...")
     for ep in range(args.start_epoch, args.epochs):
         loss_sum, acc_sum, t0 = torch.zeros((), device="cuda"), torch.zeros((), device="cuda"), time.time()
