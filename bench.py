@@ -230,6 +230,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg_kw, seed)
         print(json.dumps(out), flush=True)
     D.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -830,7 +830,11 @@ class Engine:
             x_in = self.x_in[l]
             # bias gradients ride along: dx column sums from LayerNorm backward, the dgrad epilogue, attention backward;
             # all partial sums of the layer are reduced by one launch at the end (fixed order)
-            rb = self.red.setdefault((l, acc, N), _ReduceBatch(self.dev)) if tr else None
+            # two gradient buckets per layer, in completion order: the FFN block (names[10:16]) is final after the W1
+            # weight gradient, the attention block (names[0:10]) at the end of the layer -- the last all-reduce of a step
+            # (attention block of layer lo) is then a third of a layer instead of a whole one
+            rb = self.red.setdefault((l, acc, N, "ffn"), _ReduceBatch(self.dev)) if tr else None
+            rba = self.red.setdefault((l, acc, N, "att"), _ReduceBatch(self.dev)) if tr else None
             nblk = T.query("tnr_ln_bwd_blocks", M)
             self._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None,
                     self.ln_part if tr else None, M, H)
@@ -843,19 +847,23 @@ class Engine:
             if tr:
                 rb.add(self.gcs_part, self._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], acc)
                 self._wgrad(self.du, a["h1"], gr[names[10]], M, acc)
+                rb.flush()
+                if after_bucket:
+                    after_bucket(bucket)
+                    bucket += 1
             self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
             self._c("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, None, None, None,
                     self.ln_part1 if tr else None, M, H)
             if tr:
-                rb.add(self.ln_part1, nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True), acc)
-                rb.add(self.ln_part1[2 * H:], nblk, 3 * H, H, gr[names[7]], acc)                               # attention.output.dense.bias
+                rba.add(self.ln_part1, nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True), acc)
+                rba.add(self.ln_part1[2 * H:], nblk, 3 * H, H, gr[names[7]], acc)                               # attention.output.dense.bias
                 self._wgrad(self.dh1pre, a["ctx"], gr[names[6]], M, acc)
             self._gemm(self.dh1pre, sh["oT"], self.dctx, M)
             if L <= 32:
                 self._c("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv,
                         self.qkvb_part if tr else None, N, L, cfg.A)
                 if tr:
-                    rb.add(self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc)
+                    rba.add(self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc)
             else:
                 self._c("tnr_attn_long_bwd", a["qkv"], self.mask_add, self.rel, a["ctx"], self.dctx, a["lse"], self.delta,
                         self.dqkv, N, L, cfg.A)
@@ -864,7 +872,7 @@ class Engine:
                             self.cs_part, acc)
             if tr:
                 self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M, acc)
-                rb.flush()
+                rba.flush()
             if l > self.lo:
                 nxt = self.dy2 if dy is self.dy else self.dy
                 self._gemm(self.dqkv, sh["qkvT"], nxt, M, res=self.dh1pre, flags=T.EPI_RES)
@@ -884,9 +892,10 @@ class Engine:
         out = [(self.off(PFX + ("attn.att_fc1.weight" if self.cfg.pooling == "att" else "dense.weight")), self.n_train)]
         for l in sorted(self.cfg.trainable_layers, reverse=True):
             names = layer_param_order(l)
-            s = self.off(names[0])
+            a0, f0 = self.off(names[0]), self.off(names[10])
             e = self.off(names[-1]) + self.slot[names[-1]][2]
-            out.append((s, _rup(e, 64)))
+            out.append((f0, _rup(e, 64)))          # FFN block: intermediate.dense .. output.LayerNorm
+            out.append((a0, f0))                   # attention block: q/k/v .. attention.output.LayerNorm
         return out
 
     # ------------------------------------------------------------------ optimiser

@@ -191,3 +191,5 @@ def train(args):
 if __name__ == "__main__":
     utils.setuplogger()
     train(parse_args())
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()

@@ -221,3 +221,5 @@ if __name__ == "__main__":
     utils.setuplogger()
     args = parse_args()
     {"train": train, "test": test, "get_teacher_emb": get_teacher_emb}[args.mode](args)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
