@@ -451,7 +451,7 @@ class Engine:
         self.qkvb_part = f(N, 3 * H)                                       # q/k/v bias gradient partials from attention bwd
         self.db1p = f(N, QPAD)
         self.epre_u = f(B * cfg.U, cfg.Qu)
-        self.epad_buf = f(T_ + 1, cfg.Qu)
+        self.epad_buf = {1: f(1, cfg.Qu), T_: f(T_, cfg.Qu)}      # student / teachers (these run on different streams)
         self.epre_t = f(T_, B * cfg.U, cfg.Qu)
         self.KS = 8                                                        # split-K of the long-K small GEMMs
         self.sg_part = f(self.KS * max(T_ * D * D, D * H, 3 * D * D))
@@ -630,8 +630,32 @@ class Engine:
         self.cur = (B, N, Rt)
         self.mask = history_mask.to(torch.float32).contiguous()
         self.label = label.to(torch.int64).contiguous()
+        idx = None
+        if news_combined is not None or teacher_tables is not None:
+            idx = torch.cat([t_hidx.reshape(-1), t_cidx.reshape(-1)]).to(torch.int32)
+        self.nidx = idx
+        # teacher side (frozen user encoders over the teachers' rows, projection by the transform matrices): independent of
+        # the student's encoder pass; issued first (optionally on a second stream, TNR_TEACHER_STREAM=1)
+        hidx, cidx = self._idx(B)
+        main = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
+        if T_ > 0:
+            side = self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if teacher_tables is not None:
+                    T.call("tnr_gather_rows", teacher_tables, teacher_tables.shape[1], idx, N, D, T_, self.X, self.X.shape[1], 0)
+                else:
+                    for i in range(T_):
+                        self.X[i, :B * U].copy_(teacher_hist[i].reshape(B * U, D))
+                        self.X[i, B * U:N].copy_(teacher_cand[i].reshape(B * C, D))
+                self._user_forward(self.X, self.X.shape[1], T_, self._user_params("teachers.0.", T_), hidx, cidx, self.mask,
+                                   self.epre_t, self.X[0, N:], self.X.stride(0), self.t_score, self.e_t, self.alpha_t,
+                                   self.den_t, B, C, getattr(self, "nr_t", None))
+                Wt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
+                bt = self._view("transform_matrix.0.bias", T_ * D, (T_, D))
+                self._sgemm(self.X, D, 1, self.X.stride(0), Wt, D, 1, D * D, self.Pm, D, self.Pm.stride(0), bt, D, Rt, D, D,
+                            batch=T_)
         if news_combined is not None:
-            self.nidx = torch.cat([t_hidx.reshape(-1), t_cidx.reshape(-1)]).to(torch.int32)
             self.plan = plan
             if plan is None:
                 self.encode(news_combined, N, nidx=self.nidx)
@@ -648,30 +672,15 @@ class Engine:
             tok[B * U:].copy_(candidate.reshape(B * C, 2 * L))
             self.encode(tok, N)
         S = self.S[:Rt]
-        hidx, cidx = self._idx(B)
         g = self.p
         Qu = cfg.Qu
         self._user_forward(S, Rt, 1, self._user_params("student.user_encoder.", 1), hidx, cidx, self.mask, self.epre_u, S[N:],
                            B * D, self.score, self.e_u, self.alpha_u, self.den_u, B, C, getattr(self, "nr_s", None))
         if T_ > 0:
-            X = self.X[:, :Rt]
-            if teacher_tables is not None:
-                idx = self.nidx if news_combined is not None else torch.cat([t_hidx.reshape(-1), t_cidx.reshape(-1)]).to(torch.int32)
-                T.call("tnr_gather_rows", teacher_tables, teacher_tables.shape[1], idx, N, D, T_, self.X, self.X.shape[1], 0)
-            else:
-                for i in range(T_):
-                    self.X[i, :B * U].copy_(teacher_hist[i].reshape(B * U, D))
-                    self.X[i, B * U:N].copy_(teacher_cand[i].reshape(B * C, D))
-            self._user_forward(self.X, self.X.shape[1], T_, self._user_params("teachers.0.", T_), hidx, cidx, self.mask,
-                               self.epre_t, self.X[0, N:], self.X.stride(0), self.t_score, self.e_t, self.alpha_t, self.den_t,
-                               B, C, getattr(self, "nr_t", None))
+            main.wait_stream(side)
         T.call("tnr_kd_score_loss", self.score, self.t_score if T_ else None, self.label, cfg.temperature, cfg.coef,
                self.tw if T_ else None, self.dscore, self.losses, B, C, T_)
         if T_ > 0:
-            Wt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
-            bt = self._view("transform_matrix.0.bias", T_ * D, (T_, D))
-            self._sgemm(self.X, D, 1, self.X.stride(0), Wt, D, 1, D * D, self.Pm, D, self.Pm.stride(0), bt, D, Rt, D, D,
-                        batch=T_)
             T.call("tnr_kd_embed_loss", S, self.Pm, self.tw, self.losses[2:], self.dS, self.dP, self.kd_part, B, U, C, D, T_)
         else:
             self.dS[:Rt].zero_()
@@ -700,7 +709,7 @@ class Engine:
             self._sgemm(vec, D, 1, sv, p["w1"], D, 1, Qu * D, epre, Qu, B * U * Qu, p["b1"], Qu, B * U, Qu, D, batch=nm)
             epad = None
             if not ulm:        # fc1(pad_doc) once per model instead of once per (impression, model) workgroup
-                epad = self.epad_buf[:nm]
+                epad = self.epad_buf[nm]
                 self._sgemm(p["pad"], D, 1, D, p["w1"], D, 1, Qu * D, epad, Qu, Qu, p["b1"], Qu, 1, Qu, D, batch=nm)
             T.call("tnr_user_score_fwd", vec, R, hidx, cidx, mask, p["pad"], p["w1"], p["b1"], p["w2"], p["b2"], ulm, epre, epad,
                    user, user_stride, score, e, alpha, den, nm, B, U, C, D, Qu)
@@ -718,6 +727,14 @@ class Engine:
         # the pooling sees the attention output as it is: no blend (done above), mask only under user_log_mask
         T.call("tnr_user_score_fwd", ctx, ctx.shape[1], self.hpos[:B], self.cpos[:B], mask if ulm else self.ones_mask[:B], p["pad"],
                p["w1"], p["b1"], p["w2"], p["b2"], 1, epre, None, user, user_stride, score, e, alpha, den, nm, B, U, C, D, Qu)
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            import os
+            # measured on MI355X (A/B on one box): no gain from a real second stream, so it is opt-in
+            self._side = torch.cuda.Stream(device=self.dev) if os.environ.get("TNR_TEACHER_STREAM", "0") == "1" \
+                else torch.cuda.current_stream(self.dev)
+        return self._side
 
     def _idx(self, B):
         assert B == self.B_alloc
