@@ -571,6 +571,20 @@ constexpr int EPI_LD = 256 * 4 + 16;                 // bytes per staged row
 constexpr int EPI_BYTES = 128 * EPI_LD;              // 133,120 B
 constexpr int LDS3_BYTES = EPI_BYTES + LUT_N * 8;
 
+// Streaming (non-temporal) accesses for the epilogue's once-touched operands: C / side-output stores and residual /
+// pre-activation loads otherwise take L2 lines away from the A and B tiles the other workgroups of the XCD are sharing.
+// TNR_GEMM_NT=0 at build time (-DTNR_GEMM_NT=0) restores plain accesses for A/B runs.
+#ifndef TNR_GEMM_NT
+#define TNR_GEMM_NT 1
+#endif
+#if TNR_GEMM_NT
+#define TNR_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#define TNR_NT_LOAD(p) __builtin_nontemporal_load((p))
+#else
+#define TNR_NT_STORE(v, p) (*(p) = (v))
+#define TNR_NT_LOAD(p) (*(p))
+#endif
+
 template <int MI>
 __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&acc)[MI][4], char* smem, const f32x2* lut,
                                                       int bm, int bn, int wm, int wn, int lane) {
@@ -604,7 +618,7 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
             for (int it = 0; it < MI; ++it) {
                 int m = m0 + rg + 16 * it;
                 m = m < g.M ? m : g.M - 1;
-                xx[pass][it] = *(const bf16x8*)(src + (int64_t)m * ld + n);
+                xx[pass][it] = TNR_NT_LOAD((const bf16x8*)(src + (int64_t)m * ld + n));
             }
         }
     };
@@ -634,7 +648,7 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *(bf16x8*)(g.aux + (int64_t)m * g.ldaux + n) = o;
+                TNR_NT_STORE(o, (bf16x8*)(g.aux + (int64_t)m * g.ldaux + n));
             }
             if (flags & TNR_EPI_GELU) {
 #pragma unroll
@@ -655,8 +669,8 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
             }
             if (flags & TNR_EPI_OUTF32) {
                 float* c = (float*)g.C + (int64_t)m * g.ldc + n;
-                *(f32x4*)c = (f32x4){v[0], v[1], v[2], v[3]};
-                *(f32x4*)(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                TNR_NT_STORE(((f32x4){v[0], v[1], v[2], v[3]}), (f32x4*)c);
+                TNR_NT_STORE(((f32x4){v[4], v[5], v[6], v[7]}), (f32x4*)(c + 4));
             } else {
                 bf16x8 o;
 #pragma unroll
@@ -664,7 +678,7 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
                     o[e] = (bf16)v[e];
                     cs[e] += (float)o[e];
                 }
-                *(bf16x8*)((bf16*)g.C + (int64_t)m * g.ldc + n) = o;
+                TNR_NT_STORE(o, (bf16x8*)((bf16*)g.C + (int64_t)m * g.ldc + n));
             }
         }
     }
