@@ -29,6 +29,7 @@ struct NTArgs {
     int flags;
     float* colsum_part;        // TNR_EPI_COLSUM: (rows_of_partials, N) fp32, one row per 64-row strip of C
     int gm;                    // rasterisation group height
+    int nt;                    // 1: streaming (non-temporal) accesses for once-touched epilogue operands
 };
 
 constexpr int TILE_BYTES = 128 * 128;   // one operand tile: 128 rows x 64 bf16
@@ -571,15 +572,15 @@ constexpr int EPI_LD = 256 * 4 + 16;                 // bytes per staged row
 constexpr int EPI_BYTES = 128 * EPI_LD;              // 133,120 B
 constexpr int LDS3_BYTES = EPI_BYTES + LUT_N * 8;
 
-// Streaming (non-temporal) accesses for the epilogue's once-touched operands: C / side-output stores and residual /
-// pre-activation loads otherwise take L2 lines away from the A and B tiles the other workgroups of the XCD are sharing.
-// TNR_GEMM_NT=0 at build time (-DTNR_GEMM_NT=0) restores plain accesses for A/B runs.
+// Optional streaming (non-temporal) accesses for the epilogue's once-touched operands (C / side-output stores, residual /
+// pre-activation loads), env TNR_GEMM_NT=1.  Measured with an interleaved same-box A/B over seven shapes: within +-0.8 %
+// of plain accesses (an earlier "+7 %" was box-to-box variance), so the default is plain.
 #ifndef TNR_GEMM_NT
 #define TNR_GEMM_NT 1
 #endif
 #if TNR_GEMM_NT
-#define TNR_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#define TNR_NT_LOAD(p) __builtin_nontemporal_load((p))
+#define TNR_NT_STORE(v, p) do { if (g.nt) __builtin_nontemporal_store((v), (p)); else *(p) = (v); } while (0)
+#define TNR_NT_LOAD(p) (g.nt ? __builtin_nontemporal_load((p)) : *(p))
 #else
 #define TNR_NT_STORE(v, p) (*(p) = (v))
 #define TNR_NT_LOAD(p) (*(p))
@@ -1339,7 +1340,8 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     TNR_CHECK_ARG(!(flags & TNR_EPI_COLSUM) || (colsum_part && !(flags & TNR_EPI_OUTF32) && M > 128),
                   "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, g_group_m};
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, g_group_m, 0};
+    { const char* nt_s = getenv("TNR_GEMM_NT"); if (nt_s && nt_s[0] == '1') g.nt = 1; }     // A/B switch (read per call)
     static const char* gm_s = getenv("TNR_GEMM_GM");
     if (gm_s) g.gm = atoi(gm_s) > 0 ? atoi(gm_s) : 8;
     static const char* ver_s = getenv("TNR_GEMM_VER");
