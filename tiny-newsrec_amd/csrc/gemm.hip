@@ -586,10 +586,13 @@ constexpr int LDS3_BYTES = EPI_BYTES + LUT_N * 8;
 #define TNR_NT_LOAD(p) (*(p))
 #endif
 
-template <int MI>
-__device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&acc)[MI][4], char* smem, const f32x2* lut,
+// MI x NJ 16x16 accumulator blocks per wave, NTHR threads per workgroup (8 waves of 128x64 or 4 waves of 128x128)
+template <int MI, int NJ = 4, int NTHR = 512>
+__device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&acc)[MI][NJ], char* smem, const f32x2* lut,
                                                       int bm, int bn, int wm, int wn, int lane) {
     constexpr int PR = 16 * MI;          // rows per pass (= rows per wave), tile height 2 * PR
+    constexpr int RG = NTHR / 32;        // row groups working on a pass
+    constexpr int ITER = PR / RG;        // rows per thread and pass
     const int flags = g.flags;
     const int tid = threadIdx.x;
     const int c8 = (tid & 31) * 8, rg = tid >> 5;            // 8 columns, row group 0..15
@@ -609,15 +612,15 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
     // is read where it is used).
     const bool pre_aux = (flags & TNR_EPI_MULDGELU) != 0;
     const bool pre_res = !pre_aux && (flags & TNR_EPI_RES) != 0;
-    bf16x8 xx[2][MI];
+    bf16x8 xx[2][ITER];
     auto issue_loads = [&](int pass) {
         const int m0 = bm * (2 * PR) + pass * PR;
         if (pre_aux | pre_res) {
             const bf16* src = pre_aux ? g.aux : g.res;
             const int64_t ld = pre_aux ? g.ldaux : g.ldres;
 #pragma unroll
-            for (int it = 0; it < MI; ++it) {
-                int m = m0 + rg + 16 * it;
+            for (int it = 0; it < ITER; ++it) {
+                int m = m0 + rg + RG * it;
                 m = m < g.M ? m : g.M - 1;
                 xx[pass][it] = TNR_NT_LOAD((const bf16x8*)(src + (int64_t)m * ld + n));
             }
@@ -631,15 +634,15 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *(f32x4*)(smem + (i * 16 + (lane & 15)) * EPI_LD + (wn * 64 + j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+                for (int j = 0; j < NJ; ++j)
+                    *(f32x4*)(smem + (i * 16 + (lane & 15)) * EPI_LD + (wn * (NJ * 16) + j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
         }
         __syncthreads();
         const int m0 = bm * (2 * PR) + pass * PR;
         if (pass == 0) issue_loads(1);
 #pragma unroll
-        for (int it = 0; it < MI; ++it) {
-            const int row = rg + 16 * it;
+        for (int it = 0; it < ITER; ++it) {
+            const int row = rg + RG * it;
             const int m = m0 + row;
             if (m >= g.M) continue;
             f32x4 v0 = *(const f32x4*)(smem + row * EPI_LD + c8 * 4) + b0;
@@ -686,14 +689,14 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
     if (flags & TNR_EPI_COLSUM) {
         // column sums of the 256-row tile: 16 row groups hold partials for the same 8 columns
         __syncthreads();
-        float* red = (float*)smem;                             // [16][256]
+        float* red = (float*)smem;                             // [RG][256]
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[rg * 256 + c8 + e] = cs[e];
         __syncthreads();
         if (tid < 256) {
             float t = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
+            for (int r = 0; r < RG; ++r) t += red[r * 256 + tid];
             float* pr = g.colsum_part + (int64_t)(bm * 4) * g.N + bn * 256 + tid;   // 4 partial rows per row-tile (v2 layout)
             pr[0] = t;
             pr[g.N] = 0.f;
@@ -786,6 +789,88 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
         }
     }
     nt_epilogue_coalesced<MI>(g, acc, smem, lut, bm, bn, wm, wn, lane);
+}
+
+// ================================================================================================
+// v7: the v3 tile and ring with FOUR waves of 128 x 128 (8 x 8 MFMA blocks each, 256 accumulator registers; one wave per
+// SIMD).  Per K tile the workgroup reads 128 KB of fragments from LDS instead of 192 KB and half as many waves meet at the
+// barrier; the layout of the vendor library's hand-scheduled MT256x256x64 kernel.  TNR_GEMM_VER=7.
+template <int PROBE>
+__global__ __launch_bounds__(256, 1) void gemm_nt256x256_w4_kernel(NTArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MI = 8, NJ = 8;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int nbn = g.N >> 8;
+    const int nbm = (g.M + 255) / 256;
+    const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+    int bm, bn;
+    tile_coords(wg, nbm, nbn, g.gm, bm, bn);
+
+    // 64 pieces of 1 KiB per stage: wave w loads sub-tile w (A rows 0-127 | A 128-255 | B 0-127 | B 128-255), 16 pieces
+    const bf16* src0;
+    int64_t row_stride8;                                        // 8 rows further down
+    {
+        int row = lane >> 3;
+        int chunk = (lane & 7) ^ (row & 7);                     // (row + 8 q) & 7 == row & 7: the swizzle is the same for every piece
+        if (w < 2) {
+            src0 = g.A + chunk * 8;
+            row_stride8 = 8 * g.lda;
+        } else {
+            src0 = g.B + (int64_t)(bn * 256 + (w - 2) * 128 + row) * g.ldb + chunk * 8;
+            row_stride8 = 8 * g.ldb;
+        }
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE3 + w * TILE_BYTES;
+        if (w < 2) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int gm = bm * 256 + w * 128 + q * 8 + (lane >> 3);
+                gm = gm < g.M ? gm : g.M - 1;
+                glds16(src0 + (int64_t)gm * g.lda + kt * 64, base + q * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) glds16(src0 + q * row_stride8 + kt * 64, base + q * 1024);
+        }
+    };
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x2* lut = (f32x2*)(smem + EPI_BYTES);
+    if (g.flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (g.flags & TNR_EPI_MULDGELU) != 0);
+    const int nk = g.K >> 6;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        TNR_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sa = smem + cur * STAGE3 + wm * TILE_BYTES;
+        const char* sb = smem + cur * STAGE3 + (2 + wn) * TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < (PROBE == 1 ? 0 : 2); ++s) {
+            bf16x8 af[MI], bfr[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    nt_epilogue_coalesced<MI, NJ, 256>(g, acc, smem, lut, bm, bn, wm, wn, lane);
 }
 
 // ================================================================================================
@@ -1344,8 +1429,8 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     { const char* nt_s = getenv("TNR_GEMM_NT"); if (nt_s && nt_s[0] == '1') g.nt = 1; }     // A/B switch (read per call)
     static const char* gm_s = getenv("TNR_GEMM_GM");
     if (gm_s) g.gm = atoi(gm_s) > 0 ? atoi(gm_s) : 8;
-    static const char* ver_s = getenv("TNR_GEMM_VER");
-    static const int ver = ver_s ? atoi(ver_s) : 3;   // 5 = persistent variant (A/B: within noise of 3)
+    const char* ver_s = getenv("TNR_GEMM_VER");        // read per call: tools/gemm_ab.py flips it inside one process
+    const int ver = ver_s ? atoi(ver_s) : 3;          // 5 = persistent variant (A/B: within noise of 3)
     static const char* probe_s = getenv("TNR_GEMM_PROBE");
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -1364,6 +1449,8 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_w4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_k32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_k32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
@@ -1384,6 +1471,10 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         int nwg = (int)(((M + 255) / 256) * (N / 128));
         if (probe) hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), RING2, st, g);
         else hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), RING2, st, g);
+    } else if (ver == 7) {
+        const int64_t t256 = ((M + 255) / 256) * (N / 256);
+        if (probe) hipLaunchKernelGGL(gemm_nt256x256_w4_kernel<1>, dim3((int)t256), dim3(256), LDS3_BYTES, st, g);
+        else hipLaunchKernelGGL(gemm_nt256x256_w4_kernel<0>, dim3((int)t256), dim3(256), LDS3_BYTES, st, g);
     } else if (ver == 6) {
         const int64_t t256 = ((M + 255) / 256) * (N / 256);
         if (probe) hipLaunchKernelGGL(gemm_nt256x256_k32_kernel<1>, dim3((int)t256), dim3(512), LDS3_BYTES, st, g);
