@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--dedup", choices=["off", "also", "only"], default="also",
                     help="in-batch news de-duplication (dedup.py): 'also' times it in a second loop and reports it beside "
                          "the headline (which stays un-deduplicated), 'only' makes it the headline")
+    ap.add_argument("--frozen-cache", action="store_true",
+                    help="with --dedup only: also take the frozen lower layers from the per-news cache in the headline loop "
+                         "(run.py's default mode; not the BASELINE workload, which recomputes every layer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -168,6 +171,8 @@ def main():
             dt_cache = timed_loop()
         use_plan[0] = False
         reset()                                  # also drops the cache: the headline recomputes every layer every step
+    if a.dedup == "only" and a.frozen_cache:
+        eng.build_frozen_cache(comb)
     # headline: W untimed warm-up steps, then exactly K timed steps
     for i in range(W):
         one_step(i)
@@ -218,7 +223,7 @@ def main():
         else:
             out["roofline"] = None
         if a.dedup != "off":
-            out["dedup"] = {"in_headline": a.dedup == "only", "distinct_news_frac": round(distinct, 4),
+            out["dedup"] = {"in_headline": a.dedup == "only", "frozen_layer_cache_in_headline": bool(a.dedup == "only" and a.frozen_cache), "distinct_news_frac": round(distinct, 4),
                             "encoded_frac": round(encoded, 4),
                             "note": "identical outputs; FLOPs per impression above stay un-deduplicated (SURVEY 8-d)"}
             if dt_dedup is not None:
