@@ -47,6 +47,8 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // 32/GM of them and each B column slice by GM (measured before: bn-fastest order, 71% L2 hit rate, every
 // workgroup streaming its own B slice from beyond L2).
 __device__ __forceinline__ void tile_coords(int wg, int nbm, int nbn, int GM, int& bm, int& bn) {
+    const bool snake = GM < 0;           // odd row groups walk the column slices backwards (reuse the last B slices)
+    GM = snake ? -GM : GM;
     int per = GM * nbn;
     int grp = wg / per;
     int first = grp * GM;
@@ -54,6 +56,7 @@ __device__ __forceinline__ void tile_coords(int wg, int nbm, int nbn, int GM, in
     int local = wg - grp * per;
     bm = first + local % gsz;
     bn = local / gsz;
+    if (snake && (grp & 1)) bn = nbn - 1 - bn;
 }
 
 // erf-GELU / its derivative from an LDS table over [-8, 8), step 1/128 (2048 intervals), linear interpolation between
@@ -1429,6 +1432,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     { const char* nt_s = getenv("TNR_GEMM_NT"); if (nt_s && nt_s[0] == '1') g.nt = 1; }     // A/B switch (read per call)
     static const char* gm_s = getenv("TNR_GEMM_GM");
     if (gm_s) g.gm = atoi(gm_s) > 0 ? atoi(gm_s) : 8;
+    { const char* sn_s = getenv("TNR_GEMM_SNAKE"); if (sn_s && sn_s[0] == '1') g.gm = -g.gm; }
     const char* ver_s = getenv("TNR_GEMM_VER");        // read per call: tools/gemm_ab.py flips it inside one process
     const int ver = ver_s ? atoi(ver_s) : 3;          // 5 = persistent variant (A/B: within noise of 3)
     static const char* probe_s = getenv("TNR_GEMM_PROBE");
