@@ -309,3 +309,60 @@ def test_news_vectors_do_not_depend_on_the_batch_they_are_in(dtype):
     perm = torch.randperm(110, device=DEV)
     got = eng.encode(comb, 110, nidx=ids[perm])
     assert torch.equal(got[:110], ref[perm])
+
+
+@pytest.mark.parametrize("shape", [dict(B=3, U=13, C=3, L=17, D=64, Q=40, T=2, nl=2, tr=(1,), ulm=True),
+                                   dict(B=1, U=5, C=2, L=32, D=128, Q=200, T=1, nl=1, tr=(0,), ulm=False),
+                                   dict(B=5, U=50, C=5, L=9, D=256, Q=72, T=3, nl=2, tr=(0, 1), ulm=False)])
+def test_odd_shapes_against_oracle(shape):
+    """Shapes away from demo.sh's (row counts that are not multiples of the tile sizes, short / full 32-token titles,
+    other head dimensions): one fp16 training step against the numpy oracle on hash-initialised weights."""
+    import hashinit
+    from helpers import FULL, state_shapes
+    s = shape
+    dims = dict(FULL, Q=s["Q"])
+    P = hashinit.init_state_dict(77, state_shapes(dims, s["nl"], s["D"], s["T"]))
+    cfg = dict(n_layers=s["nl"], heads=12, trainable_layers=list(s["tr"]), user_log_mask=s["ulm"], temperature=1.5, coef=0.3)
+    rs = np.random.RandomState(5)
+    B, U, C, L, D, T_ = s["B"], s["U"], s["C"], s["L"], s["D"], s["T"]
+
+    def toks(n):
+        out = np.zeros((n, 2 * L), np.int64)
+        for r in range(n):
+            k = rs.randint(1, L + 1)
+            out[r, :k] = rs.randint(1, 30522, k)
+            out[r, L:L + k] = 1
+        return out
+    hist, cand = toks(B * U).reshape(B, U, 2 * L), toks(B * C).reshape(B, C, 2 * L)
+    mask = (rs.rand(B, U) > 0.3).astype(np.float32)
+    mask[0, :] = 0 if B > 1 else 1
+    label = rs.randint(0, C, B)
+    th = [rs.randn(B, U, D).astype(np.float32) * 0.3 for _ in range(T_)]
+    tc = [rs.randn(B, C, D).astype(np.float32) * 0.3 for _ in range(T_)]
+    ec = E.EngineConfig(n_layers=s["nl"], trainable_layers=s["tr"], num_teachers=T_, user_log_length=U, npratio=C - 1,
+                        num_words=L, news_dim=D, news_query=s["Q"], user_query=s["Q"], user_log_mask=s["ulm"],
+                        temperature=1.5, coef=0.3)
+    eng = E.Engine(ec, DEV, max_batch=B, dtype="fp16")
+    eng.load_state_dict(P)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    losses, score = eng.forward(t(hist), t(mask), t(cand), t(label), [t(x) for x in th], [t(x) for x in tc])
+    eng.backward()
+    torch.cuda.synchronize()
+    out = O.model_fwd(P, cfg, hist, mask, cand, label, th, tc)
+    G = O.model_bwd(P, cfg, out)
+    ref_l = np.array([out["distill_loss"], out["target_loss"], out["emb_loss"]])
+    assert np.abs(losses[:3].cpu().numpy() - ref_l).max() <= 2e-3 * max(1.0, np.abs(ref_l).max())
+    assert np.abs(score.cpu().numpy() - out["student_score"]).max() <= 2e-3 * max(1.0, np.abs(out["student_score"]).max())
+    worst = 0.0
+    for k in eng.grads:
+        if k.endswith("self.key.bias") or k.endswith("att_fc2.bias"):
+            continue
+        got, ref = eng.grad(k).cpu().numpy(), G[k]
+        rn = np.sqrt((ref.astype(np.float64) ** 2).sum())
+        if rn < 1e-7:
+            assert np.abs(got).max() < 1e-6, k
+            continue
+        err = np.sqrt(((got - ref).astype(np.float64) ** 2).sum()) / rn
+        worst = max(worst, err)
+        assert err < 2e-2, "%s: %.3e (norm %.2e)" % (k, err, rn)
+    print("\n[odd shape %s] worst gradient rel. L2 error %.2e" % (s, worst))
