@@ -521,11 +521,15 @@ def distill_fwd(P, cfg, title, body, label, teacher_titles, teacher_bodies, keep
         pt, pb = linear(tt, W, b).astype(F32), linear(tb, W, b).astype(F32)
         mses.append(((tv - pt) ** 2).mean(-1).mean(-1) + ((bvec - pb) ** 2).mean(-1))
         ptit.append(pt); pbod.append(pb)
-    tw = softmax(-np.stack(t_losses, -1), -1)
-    mix = np.einsum("bct,bt->bc", np.stack(t_scores, -1), tw).astype(F32)
-    pT = softmax(mix, -1)
-    distill = (-(pT * log_softmax(score, -1)).sum(-1)).mean(dtype=F32)
-    emb = (np.stack(mses, -1) * tw).sum(-1).mean(dtype=F32)
+    if T:
+        tw = softmax(-np.stack(t_losses, -1), -1)
+        mix = np.einsum("bct,bt->bc", np.stack(t_scores, -1), tw).astype(F32)
+        pT = softmax(mix, -1)
+        distill = (-(pT * log_softmax(score, -1)).sum(-1)).mean(dtype=F32)
+        emb = (np.stack(mses, -1) * tw).sum(-1).mean(dtype=F32)
+    else:       # no teachers: stage 0, TitleBodySimModel of Domian-specific_Post-train.ipynb cell 11 (plain CE)
+        tw, pT = np.zeros((B, 0), F32), None
+        distill = emb = F32(0.0)
     out = dict(total_loss=F32(target + distill + emb), target_loss=F32(target), distill_loss=F32(distill), emb_loss=F32(emb),
                student_score=score, title_vec=tv, body_vec=bvec, teacher_weights=tw)
     out["cache"] = dict(bc=bc, tc=tc, pT=pT, tw=tw, ptit=ptit, pbod=pbod, label=label, B=B, C=C, D=D,
@@ -539,7 +543,9 @@ def distill_bwd(P, cfg, out):
     score, tv, bvec = out["student_score"], out["title_vec"], out["body_vec"]
     onehot = np.zeros_like(score)
     onehot[np.arange(B), label] = 1.0
-    dscore = ((softmax(score, -1) - c["pT"]) + (softmax(score, -1) - onehot)) / F32(B)
+    dscore = (softmax(score, -1) - onehot) / F32(B)
+    if c["pT"] is not None:
+        dscore = dscore + (softmax(score, -1) - c["pT"]) / F32(B)
     dtv = dscore[:, :, None] * bvec[:, None, :]
     dbv = np.einsum("bc,bcd->bd", dscore, tv)
     G = {}

@@ -239,6 +239,7 @@ def main():
         print("full", k, rec["total"], rec["distill"], rec["emb"], rec["target"])
     golden_variants(R)
     golden_plmnr()
+    golden_stage0(R)
 
 
 def golden_variants(R):
@@ -423,6 +424,58 @@ def golden_plmnr():
         rec["widx." + n], rec["wval." + n] = idx, val            # parameter samples after the two steps
     np.savez_compressed(os.path.join(HERE, "plmnr_full_0.npz"), **rec)
     print("plmnr", rec["loss0"], rec["loss1"])
+
+
+def golden_stage0(R):
+    """Domian-specific_Post-train.ipynb (stage 0: contrastive title/body matching of the teacher): its
+    TitleBodySimModel (cells 10-11) executed as published -- CE over 1+K title scores per body, no teachers."""
+    import json
+    import types
+    nb = json.load(open(os.path.join(ref_shim.REF_ROOT, "Domian-specific_Post-train.ipynb")))
+    cfg_json = dict(ref_shim.BASE_CFG, num_hidden_layers=12)       # the notebook hard-codes 12 layers (cell 10)
+    tmp = os.path.dirname(ref_shim.write_config(cfg_json))
+    os.replace(os.path.join(tmp, "config.json"), os.path.join(tmp, "unilm2-base-uncased-config.json"))
+    ns = dict(torch=torch, nn=torch.nn, np=np, os=os, MODEL_CLASSES=R.utils.MODEL_CLASSES, path_turing=tmp)
+    for i in (10, 11):
+        exec(compile("".join(nb["cells"][i]["source"]), "Domian-specific_Post-train.ipynb cell %d" % i, "exec"), ns)
+    seed, B, C, Lt, Lb, D, vocab = 302, 2, 4, 24, 96, 256, 30522
+    trainable = (9, 10, 11)                                        # cell 14
+    model = ns["TitleBodySimModel"](types.SimpleNamespace(news_dim=D, news_query_vector_dim=200))
+    sd = model.state_dict()
+    with torch.no_grad():     # hash weights under the Tiny-NewsRec key names the build's engine uses
+        for k, v in sd.items():
+            v.copy_(torch.from_numpy(hashinit.init_tensor(seed, "student." + k, tuple(v.shape))))
+    for p in model.news_encoder.bert_model.parameters():
+        p.requires_grad = False
+    for i, layer in enumerate(model.news_encoder.bert_model.bert.encoder.layer):
+        if i in trainable:
+            for p in layer.parameters():
+                p.requires_grad = True
+
+    def toks(tag, n, L):
+        ln = hashinit.hash_randint(seed, tag + "len", (n,), 3, L + 1)
+        ids = hashinit.hash_randint(seed, tag + "ids", (n, L), 1, vocab)
+        m = (np.arange(L)[None, :] < ln[:, None]).astype(np.int64)
+        return np.concatenate([ids * m, m], 1)
+    title = toks("t", B * C, Lt).reshape(B, C, 2 * Lt)
+    body = toks("b", B, Lb)
+    label = hashinit.hash_randint(seed, "lab", (B,), 0, C)
+    t_ = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    score, loss = model(t_(title), t_(body), t_(label))
+    loss.backward()
+    rec = dict(total=loss.item(), score=score.detach().numpy(), in_title=title, in_body=body, in_label=label,
+               meta=np.array([seed, B, 0, C, Lt, Lb, D, 12, 12]), trainable=np.array(trainable))
+    gn = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.numpy()
+        gn.append(k)
+        rec["gnorm." + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        rec["gidx." + k], rec["gval." + k] = grad_samples(seed, k, g)
+    rec["grad_names"] = np.array(gn)
+    np.savez_compressed(os.path.join(HERE, "stage0_full.npz"), **rec)
+    print("stage0", rec["total"], len(gn), "gradients")
 
 
 def golden_interface():

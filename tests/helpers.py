@@ -136,3 +136,13 @@ def load_plmnr_case(name="plmnr_full_0.npz"):
     cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]], user_log_mask=False,
                temperature=1.0, coef=1.0)
     return z, P, cfg, (z["in_hist"], z["in_mask"], z["in_cand"], z["in_label"])
+
+
+def load_stage0_case(name="stage0_full.npz"):
+    """Stage-0 golden (Domian-specific_Post-train.ipynb TitleBodySimModel, 12 layers, CE only) -> (z, P, cfg, inputs)."""
+    z = np.load(os.path.join(GOLDEN, name))
+    seed, B, T, C, Lt, Lb, D, A, nl = [int(x) for x in z["meta"]]
+    shapes = {k: v for k, v in state_shapes(FULL, nl, D, 0).items() if k.startswith("student.news_encoder.")}
+    P = hashinit.init_state_dict(seed, shapes)
+    cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]])
+    return z, P, cfg, (z["in_title"], z["in_body"], z["in_label"], [], [])

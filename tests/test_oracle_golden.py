@@ -211,3 +211,30 @@ def test_plmnr_training_steps_match_reference():
         got = P["student." + k].reshape(-1)[z["widx." + k]]
         # Adam normalises the update to ~lr per element, so parameter samples pin the optimiser semantics tightly
         np.testing.assert_allclose(got, z["wval." + k], rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_stage0_contrastive_post_train_matches_notebook():
+    """Domian-specific_Post-train.ipynb TitleBodySimModel (12 layers, layers 9-11 trainable, CE over 1+K titles).
+    With hash weights twelve layers deep the attention (and the pooling) is close to uniform, so the q / k and pooling-head
+    gradients are ~1e-6 of the others and sit at the fp32 noise of the reference's own autograd (its mathematically-zero
+    key-bias gradient has the same size): errors are judged against the largest gradient entry of the step."""
+    from helpers import load_stage0_case
+    z, P, cfg, inp = load_stage0_case()
+    out = O.distill_fwd(P, cfg, *inp)
+    np.testing.assert_allclose(out["total_loss"], z["total"], rtol=RTOL, atol=ATOL)
+    assert float(out["distill_loss"]) == 0.0 and float(out["emb_loss"]) == 0.0
+    np.testing.assert_allclose(out["student_score"], z["score"], rtol=1e-3, atol=ATOL)
+    G = O.distill_bwd(P, cfg, out)
+    names = [str(n) for n in z["grad_names"]]
+    assert set("student." + n for n in names) == set(G)
+    top = max(float(np.abs(z["gval." + n]).max()) for n in names)
+    top_norm = max(float(z["gnorm." + n]) for n in names)
+    checked = 0
+    for n in names:
+        g = G["student." + n]
+        ref = z["gval." + n]
+        np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-5 * top, err_msg=n)
+        if float(z["gnorm." + n]) > 1e-4 * top_norm:
+            np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), float(z["gnorm." + n]), rtol=1e-3, err_msg=n)
+            checked += 1
+    assert checked >= 36          # every FFN / value / output / LayerNorm / dense gradient of the three trainable layers

@@ -1,5 +1,10 @@
-"""Stage-1 knowledge distillation (title/body matching post-training) as a script: the flow of the reference's
-Post-train_KD.ipynb (cells 2-9 data, 15-19 training) on the HIP engine.
+"""Title/body matching post-training as a script: the flows of the reference's two notebooks on the HIP engine.
+
+  --stage 1 (default)  Post-train_KD.ipynb (cells 2-9 data, 15-19 training): multi-teacher distillation of the student.
+  --stage 0            Domian-specific_Post-train.ipynb: the teacher's own contrastive post-training (TitleBodySimModel,
+                       cells 10-16: 12 layers, layers 9-11 trainable, plain CE, checkpoint every --save_steps steps) and,
+                       with --mode export, its cells 18-22: title / body embeddings of the whole corpus under each of
+                       --ckpt_paths, written as teacher_title_emb_{i}.pkl / teacher_body_emb_{i}.pkl for stage 1.
 
     python post_train_kd.py --corpus_path docs_filter.tsv --teacher_emb_dir . --num_teachers 4 --num_hidden_layers 4
     python -m torch.distributed.run --nproc-per-node 8 ... post_train_kd.py ...        (data-parallel, RCCL)
@@ -28,6 +33,10 @@ import utils
 def parse_args(argv=None):
     b = utils.str2bool
     p = argparse.ArgumentParser()
+    p.add_argument("--stage", type=int, default=1, choices=[0, 1])
+    p.add_argument("--mode", default="train", choices=["train", "export"])
+    p.add_argument("--ckpt_paths", nargs="*", default=[], help="--mode export: checkpoints to embed the corpus with")
+    p.add_argument("--save_steps", type=int, default=500, help="stage 0: checkpoint period (args.T of the notebook)")
     p.add_argument("--corpus_path", default="./docs_filter.tsv")                 # cell 2
     p.add_argument("--teacher_emb_dir", default=".", help="teacher_title_emb_{i}.pkl / teacher_body_emb_{i}.pkl (cell 7)")
     p.add_argument("--num_teachers", type=int, default=4)
@@ -53,7 +62,14 @@ def parse_args(argv=None):
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     p.add_argument("--synthetic", type=b, default=False, help="hash-initialised weights + synthetic corpus / teacher tables")
     p.add_argument("--synthetic_docs", type=int, default=20000)
-    return p.parse_args(argv)
+    a = p.parse_args(argv)
+    if a.stage == 0:                                   # Domian-specific_Post-train.ipynb cells 10, 14
+        a.num_teachers = 0
+        if "--num_hidden_layers" not in (argv or __import__("sys").argv):
+            a.num_hidden_layers = 12
+        if "--bert_trainable_layer" not in (argv or __import__("sys").argv):
+            a.bert_trainable_layer = [9, 10, 11]
+    return a
 
 
 def read_corpus(path):
@@ -112,6 +128,21 @@ def _model_dims(args):
                 news_dim=args.news_dim, news_query=args.news_query_vector_dim)
 
 
+def _ckpt_state(eng, stage):
+    """Checkpoint keys: DistillModel's (student.news_encoder.*, transform_matrix.*) for stage 1, TitleBodySimModel's
+    (news_encoder.*) for stage 0."""
+    sd = {k: v.cpu() for k, v in eng.state_dict().items()}
+    return sd if stage == 1 else {k[len("student."):]: v for k, v in sd.items()}
+
+
+def _load_ckpt(eng, path, stage):
+    sd = torch.load(path, map_location="cpu")
+    sd = sd.get("model_state_dict", sd)
+    if stage == 0:
+        sd = {"student." + k: v for k, v in sd.items()}
+    eng.load_state_dict(sd)
+
+
 def train(args):
     import dist
     from model_bert import load_pretrained_into, reference_init
@@ -126,8 +157,8 @@ def train(args):
         title_tab = synth.news_table(11, n_docs - 1, args.max_title_len)          # (n_docs, 2Lt), row 0 = empty document
         body_tab = synth.news_table(12, n_docs - 1, args.max_body_len, mean_len=0.6 * args.max_body_len,
                                     std_len=0.25 * args.max_body_len)
-        tt = synth.teacher_tables(13, args.num_teachers, n_docs - 1, args.news_dim)
-        tb = synth.teacher_tables(14, args.num_teachers, n_docs - 1, args.news_dim)
+        tt = synth.teacher_tables(13, max(args.num_teachers, 1), n_docs - 1, args.news_dim)
+        tb = synth.teacher_tables(14, max(args.num_teachers, 1), n_docs - 1, args.news_dim)
     else:
         from preprocess import make_tokenizer
         encode = make_tokenizer(args)
@@ -135,7 +166,7 @@ def train(args):
         n_docs = len(titles)
         title_tab = token_table([t.lower() for t in titles], encode, args.max_title_len)
         body_tab = token_table([t.lower() for t in bodies], encode, args.max_body_len)
-        tt, tb = load_teacher_tables(args, n_docs)
+        tt, tb = load_teacher_tables(args, n_docs) if args.num_teachers else (np.zeros((1, 1, args.news_dim), np.float32),) * 2
     eng = Stage1Engine(n_layers=args.num_hidden_layers, trainable_layers=[l for l in args.bert_trainable_layer if l < args.num_hidden_layers],
                        num_teachers=args.num_teachers, npratio=args.npratio, title_len=args.max_title_len,
                        body_len=args.max_body_len, device=dev, batch=args.batch_size, dtype=args.dtype, **_model_dims(args))
@@ -152,6 +183,17 @@ def train(args):
     eng.body.refresh_rel()
     sync = dist.GradSync(t_eng.flat_g, eng.bucket_ranges(), size) if size > 1 else None
     d_title, d_body = torch.from_numpy(title_tab).to(dev), torch.from_numpy(body_tab).to(dev)
+    if args.mode == "export":                          # Domian-specific_Post-train.ipynb cells 18-22
+        os.makedirs(args.save_dir, exist_ok=True)
+        for i, ck in enumerate(args.ckpt_paths):
+            _load_ckpt(eng, ck, args.stage)
+            for which, tab in (("title", d_title), ("body", d_body)):
+                emb = eng.encode_table(tab, which).cpu().numpy()
+                if rank == 0:
+                    with open(os.path.join(args.save_dir, "teacher_%s_emb_%d.pkl" % (which, i)), "wb") as f:
+                        pickle.dump(emb, f)
+            logging.info("[%d] %s -> teacher_{title,body}_emb_%d.pkl (%d documents)", rank, ck, i, n_docs)
+        return eng
     d_tt, d_tb = torch.from_numpy(np.ascontiguousarray(tt)).to(dev), torch.from_numpy(np.ascontiguousarray(tb)).to(dev)
     B = args.batch_size
     label = torch.zeros(B, dtype=torch.int64, device=dev)                          # the positive comes first (cell 8)
@@ -176,14 +218,19 @@ def train(args):
                 sync.wait()
                 scale = sync.scale
             eng.step(args.lr, grad_scale=scale, lr_bert=args.pretrain_lr, amsgrad=False)
+            if args.stage == 0 and rank == 0 and cnt % args.save_steps == 0:          # cell 16: DP_12_layer_{cnt}.pt
+                os.makedirs(args.save_dir, exist_ok=True)
+                torch.save({"model_state_dict": _ckpt_state(eng, 0)},
+                           os.path.join(args.save_dir, "DP_%d_layer_%d.pt" % (args.num_hidden_layers, cnt)))
             if cnt % args.log_steps == 0:
                 s = (sums / cnt).tolist()
                 logging.info("[%d] ed: %d, loss: %.5f, t_loss: %.5f, d_loss: %.5f, e_loss: %.5f, acc: %.5f, %.1f pairs/s" % (
                     rank, cnt * B, s[0], s[1], s[2], s[3], s[4], size * cnt * B / max(time.time() - t0, 1e-9)))
         if rank == 0:
             os.makedirs(args.save_dir, exist_ok=True)
-            path = os.path.join(args.save_dir, "first_stage_%d_layer.pt" % args.num_hidden_layers)
-            torch.save({"model_state_dict": {k: v.cpu() for k, v in eng.state_dict().items()}}, path)
+            name = "first_stage_%d_layer.pt" if args.stage == 1 else "DP_%d_layer.pt"
+            path = os.path.join(args.save_dir, name % args.num_hidden_layers)
+            torch.save({"model_state_dict": _ckpt_state(eng, args.stage)}, path)
             logging.info("Model saved to %s", path)
     return eng
 

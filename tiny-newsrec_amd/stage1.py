@@ -29,7 +29,7 @@ class Stage1Engine:
     def __init__(self, n_layers=4, trainable_layers=(0, 1, 2, 3), num_teachers=4, npratio=4, title_len=30, body_len=256,
                  device="cuda:0", batch=32, dtype="bf16", **dims):
         """dims: hidden, heads, inter, news_dim, news_query, vocab, ... (EngineConfig keywords)."""
-        assert num_teachers >= 1, "stage 1 distils from at least one teacher"
+        # num_teachers = 0 is stage 0: TitleBodySimModel of Domian-specific_Post-train.ipynb (cells 10-11), plain CE
         common = dict(n_layers=n_layers, trainable_layers=trainable_layers, num_teachers=num_teachers, user_log_length=0,
                       temperature=1.0, coef=1.0, stage1=True, **dims)
         self.cfg_t = EngineConfig(npratio=npratio, num_words=title_len, **common)
@@ -71,8 +71,9 @@ class Stage1Engine:
         bidx = idx[:, 0].to(torch.int32).contiguous()
         b.encode(body_table, B, nidx=bidx, out=t.S[N:])
         t.encode(title_table, N, nidx=tidx)
-        T.call("tnr_gather_rows", t_title_tables, t_title_tables.shape[1], tidx, N, D, T_, t.X, t.X.shape[1], 0)
-        T.call("tnr_gather_rows", t_body_tables, t_body_tables.shape[1], bidx, B, D, T_, t.X, t.X.shape[1], N)
+        if T_:
+            T.call("tnr_gather_rows", t_title_tables, t_title_tables.shape[1], tidx, N, D, T_, t.X, t.X.shape[1], 0)
+            T.call("tnr_gather_rows", t_body_tables, t_body_tables.shape[1], bidx, B, D, T_, t.X, t.X.shape[1], N)
         return self._heads(B, N, Rt)
 
     def forward(self, title, body, label, teacher_titles, teacher_bodies):
@@ -108,12 +109,25 @@ class Stage1Engine:
         X = t.X
         for i in range(T_):
             t._sgemm(X[i], D, 1, C * D, X[i, N:], D, 1, D, t.t_score[i], 1, C, None, 0, C, 1, D, batch=B)
-        T.call("tnr_kd_score_loss", t.score, t.t_score, t.label, 1.0, 1.0, t.tw, t.dscore, t.losses, B, C, T_)
-        Wt = t._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
-        bt = t._view("transform_matrix.0.bias", T_ * D, (T_, D))
-        t._sgemm(X, D, 1, X.stride(0), Wt, D, 1, D * D, t.Pm, D, t.Pm.stride(0), bt, D, Rt, D, D, batch=T_)
-        T.call("tnr_kd_embed_loss", S, t.Pm, t.tw, t.losses[2:], t.dS, t.dP, t.kd_part, B, 0, C, D, T_)
+        T.call("tnr_kd_score_loss", t.score, t.t_score if T_ else None, t.label, 1.0, 1.0, t.tw if T_ else None, t.dscore,
+               t.losses, B, C, T_)
+        if T_:
+            Wt = t._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
+            bt = t._view("transform_matrix.0.bias", T_ * D, (T_, D))
+            t._sgemm(X, D, 1, X.stride(0), Wt, D, 1, D * D, t.Pm, D, t.Pm.stride(0), bt, D, Rt, D, D, batch=T_)
+            T.call("tnr_kd_embed_loss", S, t.Pm, t.tw, t.losses[2:], t.dS, t.dP, t.kd_part, B, 0, C, D, T_)
+        else:
+            t.dS[:Rt].zero_()
+            t.losses[2:3].zero_()
         return t.losses, t.score[:B]
+
+    @torch.no_grad()
+    def encode_table(self, table, which):
+        """Embeddings of every row of a resident token table (Domian-specific_Post-train.ipynb cells 20-22: the teacher
+        title / body embeddings stage 1 distils from).  which: "title" | "body".  -> (n, D) fp32 on device."""
+        eng = self.title if which == "title" else self.body
+        assert table.shape[1] == 2 * eng.cfg.L
+        return eng.encode_news(table)
 
     def total_loss(self):
         """target + distill + emb (cell 14) as a device scalar."""
@@ -127,7 +141,8 @@ class Stage1Engine:
         B, N, Rt = self.cur
         C, D = self.cfg_t.C, self.cfg_t.D
         S, dS = t.S[:Rt], t.dS
-        t._transform_grads(Rt)
+        if self.cfg_t.T:
+            t._transform_grads(Rt)
         T.call("tnr_score_bwd", S, t.cidx, S[N:], t.dscore, dS, dS[N:], B, C, D)
         t.backward_encoder(dS[:N], N, acc=0)
         b.backward_encoder(dS[N:Rt], B, acc=1, after_bucket=after_bucket)
