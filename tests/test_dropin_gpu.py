@@ -228,3 +228,54 @@ def IFACE_2L():
             continue
         out[k] = v
     return out
+
+
+def test_run_py_plmnr_train_and_teacher_pipeline(tmp_path):
+    """`run.py --mode train --num_teachers 0` = PLM-NR/run.py's train(): CE fine-tuning of ModelBert with PLM-NR checkpoint
+    keys, optionally initialised from a first-stage student (two learning rates); its checkpoint then serves as a teacher
+    checkpoint of the Tiny-NewsRec flow (run.py:61-70 reads user_encoder.* from it)."""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tiny-newsrec_amd"))
+    tok_args = _tok_cfg_args(tmp_path)
+    first = {"student." + k: v for k, v in _plmnr_sd(2).items() if k.startswith("news_encoder.")}
+    torch.save({"model_state_dict": first}, str(tmp_path / "first_stage_2_layer.pt"))
+    cmd = [sys.executable, "-u", os.path.join(ROOT, "tiny-newsrec_amd", "run.py"), "--mode", "train", "--synthetic", "False",
+           "--enable_hvd", "False", "--num_teachers", "0", "--num_hidden_layers", "2", "--bert_trainable_layer", "0", "1",
+           "--batch_size", "4", "--epochs", "1", "--log_steps", "1", "--use_pretrain_model", "True", "--pretrain_model_path",
+           str(tmp_path / "first_stage_2_layer.pt"), "--pretrain_lr", "1e-6", "--lr", "1e-4", "--model_dir", str(tmp_path / "out"),
+           "--train_data_dir", os.path.join(GOLDEN, "data"), "--filename_pat", "behaviors_np4_*.tsv"] + tok_args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=os.path.join(ROOT, "tiny-newsrec_amd"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    sd = torch.load(str(tmp_path / "out" / "epoch-1.pt"), map_location="cpu")["model_state_dict"]
+    assert "user_encoder.attn.att_fc1.weight" in sd and "news_encoder.dense.weight" in sd and not any(k.startswith("student.") for k in sd)
+    # the pretrained encoder moved by ~pretrain_lr per step, the fresh user encoder by ~lr per step (3 steps)
+    w0 = first["student.news_encoder.bert_model.bert.encoder.layer.1.output.dense.weight"]
+    dw = (sd["news_encoder.bert_model.bert.encoder.layer.1.output.dense.weight"] - w0).abs()
+    assert 0 < dw.max() < 1e-5
+    dd = (sd["news_encoder.dense.weight"] - first["student.news_encoder.dense.weight"]).abs()
+    assert 0 < dd.max() < 1e-5                               # pooling / dense of the news encoder were pretrained too
+
+
+def _plmnr_sd(nl):
+    import hashinit
+    from helpers import FULL, state_shapes
+    shapes = {k[len("student."):]: v for k, v in state_shapes(dict(FULL, vocab=_VOCAB_N), nl, 256, 0).items() if k.startswith("student.")}
+    shapes = {k: ((64, 768) if k.endswith("position_embeddings.weight") else v) for k, v in shapes.items()}
+    return {k: torch.from_numpy(v) for k, v in hashinit.init_state_dict(9, shapes).items()}
+
+
+_VOCAB_N = 0
+
+
+def _tok_cfg_args(tmp_path):
+    global _VOCAB_N
+    data = os.path.join(GOLDEN, "data")
+    words = sorted({w for ln in open(os.path.join(data, "news.tsv")) for w in ln.split("\t")[3].lower().split()})
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n")
+    (tmp_path / "config.json").write_text(json.dumps(dict(
+        hidden_size=768, num_attention_heads=12, intermediate_size=3072, vocab_size=len(vocab), max_position_embeddings=64,
+        type_vocab_size=2, layer_norm_eps=1e-12)))
+    _VOCAB_N = len(vocab)
+    return ["--tokenizer_name", str(tmp_path / "vocab.txt"), "--config_name", str(tmp_path / "config.json"), "--model_name",
+            str(tmp_path / "none.bin"), "--num_words_title", "30", "--news_dim", "256", "--user_log_mask", "False",
+            "--model", "NAML", "--model_type", "tnlrv3"]

@@ -916,16 +916,20 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ optimiser
-    def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, lr_bert=None, amsgrad=True):
+    def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, lr_bert=None, amsgrad=True, lr_news_head=None):
         """torch.optim.Adam(amsgrad=True).step() (run.py:134,195) + refresh of the 16-bit weight copies.
-        lr_bert: learning rate of the encoder layers when it differs (PLM-NR/run.py:104-106: {'params': pretrained,
-        'lr': pretrain_lr}, {'params': rest, 'lr': lr}).  amsgrad=False: plain Adam (Post-train_KD.ipynb cell 18)."""
+        lr_bert / lr_news_head: learning rates of the encoder layers / of the news encoder's pooling + dense when they
+        differ (PLM-NR/run.py:104-106: {'params': pretrained, 'lr': pretrain_lr}, {'params': rest, 'lr': lr}; the notebooks
+        use 1e-6 for bert_model and 1e-5 for the rest).  amsgrad=False: plain Adam (Post-train_KD.ipynb cell 18)."""
         self.step_count += 1
         head0 = self.off(PFX + ("attn.att_fc1.weight" if self.cfg.pooling == "att" else "dense.weight"))   # end of the BERT layers
         cut = self.off(PFX + "dense.weight")     # [0, cut): encoder layers + pooling head = gradients carrying the loss scale
+        e = self.off(PFX + "dense.bias") + self.slot[PFX + "dense.bias"][2]
+        rest0 = min(_rup(e, 64), self.n_train)   # user encoders / transform matrices start here
         lb = lr if lr_bert is None else lr_bert
-        for lo_, hi_, sc, rate in ((0, head0, grad_scale / self.gscale, lb), (head0, cut, grad_scale / self.gscale, lr),
-                                   (cut, self.n_train, grad_scale, lr)):
+        lh = lr if lr_news_head is None else lr_news_head
+        for lo_, hi_, sc, rate in ((0, head0, grad_scale / self.gscale, lb), (head0, cut, grad_scale / self.gscale, lh),
+                                   (cut, rest0, grad_scale, lh), (rest0, self.n_train, grad_scale, lr)):
             if hi_ > lo_:
                 T.call("tnr_amsgrad_step", self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_],
                        self.adam_v[lo_:hi_], self.adam_vmax[lo_:hi_] if amsgrad else None, hi_ - lo_, self.step_count, rate,

@@ -218,9 +218,11 @@ class TnrAdam:
     """optim.Adam(model.parameters(), lr, amsgrad=True) of run.py:134 on the engine's flat buffers
     (one fused kernel + bf16-copy refresh); zero_grad / step keep the reference's call order (run.py:193-195)."""
 
-    def __init__(self, model, lr, grad_sync=None, pretrain_lr=None):
-        """pretrain_lr: PLM-NR/run.py:104-106 - the encoder ("pretrained") parameters step with their own rate."""
+    def __init__(self, model, lr, grad_sync=None, pretrain_lr=None, pretrained_heads=False):
+        """pretrain_lr: PLM-NR/run.py:104-106 - the "pretrained" parameters step with their own rate: the encoder layers,
+        and (pretrained_heads) the news encoder's pooling + dense when they came from the first-stage checkpoint too."""
         self.model, self.lr, self.grad_sync, self.pretrain_lr = model, lr, grad_sync, pretrain_lr
+        self.pretrained_heads = pretrained_heads
 
     def zero_grad(self):
         pass                      # every backward overwrites the whole flat gradient buffer
@@ -230,4 +232,5 @@ class TnrAdam:
         if self.grad_sync is not None:
             self.grad_sync.wait()
             scale = self.grad_sync.scale
-        self.model.engine.step(self.lr, grad_scale=scale, lr_bert=self.pretrain_lr)
+        self.model.engine.step(self.lr, grad_scale=scale, lr_bert=self.pretrain_lr,
+                               lr_news_head=self.pretrain_lr if self.pretrained_heads else None)

@@ -35,17 +35,30 @@ def _load_inputs(args):
 def train(args):
     import dist
     from dataloader import DataLoaderTrain, IndexBatch
-    from model_bert import Model, TnrAdam
+    from model_bert import Model, ModelBert, TnrAdam
     from streaming import get_stat, get_worker_files
     size, rank, local = utils.init_hvd_cuda(args.enable_hvd, args.enable_gpu)
     assert args.enable_gpu, "the HIP path needs a GPU (there is no CPU fallback)"
     news_index, news_combined, teacher_embs, category_dict, subcategory_dict = _load_inputs(args)
-    model = Model(args)
+    # --num_teachers 0 is PLM-NR/run.py's train(): the same encoders with plain CE (ModelBert), checkpoints with PLM-NR's
+    # key names, and -- with --use_pretrain_model -- its two learning rates (PLM-NR/run.py:56-106).  Tiny-NewsRec's own
+    # Model cannot be built without teachers, so the flag value is free for this.
+    plmnr = args.num_teachers == 0
+    model = ModelBert(args) if plmnr else Model(args)
     eng = model.engine
     sd = model.state_dict()
+    pretrained = False
     if args.synthetic:
         import hashinit
-        sd = {k: torch.from_numpy(hashinit.init_tensor(1234, k, tuple(v.shape))) for k, v in sd.items()}
+        pfx = "student." if plmnr else ""
+        sd = {k: torch.from_numpy(hashinit.init_tensor(1234, pfx + k, tuple(v.shape))) for k, v in sd.items()}
+    elif plmnr:
+        if args.use_pretrain_model:                                          # PLM-NR/run.py:56-70 (first-stage student -> this model)
+            for k, v in torch.load(args.pretrain_model_path, map_location="cpu")["model_state_dict"].items():
+                k2 = k[len("student."):] if k.startswith("student.") else None
+                if k2 in sd:
+                    sd[k2] = v
+                    pretrained = True
     else:
         for i, ck in enumerate(args.teacher_ckpts[:args.num_teachers]):      # run.py:61-70
             for k, v in torch.load(ck, map_location="cpu")["model_state_dict"].items():
@@ -64,7 +77,9 @@ def train(args):
     eng.refresh_shadows(all_layers=True)
     sync = dist.GradSync(eng.flat_g, eng.bucket_ranges(), size)             # hvd.DistributedOptimizer(Average), :145-149
     model._after_bucket = sync.launch if size > 1 else None
-    optimizer = TnrAdam(model, args.lr, sync if size > 1 else None)
+    optimizer = TnrAdam(model, args.lr, sync if size > 1 else None,
+                        pretrain_lr=args.pretrain_lr if (plmnr and pretrained) else None,      # PLM-NR/run.py:94-106
+                        pretrained_heads=plmnr and pretrained)
 
     if args.synthetic:
         import synth
@@ -105,7 +120,12 @@ def train(args):
                 break
             if isinstance(batch, IndexBatch):
                 h, m, c, y, plan = batch
-                total, distill, emb, target, y_student = model.forward_indexed(dev_news, h, m, c, y, dev_tab, plan)
+                if plmnr:
+                    total, y_student = model.forward_indexed(dev_news, h, m, c, y, plan)
+                else:
+                    total, distill, emb, target, y_student = model.forward_indexed(dev_news, h, m, c, y, dev_tab, plan)
+            elif plmnr:
+                total, y_student = model(*batch[:4])
             else:
                 h, m, c, y, th, tc = batch
                 total, distill, emb, target, y_student = model(h, m, c, y, th, tc)
