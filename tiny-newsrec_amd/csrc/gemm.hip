@@ -30,6 +30,7 @@ struct NTArgs {
     float* colsum_part;        // TNR_EPI_COLSUM: (rows_of_partials, N) fp32, one row per 64-row strip of C
     int gm;                    // rasterisation group height
     int nt;                    // 1: streaming (non-temporal) accesses for once-touched epilogue operands
+    int tile0;                 // first logical tile of this launch (a GEMM may be issued as several one-round launches)
 };
 
 constexpr int TILE_BYTES = 128 * 128;   // one operand tile: 128 rows x 64 bf16
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
     const int wm = w >> 2, wn = w & 3;
     const int nbn = g.N >> 8;
     const int nbm = (g.M + BM - 1) / BM;
-    const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+    const int wg = g.tile0 + xcd_remap(blockIdx.x, gridDim.x);      // gridDim.x = tiles of this launch
     int bm, bn;
     tile_coords(wg, nbm, nbn, g.gm, bm, bn);
 
@@ -1428,7 +1429,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     TNR_CHECK_ARG(!(flags & TNR_EPI_COLSUM) || (colsum_part && !(flags & TNR_EPI_OUTF32) && M > 128),
                   "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, g_group_m, 0};
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, g_group_m, 0, 0};
     { const char* nt_s = getenv("TNR_GEMM_NT"); if (nt_s && nt_s[0] == '1') g.nt = 1; }     // A/B switch (read per call)
     static const char* gm_s = getenv("TNR_GEMM_GM");
     if (gm_s) g.gm = atoi(gm_s) > 0 ? atoi(gm_s) : 8;
@@ -1464,8 +1465,10 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     hipStream_t st = (hipStream_t)stream;
     // short inputs (stage-1 title / body passes, small eval batches): when the 256x256 grid would leave more than 40 % of
     // the CUs without a tile, the 128x128 kernel (2 workgroups per CU) spreads the same work four times finer
-    const bool sparse256 = (N % 256) == 0 && ((M + 255) / 256) * (N / 256) * 10 < (int64_t)n_cu * 6 && !(flags & TNR_EPI_COLSUM);
-    static const char* fine_s = getenv("TNR_GEMM_FINE");
+    const char* pct_s = getenv("TNR_GEMM_FINE_PCT");   // per call (A/B): fill threshold in percent of the CUs
+    const int fine_pct = pct_s ? atoi(pct_s) : 60;
+    const bool sparse256 = (N % 256) == 0 && ((M + 255) / 256) * (N / 256) * 100 < (int64_t)n_cu * fine_pct && !(flags & TNR_EPI_COLSUM);
+    const char* fine_s = getenv("TNR_GEMM_FINE");      // per call (A/B)
     const bool allow_fine = !fine_s || fine_s[0] != '0';
     const bool odd_gelu = (N % 256) != 0 && (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) && ver != 2;   // v2 has no table GELU
     if (ver == 1 || M <= 128 || odd_gelu || (sparse256 && allow_fine && ver == 3 && !probe)) {
@@ -1503,9 +1506,18 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         const int64_t c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
         bool use224 = c224 * 108 < c256 * 100 && !(flags & TNR_EPI_COLSUM);   // per-tile fixed costs: need a clear win
         if (bm_s) use224 = atoi(bm_s) == 224 && !(flags & TNR_EPI_COLSUM);
-        if (probe) hipLaunchKernelGGL((gemm_nt256x256_kernel<1, 8>), dim3((int)t256), dim3(512), LDS3_BYTES, st, g);
-        else if (use224) hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 7>), dim3((int)t224), dim3(512), LDS3_BYTES, st, g);
-        else hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 8>), dim3((int)t256), dim3(512), LDS3_BYTES, st, g);
+        // TNR_GEMM_ROUNDS=1: one launch per round of workgroups, so that every round starts in lock-step again
+        const char* rounds_s = getenv("TNR_GEMM_ROUNDS");
+        const bool by_round = rounds_s && rounds_s[0] == '1' && !probe;
+        const int64_t total = use224 ? t224 : t256;
+        const int64_t per = by_round ? n_cu : total;
+        for (int64_t t0 = 0; t0 < total; t0 += per) {
+            const int nlaunch = (int)(total - t0 < per ? total - t0 : per);
+            g.tile0 = (int)t0;
+            if (probe) hipLaunchKernelGGL((gemm_nt256x256_kernel<1, 8>), dim3(nlaunch), dim3(512), LDS3_BYTES, st, g);
+            else if (use224) hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 7>), dim3(nlaunch), dim3(512), LDS3_BYTES, st, g);
+            else hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 8>), dim3(nlaunch), dim3(512), LDS3_BYTES, st, g);
+        }
     } else {
         int ntile = (int)(((M + 255) / 256) * (N / 256));
         int nwg = ntile < n_cu ? ntile : n_cu;
