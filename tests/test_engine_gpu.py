@@ -313,7 +313,8 @@ def test_news_vectors_do_not_depend_on_the_batch_they_are_in(dtype):
 
 @pytest.mark.parametrize("shape", [dict(B=3, U=13, C=3, L=17, D=64, Q=40, T=2, nl=2, tr=(1,), ulm=True),
                                    dict(B=1, U=5, C=2, L=32, D=128, Q=200, T=1, nl=1, tr=(0,), ulm=False),
-                                   dict(B=5, U=50, C=5, L=9, D=256, Q=72, T=3, nl=2, tr=(0, 1), ulm=False)])
+                                   dict(B=5, U=50, C=5, L=9, D=256, Q=72, T=3, nl=2, tr=(0, 1), ulm=False),
+                                   dict(B=1, U=1, C=2, L=9, D=64, Q=40, T=1, nl=1, tr=(0,), ulm=False)])   # 27 token rows (found by tools/fuzz_engine.py)
 def test_odd_shapes_against_oracle(shape):
     """Shapes away from demo.sh's (row counts that are not multiples of the tile sizes, short / full 32-token titles,
     other head dimensions): one fp16 training step against the numpy oracle on hash-initialised weights."""

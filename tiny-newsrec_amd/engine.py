@@ -445,6 +445,7 @@ class Engine:
         self.ln_part1 = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
         self.red = {}                                                      # gradient bucket -> _ReduceBatch
         self.cs_part = f(max(T.query("tnr_colsum_part_elems", Mp, 3 * H if L > 32 else QPAD),
+                             T.query("tnr_colsum_part_elems", 128, I),
                              T.query("tnr_colsum_part_elems", max(B * cfg.U, 1), 3 * D),
                              T_ * T.query("tnr_colsum_part_elems", Rt, D)))
         self.gcs_part = f(T.query("tnr_gemm_colsum_rows", Mp), I)        # b1 gradient partials from the dgrad epilogue
@@ -859,10 +860,14 @@ class Engine:
                 rb.add(self.ln_part, nblk, 3 * H, 2 * H, self._view(names[14], 2 * H, (2 * H,), grad=True), acc)   # [dgamma | dbeta]
                 rb.add(self.ln_part[2 * H:], nblk, 3 * H, H, gr[names[13]], acc)                                 # output.dense.bias
                 self._wgrad(self.dypre, a["g"], gr[names[12]], M, acc)
-            self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if tr else 0),
-                       colsum=self.gcs_part if tr else None)
+            fused_cs = tr and M > 128            # the column-sum epilogue needs more than one 128-row strip
+            self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if fused_cs else 0),
+                       colsum=self.gcs_part if fused_cs else None)
             if tr:
-                rb.add(self.gcs_part, self._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], acc)
+                if fused_cs:
+                    rb.add(self.gcs_part, self._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], acc)
+                else:
+                    self._c("tnr_colsum", self.du, I, T.BF16, M, I, gr[names[11]], self.cs_part, acc)
                 self._wgrad(self.du, a["h1"], gr[names[10]], M, acc)
                 rb.flush()
                 if after_bucket:
