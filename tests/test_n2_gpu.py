@@ -92,3 +92,26 @@ def test_run_test_mode_end_to_end(tmp_path, monkeypatch):
         cnt += 1
     assert cnt == n_metric
     np.testing.assert_allclose(sums / n_metric, want / cnt, rtol=0, atol=0.03)     # rank flips on near-ties only
+
+
+@pytest.mark.parametrize("ulm", [True, False])
+@pytest.mark.parametrize("pooling", ["att", "mean"])
+def test_eval_paths_of_the_variants(ulm, pooling):
+    """run.py's test / get_teacher_emb forward paths with the NRMS user encoder and a non-attention news pooling:
+    news_scoring over the whole table and user vectors for a batch smaller than the engine's."""
+    z = np.load(os.path.join(GOLDEN, "datapath.npz"))
+    comb = z["news_combined"].astype(np.int32)
+    P = hashinit.init_state_dict(8, state_shapes(FULL, 2, 256, 0, pooling, 16))
+    cfg = E.EngineConfig(n_layers=2, trainable_layers=(), num_teachers=0, user_log_mask=ulm, pooling=pooling, nrms_heads=16)
+    eng = E.Engine(cfg, DEV, max_batch=4)
+    eng.load_state_dict(P)
+    ns = eng.encode_news(torch.from_numpy(comb).to(DEV))
+    want, _ = O.news_encoder_fwd(P, comb.astype(np.int64), 2, 12, None, pooling)
+    got = ns.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1.6e-2 * max(1.0, np.abs(want).max()))
+    rs = np.random.RandomState(1)
+    hidx = rs.randint(0, 41, (3, 50)).astype(np.int32)
+    mask = (rs.rand(3, 50) > 0.5).astype(np.float32)
+    uv = eng.user_vectors(ns, torch.from_numpy(hidx).to(DEV), torch.from_numpy(mask).to(DEV)).cpu().numpy()
+    ref, _ = O.user_encoder_fwd(P, "student.user_encoder.", got[hidx], mask, ulm, 16)
+    np.testing.assert_allclose(uv, ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
