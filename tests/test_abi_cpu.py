@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 import tnr_hip as T
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,3 +22,13 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_version_without_gpu():
     assert T.query("tnr_version") == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No CPU / eager fallback anywhere on the product path: without libtnr_hip.so the first engine call raises."""
+    import engine as E
+    import tnr_hip as T
+    monkeypatch.setattr(T, "_lib", None)
+    monkeypatch.setattr(T, "LIB_PATH", "/nonexistent/libtnr_hip.so")
+    with pytest.raises(T.TnrError, match="not built"):
+        E.Engine(E.EngineConfig(n_layers=1, trainable_layers=(0,), num_teachers=1), device="cpu", max_batch=1)
