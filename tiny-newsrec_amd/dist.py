@@ -1,9 +1,9 @@
 """Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI)
 replacing horovod (run.py:141-149, utils.py:43-60): flat parameter broadcast from rank 0, and a
 gradient AVERAGE (hvd.Average, Compression.none, fp32) done as a few large contiguous all-reduces
-(one per gradient bucket, heads first then one per trainable layer) launched as soon as backward
-has produced the bucket, so they overlap the remaining backward GEMMs; the 1/world scale is folded
-into the AMSGrad kernel.  xGMI is point-to-point, so few large messages beat many small ones."""
+(one per gradient bucket: heads first, then per trainable layer from the top its FFN block and its
+attention block, Engine.bucket_ranges) launched as soon as backward has produced the bucket, so they
+overlap the remaining backward GEMMs; the 1/world scale is folded into the AMSGrad kernel.  xGMI is point-to-point, so few large messages beat many small ones."""
 import os
 
 import torch
