@@ -15,6 +15,8 @@ for case in range(n_cases):
     nl = int(rs.randint(1, 3))
     tr = tuple(sorted(rs.choice(nl, size=rs.randint(1, nl + 1), replace=False).tolist()))
     B, U, C, L = int(rs.randint(1, 7)), int(rs.randint(1, 51)), int(rs.randint(2, 7)), int(rs.randint(2, 33))
+    if os.environ.get("LONG_TITLES"):          # stage-2 shapes on the long-sequence attention kernels
+        L, U = int(rs.randint(33, 97)), int(rs.randint(1, 13))
     pooling = ["att", "att", "cls", "mean"][rs.randint(4)]
     nrms = bool(rs.rand() < 0.25)
     D = 256 if nrms else int(rs.choice([64, 128, 256]))
