@@ -9,6 +9,8 @@ from helpers import FULL, state_shapes
 from oracle import newsrec_oracle as O
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+DTYPE = os.environ.get("DTYPE", "fp16")
+TOLS = dict(fp16=(2e-3, 3e-3, 2e-2), bf16=(1.6e-2, 2.4e-2, 8e-2))[DTYPE]
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n_cases):
@@ -42,7 +44,7 @@ for case in range(n_cases):
     ec = E.EngineConfig(n_layers=nl, trainable_layers=tr, num_teachers=T_, user_log_length=U, npratio=C - 1, num_words=L, news_dim=D,
                         news_query=Q, user_query=Q, user_log_mask=ulm, temperature=tau, coef=coef, pooling=pooling,
                         nrms_heads=16 if nrms else 0)
-    eng = E.Engine(ec, "cuda:0", max_batch=B, dtype="fp16")
+    eng = E.Engine(ec, "cuda:0", max_batch=B, dtype=DTYPE)
     eng.load_state_dict(P)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
     losses, score = eng.forward(t(hist), t(mask), t(cand), t(label), [t(x) for x in th], [t(x) for x in tc])
@@ -61,7 +63,7 @@ for case in range(n_cases):
         if rn < 1e-4 * top: continue
         err = np.sqrt(((eng.grad(k).cpu().numpy() - ref).astype(np.float64) ** 2).sum()) / rn
         if err > worst: worst, wk = err, k
-    ok = le < 2e-3 and se < 3e-3 and worst < 2e-2 and np.isfinite(le + se + worst)
+    ok = le < TOLS[0] and se < TOLS[1] and worst < TOLS[2] and np.isfinite(le + se + worst)
     bad += not ok
     print("%s case %2d nl=%d tr=%s B=%d U=%d C=%d L=%d D=%d Q=%d T=%d ulm=%d pool=%s nrms=%d : loss %.1e score %.1e grad %.1e %s" % (
         "ok " if ok else "BAD", case, nl, tr, B, U, C, L, D, Q, T_, ulm, pooling, nrms, le, se, worst, "" if ok else wk), flush=True)
