@@ -80,6 +80,18 @@ int tnr_gemm_nt_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void*
                    void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream);
 int64_t tnr_gemm_colsum_rows(int64_t M);
 
+/* Debug / test hooks.  tnr_gemm_nt_route: which kernel tnr_gemm_nt(_ex) launches for a shape on the current
+ * device (the decision depends on (M, N, K, flags) and the CU count only) -- the parity tests assert it so that
+ * every tile variant is pinned at the shapes the training step issues.  tnr_gemm_set_option: process-wide A/B
+ * switches for tools/ ("ver", "gm", "fine_pct", "allow_fine", "bm", "nt", "pp"); the library never reads the
+ * environment and the defaults are the shipped configuration. */
+#define TNR_ROUTE_128x128 128    /* 128x128 tile, 4 waves, 2 workgroups per CU */
+#define TNR_ROUTE_256x128 2128   /* 256x128 tile (N % 256 != 0) */
+#define TNR_ROUTE_256x256 256    /* 256x256 tile, 8 waves */
+#define TNR_ROUTE_224x256 224    /* 224-row variant of the same kernel (fewer wasted rows per round) */
+int tnr_gemm_nt_route(int64_t M, int64_t N, int64_t K, int flags);
+int tnr_gemm_set_option(const char* key, int value);
+
 /* dW[N,K] (fp32) = dY[M,N]^T . X[M,K] : weight gradient of a Linear.  Reduction over M is split into
  * `splits` slabs in `ws` (fp32, splits*N*K elements) and summed in fixed order (deterministic).
  * Rows [M, Mpad) of dY and X must be zero, Mpad = roundup(M, 64) ; N % 128 == 0, K % 128 == 0.
@@ -272,6 +284,7 @@ int tnr_gemm_nt_ex_f16(const void* A, int64_t lda, const void* B, int64_t ldb, v
                    int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                    void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream);
 int64_t tnr_gemm_colsum_rows_f16(int64_t M);
+int tnr_gemm_nt_route_f16(int64_t M, int64_t N, int64_t K, int flags);
 int tnr_gemm_tn_wgrad_f16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
                       int64_t M, int64_t N, int64_t K, float* ws, int splits, int accumulate, void* stream);
 int64_t tnr_gemm_tn_ws_elems_f16(int64_t N, int64_t K, int splits);

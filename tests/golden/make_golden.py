@@ -240,6 +240,20 @@ def main():
     golden_variants(R)
     golden_plmnr()
     golden_stage0(R)
+    golden_configs(R)
+
+
+def golden_configs(R):
+    """The BASELINE.json configurations that round 1 covered only piecewise, as stated:
+    configs[1] PLM-NR 12-layer fine-tune (train 10-11); configs[4] 2-layer student + 4 teachers, stage 2 (titles 30) and
+    stage 1 (titles 30 / bodies 128)."""
+    golden_plmnr("plmnr_full_1.npz", seed=42, nl=12, trainable=(10, 11))
+    cfg = dict(ref_shim.BASE_CFG, num_hidden_layers=2)
+    rec, _ = run_model(R, cfg, dict(num_student_layers=2, user_log_mask=False, temperature=1.0, coef=0.2), (0, 1), seed=24,
+                       B=2, T=4, full_grads=False)
+    np.savez_compressed(os.path.join(HERE, "full_model_5.npz"), **rec)
+    print("full 5 (configs[4] stage 2)", rec["total"], rec["distill"], rec["emb"], rec["target"])
+    golden_stage1(R, only=("cfg4",))
 
 
 def golden_variants(R):
@@ -280,14 +294,19 @@ def _notebook_distill_classes(R, cfg_json):
     return ns
 
 
-def golden_stage1(R):
+def golden_stage1(R, only=None):
     import types
     cases = [("tiny", dict(ref_shim.BASE_CFG, hidden_size=64, num_attention_heads=4, intermediate_size=256, vocab_size=128,
                            max_position_embeddings=64, num_hidden_layers=2), dict(news_dim=32, news_query_vector_dim=16),
               (0, 1), 3, 4, 3, 10, 40, 128, True, 300),
              ("full", dict(ref_shim.BASE_CFG, num_hidden_layers=2), dict(news_dim=256, news_query_vector_dim=200),
-              (0, 1), 2, 2, 4, 24, 128, 30522, False, 301)]
+              (0, 1), 2, 2, 4, 24, 128, 30522, False, 301),
+             # BASELINE configs[4] exactly: 2-layer student + FOUR teachers, titles of 30 / bodies of 128 tokens, 1+4 titles
+             ("cfg4", dict(ref_shim.BASE_CFG, num_hidden_layers=2), dict(news_dim=256, news_query_vector_dim=200),
+              (0, 1), 4, 2, 5, 30, 128, 30522, False, 303)]
     for name, cfg_json, dims, trainable, T, B, C, Lt, Lb, vocab, full, seed in cases:
+        if only is not None and name not in only:
+            continue
         ns = _notebook_distill_classes(R, cfg_json)
         args = types.SimpleNamespace(num_hidden_layers=cfg_json["num_hidden_layers"], num_teachers=T, **dims)
         model = ns["DistillModel"](args)
@@ -371,11 +390,13 @@ def golden_convert(R):
     print("convert.npz:", len(conv), "keys")
 
 
-def golden_plmnr():
+def golden_plmnr(out_name="plmnr_full_0.npz", seed=41, nl=2, trainable=(0, 1)):
     """BASELINE.json configs[0]/[1]: PLM-NR's ModelBert (PLM-NR/model_bert.py:178-207: same encoders, plain CE) with the
-    freeze policy and the two-learning-rate AMSGrad of PLM-NR/run.py:84-106, two optimiser steps."""
+    freeze policy and the two-learning-rate AMSGrad of PLM-NR/run.py:84-106, two optimiser steps.
+    plmnr_full_0 = 2 layers (configs[0]'s model); plmnr_full_1 = configs[1] exactly: 12 layers, layers 10-11 trainable
+    (PLM-NR/demo.sh:21-22), U=50, C=5, L=30."""
     R = ref_shim.load_reference("PLM-NR")
-    seed, B, nl, trainable = 41, 2, 2, (0, 1)
+    B = 2
     cfg_json = dict(ref_shim.BASE_CFG, num_hidden_layers=nl)
     a = ref_shim.make_args(config_name=ref_shim.write_config(cfg_json), num_hidden_layers=nl, batch_size=B)
     model = R.model_bert.ModelBert(a)
@@ -417,13 +438,13 @@ def golden_plmnr():
                 rec["gidx." + n], rec["gval." + n] = idx, val
         opt.step()
     rec["grad_names"] = np.array(names)
-    for n in ("news_encoder.dense.weight", "news_encoder.bert_model.bert.encoder.layer.1.output.dense.weight",
+    for n in ("news_encoder.dense.weight", "news_encoder.bert_model.bert.encoder.layer.%d.output.dense.weight" % max(trainable),
               "user_encoder.attn.att_fc1.weight"):
         w = dict(model.named_parameters())[n].detach().numpy()
         idx, val = grad_samples(seed, "w." + n, w)
         rec["widx." + n], rec["wval." + n] = idx, val            # parameter samples after the two steps
-    np.savez_compressed(os.path.join(HERE, "plmnr_full_0.npz"), **rec)
-    print("plmnr", rec["loss0"], rec["loss1"])
+    np.savez_compressed(os.path.join(HERE, out_name), **rec)
+    print(out_name, rec["loss0"], rec["loss1"])
 
 
 def golden_stage0(R):
@@ -513,4 +534,7 @@ def golden_interface():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "configs":       # only the round-2 additions (the other fixtures are unchanged)
+        golden_configs(ref_shim.load_reference())
+    else:
+        main()

@@ -1,0 +1,199 @@
+"""GPU parity of the dominant kernels AT THE LAUNCHES THE HEADLINE STEP ISSUES (B=32: M = 52 800 token rows).
+
+Every (N, K, epilogue flags) engine.py passes to tnr_gemm_nt_ex / tnr_gemm_tn_wgrad in the 4-layer + 4-teacher step,
+both 16-bit builds, multi-round grids (621 ... 2484 tiles on 256 CUs):
+  * integer-valued asymmetric operands -> the main loop, the tile rasterisation (xcd_remap / tile_coords) and every tile
+    variant are checked BIT-EXACT against numpy fp32 on rows sampled from every row tile (plus the ragged tail), and the
+    full matrix against an fp32 GPU product that is itself pinned to numpy on those rows;
+  * random operands -> the fused epilogues against numpy fp32 with the 16-bit output rounding as tolerance;
+  * tnr_gemm_nt_route pins which kernel / tile height each launch takes (256-row, 224-row, 128x128 routes);
+  * one B=32 forward (losses + scores) against the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import tnr_hip as T                      # noqa: E402
+from oracle import newsrec_oracle as O   # noqa: E402
+
+DEV = "cuda:0"
+M_BENCH = 52800                           # 32 impressions x 55 titles x 30 tokens
+H, I, QPAD = 768, 3072, 256
+TD = {"bf16": torch.bfloat16, "fp16": torch.float16}
+EPS = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}      # one rounding of the 16-bit output
+
+B_, G_, TH, R_, MD, F32O, AUX, CS = (T.EPI_BIAS, T.EPI_GELU, T.EPI_TANH, T.EPI_RES, T.EPI_MULDGELU, T.EPI_OUTF32, T.EPI_AUXOUT,
+                                     T.EPI_COLSUM)
+# (name, N, K, flags) of every NT launch of the headline step (engine.py: encode / backward_encoder)
+NT_LAUNCHES = [
+    ("qkv", 3 * H, H, B_),
+    ("attn_out", H, H, B_ | R_),
+    ("ffn_up_kept", I, H, B_ | G_ | AUX),
+    ("ffn_up_frozen", I, H, B_ | G_),
+    ("ffn_down", H, I, B_ | R_),
+    ("pool_fc1", QPAD, H, B_ | TH | F32O),
+    ("dgrad_pool", H, QPAD, R_),
+    ("dgrad_w2_geluprime", I, H, MD | CS),
+    ("dgrad_w1", H, I, R_),
+    ("dgrad_o", H, H, 0),
+    ("dgrad_qkv", H, 3 * H, R_),
+]
+WGRAD_LAUNCHES = [("qkv", 3 * H, H), ("attn_out", H, H), ("ffn_up", I, H), ("ffn_down", H, I), ("pool_fc1", QPAD, H)]
+
+
+def _sfx(dtype):
+    return "_f16" if dtype == "fp16" else ""
+
+
+def _rows(M):
+    """Rows sampled from every 224- and 256-row tile (stride 13 is coprime to both) + the ragged tail."""
+    return np.unique(np.concatenate([np.arange(0, M, 13), np.arange(max(0, M - 300), M)]))
+
+
+def _expected_route(M, N, flags, n_cu=256):
+    if N % 256:
+        return T.ROUTE_128 if (M <= 128 or flags & (G_ | MD)) else T.ROUTE_256x128
+    t256, t224 = -(-M // 256) * (N // 256), -(-M // 224) * (N // 256)
+    if M <= 128 or (t256 * 100 < n_cu * 60 and not flags & CS):
+        return T.ROUTE_128
+    c256, c224 = -(-t256 // n_cu) * 256, -(-t224 // n_cu) * 224
+    return T.ROUTE_224 if (c224 * 108 < c256 * 100 and not flags & CS) else T.ROUTE_256
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("name,N,K,flags", NT_LAUNCHES)
+def test_gemm_nt_main_loop_bit_exact_at_bench_shape(dtype, name, N, K, flags):
+    M = M_BENCH
+    rs = np.random.RandomState(N + K)
+    A = rs.randint(-3, 4, (M, K)).astype(np.float32)
+    Bm = rs.randint(-3, 4, (N, K)).astype(np.float32)
+    Bm[:, 0] += np.arange(N) % 5                      # asymmetric: a row <-> col or tile swap cannot hide
+    A[:, 1] += np.arange(M) % 3
+    a, b = torch.from_numpy(A).to(DEV), torch.from_numpy(Bm).to(DEV)
+    c = torch.full((M + 64, N), 7.0, device=DEV, dtype=torch.float32)
+    route = T.query("tnr_gemm_nt_route" + _sfx(dtype), M, N, K, F32O)
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert route == _expected_route(M, N, F32O), (name, route)
+    T.call("tnr_gemm_nt" + _sfx(dtype), a.to(TD[dtype]), K, b.to(TD[dtype]), K, c, N, M, N, K, None, None, 0, None, 0, F32O)
+    full = a @ b.T                                    # fp32 GPU product: exact for these integers (|sum| < 2^24)
+    torch.cuda.synchronize()
+    rows = _rows(M)
+    want = A[rows] @ Bm.T
+    assert np.array_equal(full[rows].cpu().numpy(), want)            # pins the GPU checker to numpy
+    assert np.array_equal(c[rows].cpu().numpy(), want), name         # the kernel against numpy
+    assert torch.equal(c[:M], full), name                            # ... and every element of every tile
+    assert (c[M:] == 7.0).all()                                      # nothing written past M
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("name,N,K,flags", NT_LAUNCHES)
+def test_gemm_nt_epilogues_at_bench_shape(dtype, name, N, K, flags):
+    M, td = M_BENCH, TD[dtype]
+    g = torch.Generator(device=DEV).manual_seed(N * 7 + K + flags)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, device=DEV, generator=g) * sc)
+    a, b = rnd(M, K).to(td), rnd(N, K, sc=0.05).to(td)
+    bias = rnd(N) if flags & B_ else None
+    res = rnd(M, N).to(td) if flags & R_ else None
+    aux = rnd(M, N).to(td) if flags & MD else (torch.zeros((M, N), device=DEV, dtype=td) if flags & AUX else None)
+    aux_in = aux.clone() if flags & MD else None
+    c = torch.zeros((M, N), device=DEV, dtype=torch.float32 if flags & F32O else td)
+    cs = torch.zeros((T.query("tnr_gemm_colsum_rows" + _sfx(dtype), M), N), device=DEV) if flags & CS else None
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert T.query("tnr_gemm_nt_route" + _sfx(dtype), M, N, K, flags) == _expected_route(M, N, flags), name
+    T.call("tnr_gemm_nt_ex" + _sfx(dtype), a, K, b, K, c, N, M, N, K, bias, res, N if res is not None else 0, aux,
+           N if aux is not None else 0, flags, cs)
+    torch.cuda.synchronize()
+    rows = _rows(M)
+    ridx = torch.from_numpy(rows).to(DEV)
+    f = lambda t: t[ridx].float().cpu().numpy()
+    pre = f(a) @ b.float().cpu().numpy().T
+    if bias is not None:
+        pre = pre + bias.cpu().numpy()
+    want = pre
+    if flags & G_:
+        want = O.gelu(pre)
+    if flags & TH:
+        want = np.tanh(pre)
+    if flags & MD:
+        want = pre * O.gelu_grad(f(aux_in))
+    if flags & R_:
+        want = want + f(res)
+    eps = 1e-5 if flags & F32O else EPS[dtype]
+    got = f(c)
+    np.testing.assert_allclose(got, want, rtol=2 * eps, atol=2 * eps + 2e-5 * np.sqrt(K), err_msg=name)
+    if flags & AUX:                                    # pre-activation stored beside the GELU output
+        np.testing.assert_allclose(f(aux), pre, rtol=2 * eps, atol=2 * eps + 2e-5 * np.sqrt(K), err_msg=name + "/aux")
+    if flags & CS:                                     # column sums of the ROUNDED 16-bit output (bias gradient)
+        want_cs = c.float().sum(0).cpu().numpy()
+        np.testing.assert_allclose(cs.sum(0).cpu().numpy(), want_cs, rtol=1e-4, atol=1e-2, err_msg=name + "/colsum")
+
+
+def test_gemm_nt_routes_cover_every_tile_variant():
+    """The three routes the engine's shapes can take, each pinned on a small integer-exact case as well."""
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("route table is written for 256 CUs")
+    assert T.query("tnr_gemm_nt_route", M_BENCH, 768, 768, B_) == T.ROUTE_224
+    assert T.query("tnr_gemm_nt_route", M_BENCH, 2304, 768, B_) == T.ROUTE_256
+    assert T.query("tnr_gemm_nt_route", M_BENCH, 3072, 768, MD | CS) == T.ROUTE_256
+    assert T.query("tnr_gemm_nt_route", 3300, 768, 768, B_) == T.ROUTE_128          # the B=2 goldens
+    assert T.query("tnr_gemm_nt_route", M_BENCH, 384, 768, B_) == T.ROUTE_256x128   # N % 256 != 0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("name,N,K", WGRAD_LAUNCHES)
+def test_gemm_tn_wgrad_bit_exact_at_bench_shape(dtype, name, N, K):
+    import engine as E
+    M = M_BENCH
+    Mp = (M + 127) // 128 * 128
+    rs = np.random.RandomState(N + 3 * K)
+    dY = np.zeros((Mp, N), np.float32)
+    X = np.zeros((Mp, K), np.float32)
+    dY[:M] = rs.randint(-2, 3, (M, N))
+    X[:M] = rs.randint(-2, 3, (M, K))
+    X[:M, 0] += np.arange(M) % 3
+    dY[:M, 1] += np.arange(M) % 2
+    splits = E.Engine._wgrad_splits(N, K)[0]                         # what the engine passes
+    ws = torch.zeros(T.query("tnr_gemm_tn_ws_elems" + _sfx(dtype), N, K, splits), device=DEV)
+    dW = torch.full((N, K), 3.0, device=DEV)
+    dy, x = torch.from_numpy(dY).to(DEV).to(TD[dtype]), torch.from_numpy(X).to(DEV).to(TD[dtype])
+    T.call("tnr_gemm_tn_wgrad" + _sfx(dtype), dy, N, x, K, dW, K, M, N, K, ws, splits, 0)
+    torch.cuda.synchronize()
+    want = dY.T @ X                                                  # |sum| <= 9 * 52800 < 2^24: exact in fp32
+    assert np.array_equal(dW.cpu().numpy(), want), name
+    T.call("tnr_gemm_tn_wgrad" + _sfx(dtype), dy, N, x, K, dW, K, M, N, K, ws, splits, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(dW.cpu().numpy(), 2 * want), name + "/accumulate"
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_b32_forward_matches_oracle(dtype):
+    """The benchmark's own forward (B=32, 4-layer student + 4 teachers, synthetic MIND-shaped inputs): the four losses and
+    the (32, 5) scores against the numpy oracle on the same inputs, to the bound of the build."""
+    import engine as E
+    import hashinit
+    import synth
+    from schema import FULL, state_shapes
+    nl, T_, B, n_news = 4, 4, 32, 4000
+    cfg = E.EngineConfig(n_layers=nl, trainable_layers=(2, 3), num_teachers=T_)
+    eng = E.Engine(cfg, DEV, max_batch=B, dtype=dtype)
+    P = hashinit.init_state_dict(1234, state_shapes(FULL, nl, cfg.D, T_))
+    eng.load_state_dict(P)
+    comb = synth.news_table(1234, n_news, cfg.L)
+    tabs = synth.teacher_tables(1234, T_, n_news, cfg.D)
+    hidx, mask, cidx, label = synth.impressions(1235, B, n_news, cfg.U, cfg.C)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    losses, score = eng.forward_indexed(d(comb), d(hidx), d(mask), d(cidx), d(label), d(tabs))
+    torch.cuda.synchronize()
+    ocfg = dict(n_layers=nl, heads=12, trainable_layers=[2, 3], user_log_mask=False, temperature=1.0, coef=0.2)
+    c64 = comb.astype(np.int64)
+    ref = O.model_fwd(P, ocfg, c64[hidx], mask, c64[cidx], label, [tabs[i][hidx] for i in range(T_)],
+                      [tabs[i][cidx] for i in range(T_)], keep=False)
+    tol = {"fp16": 1e-3, "bf16": 1.6e-2}[dtype]
+    l = losses.cpu().numpy()
+    for got, key in ((l[0], "distill_loss"), (l[1], "target_loss"), (l[2], "emb_loss")):
+        assert abs(got - float(ref[key])) <= tol * max(1.0, abs(float(ref[key]))), (key, got, float(ref[key]))
+    rs_ = ref["student_score"]
+    err = np.abs(score.cpu().numpy() - rs_) / np.maximum(1.0, np.abs(rs_))
+    print("B=32 forward %s: score max err / max(1,|ref|) %.2e, |logit| max %.2f" % (dtype, err.max(), np.abs(rs_).max()))
+    assert err.max() <= tol

@@ -40,7 +40,8 @@ GTOL = {"bf16": 6e-2, "fp16": 1.5e-2}
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", ["full_model_0.npz", "full_model_1.npz", "full_model_2.npz",
-                                  "full_model_3.npz", "full_model_4.npz"])       # 3: mean pooling + NRMS, 4: cls + NRMS (masked)
+                                  "full_model_3.npz", "full_model_4.npz",         # 3: mean pooling + NRMS, 4: cls + NRMS (masked)
+                                  "full_model_5.npz"])                             # 5: BASELINE configs[4]: 2 layers + FOUR teachers
 def test_training_step_matches_reference_and_oracle(name, dtype):
     LOGIT_TOL = TOL[dtype]
     z, P, cfg, inp = load_case(name)
@@ -203,11 +204,13 @@ def test_in_batch_dedup_gives_the_same_step(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_plmnr_finetune_steps(dtype):
-    """BASELINE configs[1] shape of work (PLM-NR ModelBert: CE only, no teachers, two learning rates) on the engine:
-    two full training steps against the reference's own run (plmnr_full_0.npz) and the oracle's gradients."""
+@pytest.mark.parametrize("case", ["plmnr_full_0.npz", "plmnr_full_1.npz"])
+def test_plmnr_finetune_steps(dtype, case):
+    """PLM-NR ModelBert (CE only, no teachers, two learning rates) on the engine: two full training steps against the
+    reference's own run and the oracle's gradients.  plmnr_full_0 = 2 layers (BASELINE configs[0]'s model);
+    plmnr_full_1 = BASELINE configs[1] exactly: 12 layers, layers 10-11 trainable (PLM-NR/demo.sh:21-22), U=50 C=5 L=30."""
     from helpers import load_plmnr_case
-    z, P, cfg, inp = load_plmnr_case()
+    z, P, cfg, inp = load_plmnr_case(case)
     seed, B, _, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
     ec = E.EngineConfig(n_layers=nl, trainable_layers=cfg["trainable_layers"], num_teachers=0, user_log_length=U, npratio=C - 1,
                         num_words=L, news_dim=D, user_log_mask=False, temperature=1.0, coef=1.0)
@@ -233,11 +236,18 @@ def test_plmnr_finetune_steps(dtype):
             _, _, out = O.plmnr_fwd(P, cfg, *inp, keep=True)
             G = O.plmnr_bwd(P, cfg, out)
             worst = 0.0
+            nrm = lambda a: float(np.sqrt((a.astype(np.float64) ** 2).sum()))
+            top_norm = max(nrm(G[k]) for k in eng.grads)
             for k in eng.grads:
                 if k.endswith("self.key.bias") or k.endswith("att_fc2.bias"):
                     continue
                 got, refg = eng.grad(k).cpu().numpy(), G[k]
-                err = np.sqrt(((got - refg).astype(np.float64) ** 2).sum()) / (np.sqrt((refg.astype(np.float64) ** 2).sum()) + 1e-12)
+                if nrm(refg) < 1e-4 * top_norm:
+                    # 12-layer hash model: q / k and pooling-head gradients sit at the fp32 rounding floor of the reference's
+                    # own autograd (tests/test_oracle_golden.py carries the same floor): bounded in absolute terms only
+                    assert nrm(got - refg) < 1e-4 * top_norm, "%s: %.3e" % (k, nrm(got - refg))
+                    continue
+                err = nrm(got - refg) / (nrm(refg) + 1e-12)
                 worst = max(worst, err)
                 assert err < GTOL[dtype], "%s: %.3e" % (k, err)
             print("   worst gradient relative L2 error %.3e" % worst)

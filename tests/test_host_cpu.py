@@ -160,6 +160,37 @@ def test_gradient_average_two_ranks_gloo():
         assert np.array_equal(p, np.zeros(10, np.float32))            # parameters broadcast from rank 0
 
 
+def _uneven_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import dist
+    dist.init("gloo")
+    n_lines, B = (1003, 996)[rank], 32                      # uneven shards: 32 vs 32 batches ... and 1003 -> 32, 996 -> 32
+    cap = dist.min_over_ranks(-(-n_lines // B))
+    cap2 = dist.min_over_ranks((7, 5)[rank])
+    # every rank runs `cap` steps with one collective each: no rank is left waiting (the reference would hang, run.py:176)
+    t = torch.zeros(1)
+    for _ in range(cap2):
+        torch.distributed.all_reduce(t)
+    dist.barrier()
+    q.put((rank, cap, cap2))
+
+
+def test_uneven_shards_agree_on_the_shortest_step_count_gloo():
+    """SURVEY.md section 5 (failure detection): ranks read sorted(files)[r::W], so batch counts differ; run.py caps every
+    rank's epoch at the minimum over ranks (dist.min_over_ranks) instead of letting the gradient all-reduce hang."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + os.getpid() % 40
+    ps = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert [r[1] for r in res] == [32, 32] and [r[2] for r in res] == [5, 5]
+
+
 def test_metrics_match_sklearn_and_reference_formulas():
     import metrics
     from sklearn.metrics import roc_auc_score

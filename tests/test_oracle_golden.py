@@ -125,7 +125,7 @@ def test_full_model_forward_backward(name):
     _check_model(name, False)
 
 
-@pytest.mark.parametrize("name", ["stage1_tiny.npz", "stage1_full.npz"])
+@pytest.mark.parametrize("name", ["stage1_tiny.npz", "stage1_full.npz", "stage1_cfg4.npz"])
 def test_stage1_distill_forward_backward(name):
     """Stage-1 KD (title/body matching, bodies of 40 / 128 tokens) against the notebook's DistillModel."""
     from helpers import load_stage1_case
@@ -182,11 +182,12 @@ def test_nrms_self_attention_backward_matches_finite_differences():
             np.testing.assert_allclose(G[name + ".bias"][3], fd(b[key], 3, lambda: f(x, W, b)), rtol=3e-2, atol=3e-3)
 
 
-def test_plmnr_training_steps_match_reference():
+@pytest.mark.parametrize("case", ["plmnr_full_0.npz", "plmnr_full_1.npz"])      # 2 layers ; configs[1]: 12 layers, train 10-11
+def test_plmnr_training_steps_match_reference(case):
     """BASELINE configs[0]/[1]: PLM-NR ModelBert (CE only) forward, backward and two AMSGrad steps with the two
-    learning rates of PLM-NR/run.py:104-106, against the reference's own run (tests/golden/plmnr_full_0.npz)."""
+    learning rates of PLM-NR/run.py:104-106, against the reference's own run (tests/golden/plmnr_full_*.npz)."""
     from helpers import load_plmnr_case
-    z, P, cfg, inp = load_plmnr_case()
+    z, P, cfg, inp = load_plmnr_case(case)
     lr_bert, lr = [float(x) for x in z["lrs"]]
     state = {}
     for step in range(2):
@@ -197,13 +198,24 @@ def test_plmnr_training_steps_match_reference():
         if step == 0:
             names = [str(n) for n in z["grad_names"]]
             assert set("student." + n for n in names) == set(G)
+            # 12-layer hash model: the q / k gradients are ~1e-8 against ~1e-2 for the FFN ones, i.e. at the fp32 rounding
+            # floor of the reference's own autograd -- samples are held to 1e-5 of the model's largest gradient sample
+            top = max(float(np.abs(z["gval." + n]).max()) for n in names)
+            top_norm = max(float(z["gnorm." + n]) for n in names)
+            checked = 0
             for n in names:
                 g = G["student." + n]
                 if n.endswith("self.key.bias") or n.endswith("att_fc2.bias"):
                     continue
-                np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), float(z["gnorm." + n]), rtol=1e-3, atol=1e-9)
+                noisy = cfg["n_layers"] > 2 and float(z["gnorm." + n]) < 1e-4 * top_norm
+                if not noisy:       # (as in the 12-layer stage-0 case below: norms of noise-level gradients are not a measurement)
+                    np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), float(z["gnorm." + n]), rtol=1e-3,
+                                               atol=1e-9, err_msg=n)
+                    checked += 1
                 ref = z["gval." + n]
-                np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max() + 1e-10)
+                np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], ref, rtol=2e-3,
+                                           atol=2e-3 * np.abs(ref).max() + 1e-10 + (1e-5 * top if cfg["n_layers"] > 2 else 0.0), err_msg=n)
+            assert checked >= 24          # at least every FFN / value / output / LayerNorm gradient of the two trainable layers
         for k, g in G.items():
             m, v, vm = state.setdefault(k, [np.zeros_like(P[k]), np.zeros_like(P[k]), np.zeros_like(P[k])])
             O.amsgrad_step(P[k], g, m, v, vm, step + 1, lr=lr_bert if ".bert_model." in k else lr)
@@ -238,3 +250,40 @@ def test_stage0_contrastive_post_train_matches_notebook():
             np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), float(z["gnorm." + n]), rtol=1e-3, err_msg=n)
             checked += 1
     assert checked >= 36          # every FFN / value / output / LayerNorm / dense gradient of the three trainable layers
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# oracle/torch_port.py: the torch-CPU port that bench.py times as `cpu_baseline` -- pinned to the same reference goldens
+@pytest.mark.parametrize("name", ["full_model_0.npz", "full_model_1.npz"])
+def test_torch_port_matches_reference_golden(name):
+    import torch
+    from oracle import torch_port as TP
+    z, P, cfg, inp = load_case(name)
+    tr = TP.Trainer(P, cfg, lr=1e-4)
+    total, distill, emb, target, score = tr.step(*inp)
+    for got, key in ((total, "total"), (distill, "distill"), (emb, "emb"), (target, "target")):
+        np.testing.assert_allclose(float(got.detach()), z[key], rtol=RTOL, atol=ATOL, err_msg=key)
+    np.testing.assert_allclose(score.detach().numpy(), z["score"], rtol=RTOL, atol=ATOL)
+    names = [str(n) for n in z["grad_names"]]
+    assert set(names) == {k for k, v in tr.P.items() if v.requires_grad}       # the trainable set of run.py:101-112
+    for n in names:
+        if n.endswith("self.key.bias") or n.endswith("att_fc2.bias"):
+            continue                                                            # mathematical no-ops: rounding noise only
+        g = tr.P[n].grad.numpy()
+        np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), float(z["gnorm." + n]), rtol=1e-3, atol=1e-9, err_msg=n)
+
+
+def test_torch_port_plmnr_two_rate_steps():
+    """PLM-NR objective + the two learning rates of PLM-NR/run.py:104-106: parameters after two updates."""
+    from helpers import load_plmnr_case
+    from oracle import torch_port as TP
+    z, P, cfg, inp = load_plmnr_case()
+    lr_bert, lr = [float(x) for x in z["lrs"]]
+    tr = TP.Trainer(P, cfg, lr=lr, lr_bert=lr_bert)
+    for step in range(2):
+        total, _, _, target, score = tr.step(*inp)
+        np.testing.assert_allclose(float(target), z["loss%d" % step], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(score.detach().numpy(), z["score%d" % step], rtol=2e-4, atol=2e-4)
+    for k in [f[5:] for f in z.files if f.startswith("widx.")]:
+        got = tr.P["student." + k].detach().numpy().reshape(-1)[z["widx." + k]]
+        np.testing.assert_allclose(got, z["wval." + k], rtol=0, atol=2e-6, err_msg=k)

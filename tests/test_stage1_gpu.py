@@ -34,8 +34,10 @@ def _dev(inp):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_stage1_step_matches_notebook_and_oracle(dtype):
-    z, P, cfg, inp = load_stage1_case("stage1_full.npz")
+@pytest.mark.parametrize("case", ["stage1_full.npz",        # notebook shapes scaled down: 2 teachers, 1+3 titles of 24, bodies of 128
+                                  "stage1_cfg4.npz"])       # BASELINE configs[4] exactly: 4 teachers, 1+4 titles of 30, bodies of 128
+def test_stage1_step_matches_notebook_and_oracle(dtype, case):
+    z, P, cfg, inp = load_stage1_case(case)
     eng, B = _make(z, cfg, dtype)
     assert not any(k.startswith("teachers.") or "user_encoder" in k for k in eng.shapes)     # DistillModel's schema
     eng.load_state_dict(P)

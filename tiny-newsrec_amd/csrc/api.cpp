@@ -2,7 +2,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
-#include "../../include/tnr_hip.h"
+#include <string.h>
+
+#include "common.h"
 
 static thread_local char g_err[512] = "";
 
@@ -15,3 +17,20 @@ void tnr_set_error(const char* fmt, ...) {
 
 extern "C" const char* tnr_last_error(void) { return g_err; }
 extern "C" int tnr_version(void) { return 1; }
+
+static TnrGemmOpts g_gemm_opts = {3, 8, 60, 1, 0, 0, 1};
+TnrGemmOpts* tnr_gemm_opts() { return &g_gemm_opts; }
+
+extern "C" int tnr_gemm_set_option(const char* key, int value) {
+    if (!key) { tnr_set_error("tnr_gemm_set_option: null key"); return TNR_EINVAL; }
+    TnrGemmOpts& o = g_gemm_opts;
+    if (!strcmp(key, "ver")) o.ver = value;
+    else if (!strcmp(key, "gm")) o.gm = value;
+    else if (!strcmp(key, "fine_pct")) o.fine_pct = value;
+    else if (!strcmp(key, "allow_fine")) o.allow_fine = value;
+    else if (!strcmp(key, "bm")) o.bm = value;
+    else if (!strcmp(key, "nt")) o.nt = value;
+    else if (!strcmp(key, "pp")) o.pp = value;
+    else { tnr_set_error("tnr_gemm_set_option: unknown key %s", key); return TNR_EINVAL; }
+    return TNR_OK;
+}

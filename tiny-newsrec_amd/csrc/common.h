@@ -31,6 +31,19 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 void tnr_set_error(const char* fmt, ...);
 
+// Process-wide GEMM options (api.cpp).  Defaults are the product configuration; only tools/ change them, through
+// tnr_gemm_set_option(), for same-process A/B runs.  The library never reads environment variables.
+struct TnrGemmOpts {
+    int ver;         // 3 = route by shape (default) ; 1 / 2 = force the 128x128 / 256x128 kernels
+    int gm;          // rasterisation group height in row tiles
+    int fine_pct;    // 256x256 grid fill (percent of the CUs) below which the 128x128 kernel is used
+    int allow_fine;  // 0 = never fall back to the 128x128 kernel for sparse grids
+    int bm;          // 0 = pick the tile height per launch ; 224 / 256 = force it
+    int nt;          // 1 = non-temporal accesses for once-touched epilogue operands
+    int pp;          // 1 = ping-pong main loop (two wave groups staggered by a barrier), 0 = two-phase loop
+};
+TnrGemmOpts* tnr_gemm_opts();
+
 #define TNR_CHECK_ARG(cond, ...)          \
     do {                                  \
         if (!(cond)) {                    \

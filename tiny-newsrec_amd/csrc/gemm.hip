@@ -9,14 +9,9 @@
 // address and again on the read address (cdna_hip_programming.md section 5.4 rule 21).  Two LDS buffers,
 // next tile's loads issued before the current tile's MFMAs, one barrier per K tile; 64 KB LDS per
 // workgroup -> 2 workgroups per CU overlap each other's barrier stalls.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
-
-// rasterisation group height (row tiles per group); TNR_GEMM_GM overrides for experiments
-static int g_group_m = 8;
 
 struct NTArgs {
     const bf16* A; int64_t lda;
@@ -30,7 +25,7 @@ struct NTArgs {
     float* colsum_part;        // TNR_EPI_COLSUM: (rows_of_partials, N) fp32, one row per 64-row strip of C
     int gm;                    // rasterisation group height
     int nt;                    // 1: streaming (non-temporal) accesses for once-touched epilogue operands
-    int tile0;                 // first logical tile of this launch (a GEMM may be issued as several one-round launches)
+    int tile0;                 // first logical tile of this launch (0: one launch per GEMM)
 };
 
 constexpr int TILE_BYTES = 128 * 128;   // one operand tile: 128 rows x 64 bf16
@@ -393,7 +388,6 @@ constexpr int RING2 = 3 * STAGE2;
 
 #define TNR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int PROBE>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -447,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NTArgs g) {
         const char* sa = smem + cur * STAGE2 + (wm >> 1) * TILE_BYTES + ((wm & 1) * 64) * 128;
         const char* sb = smem + cur * STAGE2 + 2 * TILE_BYTES + (wn * 64) * 128;
 #pragma unroll
-        for (int s = 0; s < (PROBE == 1 ? 0 : 2); ++s) {      // PROBE 1: load pipeline only (timing experiment)
+        for (int s = 0; s < 2; ++s) {
             bf16x8 af[4], bfr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
@@ -721,7 +715,7 @@ constexpr int RING3 = 2 * STAGE3;
 // MI = 16-row MFMA tiles per wave along M: tile height BM = 32 * MI (256 or 224).  The host picks the height
 // that minimises ceil(tiles / CUs) * BM for the launch (e.g. N = 768: 621 tiles of 256 rows = 3 rounds on 256 CUs;
 // 708 tiles of 224 rows are 3 rounds too, each 12.5 % shorter).
-template <int PROBE, int MI>
+template <int MI>
 __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PR = 16 * MI, BM = 2 * PR;
@@ -779,7 +773,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
         const char* sa = smem + cur * STAGE3 + wm * TILE_BYTES;
         const char* sb = smem + cur * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
 #pragma unroll
-        for (int s = 0; s < (PROBE == 1 ? 0 : 2); ++s) {
+        for (int s = 0; s < 2; ++s) {
             bf16x8 af[MI], bfr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
@@ -795,498 +789,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
     nt_epilogue_coalesced<MI>(g, acc, smem, lut, bm, bn, wm, wn, lane);
 }
 
-// ================================================================================================
-// v7: the v3 tile and ring with FOUR waves of 128 x 128 (8 x 8 MFMA blocks each, 256 accumulator registers; one wave per
-// SIMD).  Per K tile the workgroup reads 128 KB of fragments from LDS instead of 192 KB and half as many waves meet at the
-// barrier; the layout of the vendor library's hand-scheduled MT256x256x64 kernel.  TNR_GEMM_VER=7.
-template <int PROBE>
-__global__ __launch_bounds__(256, 1) void gemm_nt256x256_w4_kernel(NTArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MI = 8, NJ = 8;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    const int nbn = g.N >> 8;
-    const int nbm = (g.M + 255) / 256;
-    const int wg = xcd_remap(blockIdx.x, nbm * nbn);
-    int bm, bn;
-    tile_coords(wg, nbm, nbn, g.gm, bm, bn);
-
-    // 64 pieces of 1 KiB per stage: wave w loads sub-tile w (A rows 0-127 | A 128-255 | B 0-127 | B 128-255), 16 pieces
-    const bf16* src0;
-    int64_t row_stride8;                                        // 8 rows further down
-    {
-        int row = lane >> 3;
-        int chunk = (lane & 7) ^ (row & 7);                     // (row + 8 q) & 7 == row & 7: the swizzle is the same for every piece
-        if (w < 2) {
-            src0 = g.A + chunk * 8;
-            row_stride8 = 8 * g.lda;
-        } else {
-            src0 = g.B + (int64_t)(bn * 256 + (w - 2) * 128 + row) * g.ldb + chunk * 8;
-            row_stride8 = 8 * g.ldb;
-        }
-    }
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE3 + w * TILE_BYTES;
-        if (w < 2) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                int gm = bm * 256 + w * 128 + q * 8 + (lane >> 3);
-                gm = gm < g.M ? gm : g.M - 1;
-                glds16(src0 + (int64_t)gm * g.lda + kt * 64, base + q * 1024);
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) glds16(src0 + q * row_stride8 + kt * 64, base + q * 1024);
-        }
-    };
-    int foff[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
-
-    f32x4 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    f32x2* lut = (f32x2*)(smem + EPI_BYTES);
-    if (g.flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (g.flags & TNR_EPI_MULDGELU) != 0);
-    const int nk = g.K >> 6;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        TNR_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sa = smem + cur * STAGE3 + wm * TILE_BYTES;
-        const char* sb = smem + cur * STAGE3 + (2 + wn) * TILE_BYTES;
-#pragma unroll
-        for (int s = 0; s < (PROBE == 1 ? 0 : 2); ++s) {
-            bf16x8 af[MI], bfr[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    nt_epilogue_coalesced<MI, NJ, 256>(g, acc, smem, lut, bm, bn, wm, wn, lane);
-}
-
-// ================================================================================================
-// v6: the v3 tile fed by a DEEPER, FINER ring: k advances 32 per step, slot = [A 256 rows | B 256 rows] x 64 B
-// = 32 KB, four slots.  While step h is computed, steps h+1..h+3 (96 KB per CU) are in flight, instead of one
-// 64 KB burst that starts only after the barrier (v3): the loads never drain.  Rows are 64 B, so a 16x16x32
-// operand fragment is 1 KB contiguous; chunk c of row r sits at position c ^ f(r), f(r) = (-(r >> 2)) & 3, which makes
-// every ds_read_b128 lane group cover all 64 banks once.
-constexpr int SLOT6 = 32 * 1024;
-__device__ __forceinline__ int swz6(int row) { return (0 - (row >> 2)) & 3; }
-
-template <int PROBE>
-__global__ __launch_bounds__(512, 2) void gemm_nt256x256_k32_kernel(NTArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MI = 8;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 2, wn = w & 3;
-    const int nbn = g.N >> 8;
-    const int nbm = (g.M + 255) / 256;
-    const int wg = xcd_remap(blockIdx.x, nbm * nbn);
-    int bm, bn;
-    tile_coords(wg, nbm, nbn, g.gm, bm, bn);
-
-    const bf16* src[4];
-    int dst[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int p = w * 4 + q, sub = p >> 4, pp = p & 15;          // piece = 16 rows x 64 B
-        int row = pp * 16 + (lane >> 2);
-        int chunk = (lane & 3) ^ swz6(row);
-        if (sub == 0) {
-            int gm = bm * 256 + row;
-            gm = gm < g.M ? gm : g.M - 1;
-            src[q] = g.A + (int64_t)gm * g.lda + chunk * 8;
-        } else {
-            src[q] = g.B + (int64_t)(bn * 256 + row) * g.ldb + chunk * 8;
-        }
-        dst[q] = sub * (SLOT6 / 2) + pp * 1024;
-    }
-    auto stage = [&](int slot, int h) {
-        char* base = smem + slot * SLOT6;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(src[q] + h * 32, base + dst[q]);
-    };
-    const int foff = (lane & 15) * 64 + (((lane >> 4) ^ swz6(lane & 15)) << 4);
-
-    f32x4 acc[MI][4];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    f32x2* lut = (f32x2*)(smem + EPI_BYTES);
-    if (g.flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (g.flags & TNR_EPI_MULDGELU) != 0);
-    const int nh = g.K >> 5;                                   // >= 2 (K % 64 == 0)
-    stage(0, 0);
-    stage(1, 1);
-    if (nh > 2) stage(2, 2);
-    for (int h = 0; h < nh; ++h) {
-        const int left = nh - 1 - h;                            // steps already issued beyond h: min(left, 2)
-        if (left >= 2) TNR_WAIT_VMCNT(8);
-        else if (left == 1) TNR_WAIT_VMCNT(4);
-        else TNR_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();                           // step h landed everywhere; step h-1 fully consumed
-        if (h + 3 < nh) stage((h + 3) & 3, h + 3);
-        if (PROBE == 0) {
-            const char* sa = smem + (h & 3) * SLOT6 + wm * (128 * 64);
-            const char* sb = smem + (h & 3) * SLOT6 + SLOT6 / 2 + wn * (64 * 64);
-            bf16x8 af[MI], bfr[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 1024 + foff);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + i * 1024 + foff);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    nt_epilogue_coalesced<MI>(g, acc, smem, lut, bm, bn, wm, wn, lane);
-}
-
-// ================================================================================================
-// v4: the v3 tile as a PERSISTENT kernel: one workgroup per CU walks its XCD's run of tiles; the first two
-// K stages of the next tile are issued before the current tile's epilogue, so the epilogue's VALU work and
-// stores run under the next tile's loads instead of leaving the (binding) L2->LDS pipe idle, and no tile but
-// the first pays the cold-start latency of its first loads.
-__global__ __launch_bounds__(512, 2) void gemm_nt256x256_persistent_kernel(NTArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 2, wn = w & 3;
-    const int nbn = g.N >> 8;
-    const int nbm = (g.M + 255) >> 8;
-    const int ntile = nbm * nbn;
-    // tiles of this workgroup: XCD x (= blockIdx % 8 under round-robin dispatch; locality only) owns a
-    // contiguous run of the grouped tile order, its workgroups sweep it side by side
-    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per = (G - xcd + 7) >> 3;
-    const int q8 = ntile >> 3, r8 = ntile & 7;
-    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
-    int tile = c0 + slot;
-    if (tile >= c1) return;
-
-    const int nk = g.K >> 6;
-    const bf16* src[8];
-    int dst[8];
-    int prow[8], pchunk[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        int p = w * 8 + q, pp = p & 15;
-        prow[q] = pp * 8 + (lane >> 3);
-        pchunk[q] = ((lane & 7) ^ (prow[q] & 7)) * 8;
-        dst[q] = (p >> 4) * TILE_BYTES + pp * 1024;
-    }
-    auto set_src = [&](int t) {
-        int bm, bn;
-        tile_coords(t, nbm, nbn, 8, bm, bn);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int sub = (w * 8 + q) >> 4;
-            if (sub < 2) {
-                int gm = bm * 256 + sub * 128 + prow[q];
-                gm = gm < g.M ? gm : g.M - 1;
-                src[q] = g.A + (int64_t)gm * g.lda + pchunk[q];
-            } else {
-                src[q] = g.B + (int64_t)(bn * 256 + (sub - 2) * 128 + prow[q]) * g.ldb + pchunk[q];
-            }
-        }
-    };
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE3;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) glds16(src[q] + kt * 64, base + dst[q]);
-    };
-    int foff[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
-
-    set_src(tile);
-    stage(0, 0);
-    int cur = 0;
-    int issued = 1;                      // K stages of the current tile already issued
-    while (true) {
-        const int next = tile + per < c1 ? tile + per : -1;
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        int bm, bn;
-        tile_coords(tile, nbm, nbn, 8, bm, bn);
-        const int n_base = bn * 256 + wn * 64 + (lane >> 4) * 4;
-        const NTBias bias = nt_load_bias(g, n_base);
-        for (int kt = 0; kt < nk; ++kt) {
-            TNR_WAIT_VMCNT(0);
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) {
-                if (kt + 1 >= issued) stage(cur ^ 1, kt + 1);
-            } else if (next >= 0) {
-                set_src(next);           // the current tile's pointers are no longer needed
-                stage(cur ^ 1, 0);
-            }
-            const char* sa = smem + cur * STAGE3 + wm * TILE_BYTES;
-            const char* sb = smem + cur * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 af[8], bfr[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
-            }
-            cur ^= 1;
-        }
-        issued = 1;
-        if (next >= 0 && nk >= 2) {
-            // second stage of the next tile: the buffer just computed is free once every wave is past its MFMAs
-            __builtin_amdgcn_s_barrier();
-            stage(cur ^ 1, 1);
-            issued = 2;
-        }
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            f32x4 (&a4)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[hh * 4]);
-            nt_epilogue(g, a4, bm * 256 + wm * 128 + hh * 64 + (lane & 15), n_base, bias);
-        }
-        if (next < 0) break;
-        tile = next;
-    }
-}
-
-// ================================================================================================
-// v5: persistent 256x256 kernel with the row-contiguous epilogue staged in the IDLE HALF of the stage ring.
-// One workgroup per CU walks its XCD's run of tiles.  During the last K step of a tile the first K stage of
-// the NEXT tile is issued into the free stage buffer; the epilogue then stages the fp32 tile through the buffer
-// that was just consumed (4 passes of 64 rows, 64 KB, 16-byte chunks XOR-swizzled by row) while that load is in
-// flight, so neither the cold start of a tile nor (part of) its epilogue leaves the L2->LDS pipe idle.
-__global__ __launch_bounds__(512, 2) void gemm_nt256x256_v5_kernel(NTArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: per-piece constants stay in SGPRs
-    const int wm = w >> 2, wn = w & 3;
-    const int nbn = g.N >> 8;
-    const int nbm = (g.M + 255) >> 8;
-    const int ntile = nbm * nbn;
-    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per = (G - xcd + 7) >> 3;
-    const int q8 = ntile >> 3, r8 = ntile & 7;
-    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
-    int tile = c0 + slot;
-    if (tile >= c1) return;
-
-    const int flags = g.flags;
-    f32x2* lut = (f32x2*)(smem + RING3);
-    if (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (flags & TNR_EPI_MULDGELU) != 0);
-
-    const int nk = g.K >> 6;
-    const bf16* src[8];
-    const int lrow = lane >> 3;                       // row of this lane inside an 8-row piece
-    const int lchunk = ((lane & 7) ^ lrow) * 8;       // swizzled 16-byte chunk (piece rows start at multiples of 8)
-    auto set_src = [&](int t) {
-        int bm, bn;
-        tile_coords(t, nbm, nbn, g.gm, bm, bn);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int p = w * 8 + q, sub = p >> 4, row = (p & 15) * 8 + lrow;
-            if (sub < 2) {
-                int gm = bm * 256 + sub * 128 + row;
-                gm = gm < g.M ? gm : g.M - 1;
-                src[q] = g.A + (int64_t)gm * g.lda + lchunk;
-            } else {
-                src[q] = g.B + (int64_t)(bn * 256 + (sub - 2) * 128 + row) * g.ldb + lchunk;
-            }
-        }
-    };
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE3;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int p = w * 8 + q;
-            glds16(src[q] + kt * 64, base + (p >> 4) * TILE_BYTES + (p & 15) * 1024);
-        }
-    };
-    int foff[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
-
-    // epilogue thread mapping: 8 consecutive columns (two 16-byte chunks), row group 0..15
-    const int c8 = (tid & 31) * 8, rg = tid >> 5;
-    const int ck0 = (tid & 31) * 2;
-
-    set_src(tile);
-    stage(0, 0);
-    int cur = 0;
-    while (true) {
-        const int next = tile + per < c1 ? tile + per : -1;
-        int bm, bn;
-        tile_coords(tile, nbm, nbn, g.gm, bm, bn);
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            TNR_WAIT_VMCNT(0);
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) {
-                stage(cur ^ 1, kt + 1);
-            } else if (next >= 0) {
-                set_src(next);
-                stage(cur ^ 1, 0);
-            }
-            const char* sa = smem + cur * STAGE3 + wm * TILE_BYTES;
-            const char* sb = smem + cur * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 af[8], bfr[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = TNR_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
-            }
-            cur ^= 1;
-        }
-        // ---- epilogue: staging buffer = the stage consumed last (cur ^ 1 after the toggle); the other one is receiving
-        char* stg = smem + (cur ^ 1) * STAGE3;
-        const int n = bn * 256 + c8;
-        f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (flags & TNR_EPI_BIAS) {
-            b0 = *(const f32x4*)(g.bias + n);
-            b1 = *(const f32x4*)(g.bias + n + 4);
-        }
-        float cs[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            __builtin_amdgcn_s_barrier();              // staging rows of the previous pass / the K loop are consumed
-            if (wm == (pass >> 1)) {
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int row = ii * 16 + (lane & 15);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int ck = wn * 16 + j * 4 + (lane >> 4);
-                        *(f32x4*)(stg + row * 1024 + ((ck ^ (row & 15)) << 4)) = acc[(pass & 1) * 4 + ii][j];
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const int m0 = bm * 256 + pass * 64;
-            bf16x8 rr[4], uu[4];
-            if (flags & TNR_EPI_RES) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    int m = m0 + rg + 16 * it;
-                    m = m < g.M ? m : g.M - 1;
-                    rr[it] = *(const bf16x8*)(g.res + (int64_t)m * g.ldres + n);
-                }
-            }
-            if (flags & TNR_EPI_MULDGELU) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    int m = m0 + rg + 16 * it;
-                    m = m < g.M ? m : g.M - 1;
-                    uu[it] = *(const bf16x8*)(g.aux + (int64_t)m * g.ldaux + n);
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = rg + 16 * it;
-                const int m = m0 + row;
-                if (m >= g.M) continue;
-                f32x4 v0 = *(const f32x4*)(stg + row * 1024 + ((ck0 ^ (row & 15)) << 4)) + b0;
-                f32x4 v1 = *(const f32x4*)(stg + row * 1024 + (((ck0 + 1) ^ (row & 15)) << 4)) + b1;
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if (flags & TNR_EPI_AUXOUT) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                    *(bf16x8*)(g.aux + (int64_t)m * g.ldaux + n) = o;
-                }
-                if (flags & TNR_EPI_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = lut_eval<false>(lut, v[e]);
-                }
-                if (flags & TNR_EPI_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-                }
-                if (flags & TNR_EPI_MULDGELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= lut_eval<true>(lut, (float)uu[it][e]);
-                }
-                if (flags & TNR_EPI_RES) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rr[it][e];
-                }
-                if (flags & TNR_EPI_OUTF32) {
-                    float* c = (float*)g.C + (int64_t)m * g.ldc + n;
-                    *(f32x4*)c = (f32x4){v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                } else {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        o[e] = (bf16)v[e];
-                        cs[e] += (float)o[e];
-                    }
-                    *(bf16x8*)((bf16*)g.C + (int64_t)m * g.ldc + n) = o;
-                }
-            }
-        }
-        if (flags & TNR_EPI_COLSUM) {
-            __builtin_amdgcn_s_barrier();
-            float* red = (float*)stg;                              // [16][256]
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[rg * 256 + c8 + e] = cs[e];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (tid < 256) {
-                float t = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
-                float* pr = g.colsum_part + (int64_t)(bm * 4) * g.N + bn * 256 + tid;
-                pr[0] = t;
-                pr[g.N] = 0.f;
-                pr[2 * (int64_t)g.N] = 0.f;
-                pr[3 * (int64_t)g.N] = 0.f;
-            }
-        }
-        if (next < 0) break;
-        tile = next;
-    }
-}
-
 // wgrad v3: output tile 256 (n) x 256 (k); stage = [dY cols 0-127 | dY cols 128-255 | X cols 0-127 | X cols 128-255]
-template <int PROBE>
 __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1349,7 +852,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
             const char* sy = smem + cur * STAGE3 + wn * TILE_BYTES;
             const char* sx = smem + cur * STAGE3 + (2 + (wk >> 1)) * TILE_BYTES;
 #pragma unroll
-            for (int s = 0; s < (PROBE == 1 ? 0 : 2); ++s) {
+            for (int s = 0; s < 2; ++s) {
                 bf16x8 yf[8], xf[4];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
@@ -1411,6 +914,43 @@ extern "C" int TNR_NAME(tnr_gemm_nt)(const void* A, int64_t lda, const void* B, 
 
 extern "C" int64_t TNR_NAME(tnr_gemm_colsum_rows)(int64_t M) { return ((M + 255) / 256) * 4; }
 
+// ---- routing ---------------------------------------------------------------------------------------
+// Which kernel a launch takes depends on the shape only (and on the process-wide options of api.cpp, which tools set
+// through tnr_gemm_set_option -- the library never reads the environment).  tnr_gemm_nt_route() exposes the decision
+// so that the parity tests can pin every route.
+static int device_cus() {
+    static int cus[64] = {0};
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return 256;
+    if (cus[devid] == 0) {
+        hipDeviceProp_t prop;
+        int n = 256;
+        if (hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+        cus[devid] = n;
+    }
+    return cus[devid];
+}
+
+static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
+    const TnrGemmOpts& o = *tnr_gemm_opts();
+    // short inputs (stage-1 title / body passes, small eval batches): when the 256x256 grid would leave more than 40 % of
+    // the CUs without a tile, the 128x128 kernel (2 workgroups per CU) spreads the same work four times finer
+    const bool sparse256 = (N % 256) == 0 && ((M + 255) / 256) * (N / 256) * 100 < (int64_t)n_cu * o.fine_pct && !(flags & TNR_EPI_COLSUM);
+    const bool odd_gelu = (N % 256) != 0 && (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU));   // the 256x128 kernel has no table GELU
+    if (o.ver == 1 || M <= 128 || odd_gelu || (sparse256 && o.allow_fine)) return TNR_ROUTE_128x128;
+    if (o.ver == 2 || (N % 256) != 0) return TNR_ROUTE_256x128;
+    // tile height: 256 or 224 rows, whichever needs less (rounds of workgroups) x (rows per tile)
+    const int64_t t256 = ((M + 255) / 256) * (N / 256), t224 = ((M + 223) / 224) * (N / 256);
+    const int64_t c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
+    bool use224 = c224 * 108 < c256 * 100 && !(flags & TNR_EPI_COLSUM);   // per-tile fixed costs: need a clear win
+    if (o.bm) use224 = o.bm == 224 && !(flags & TNR_EPI_COLSUM);
+    return use224 ? TNR_ROUTE_224x256 : TNR_ROUTE_256x256;
+}
+
+extern "C" int TNR_NAME(tnr_gemm_nt_route)(int64_t M, int64_t N, int64_t K, int flags) {
+    return nt_route(M, N, K, flags, device_cus());
+}
+
 extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                               void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream) {
@@ -1428,100 +968,31 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
     TNR_CHECK_ARG(M < (1 << 24), "tnr_gemm_nt: M too large");
     TNR_CHECK_ARG(!(flags & TNR_EPI_COLSUM) || (colsum_part && !(flags & TNR_EPI_OUTF32) && M > 128),
                   "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
+    const TnrGemmOpts& o = *tnr_gemm_opts();
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, g_group_m, 0, 0};
-    { const char* nt_s = getenv("TNR_GEMM_NT"); if (nt_s && nt_s[0] == '1') g.nt = 1; }     // A/B switch (read per call)
-    static const char* gm_s = getenv("TNR_GEMM_GM");
-    if (gm_s) g.gm = atoi(gm_s) > 0 ? atoi(gm_s) : 8;
-    { const char* sn_s = getenv("TNR_GEMM_SNAKE"); if (sn_s && sn_s[0] == '1') g.gm = -g.gm; }
-    const char* ver_s = getenv("TNR_GEMM_VER");        // read per call: tools/gemm_ab.py flips it inside one process
-    const int ver = ver_s ? atoi(ver_s) : 3;          // 5 = persistent variant (A/B: within noise of 3)
-    static const char* probe_s = getenv("TNR_GEMM_PROBE");
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int devid = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
-            n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    static const bool probe = probe_s && probe_s[0] == '1';
-    static bool attr_set = false;
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0};
+    static bool attr_set = false;       // function attributes are per code object, not per device
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + LUT_N * 8);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_w4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_k32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_k32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_v5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3 + LUT_N * 8);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    // short inputs (stage-1 title / body passes, small eval batches): when the 256x256 grid would leave more than 40 % of
-    // the CUs without a tile, the 128x128 kernel (2 workgroups per CU) spreads the same work four times finer
-    const char* pct_s = getenv("TNR_GEMM_FINE_PCT");   // per call (A/B): fill threshold in percent of the CUs
-    const int fine_pct = pct_s ? atoi(pct_s) : 60;
-    const bool sparse256 = (N % 256) == 0 && ((M + 255) / 256) * (N / 256) * 100 < (int64_t)n_cu * fine_pct && !(flags & TNR_EPI_COLSUM);
-    const char* fine_s = getenv("TNR_GEMM_FINE");      // per call (A/B)
-    const bool allow_fine = !fine_s || fine_s[0] != '0';
-    const bool odd_gelu = (N % 256) != 0 && (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) && ver != 2;   // v2 has no table GELU
-    if (ver == 1 || M <= 128 || odd_gelu || (sparse256 && allow_fine && ver == 3 && !probe)) {
-        int nwg = (int)(((M + 127) / 128) * (N / 128));
-        hipLaunchKernelGGL(gemm_nt_kernel, dim3(nwg), dim3(256), 2 * BUF_BYTES + LUT_N * 8, st, g);
-    } else if (ver == 2 || (N % 256) != 0) {
-        int nwg = (int)(((M + 255) / 256) * (N / 128));
-        if (probe) hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), RING2, st, g);
-        else hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), RING2, st, g);
-    } else if (ver == 7) {
-        const int64_t t256 = ((M + 255) / 256) * (N / 256);
-        if (probe) hipLaunchKernelGGL(gemm_nt256x256_w4_kernel<1>, dim3((int)t256), dim3(256), LDS3_BYTES, st, g);
-        else hipLaunchKernelGGL(gemm_nt256x256_w4_kernel<0>, dim3((int)t256), dim3(256), LDS3_BYTES, st, g);
-    } else if (ver == 6) {
-        const int64_t t256 = ((M + 255) / 256) * (N / 256);
-        if (probe) hipLaunchKernelGGL(gemm_nt256x256_k32_kernel<1>, dim3((int)t256), dim3(512), LDS3_BYTES, st, g);
-        else hipLaunchKernelGGL(gemm_nt256x256_k32_kernel<0>, dim3((int)t256), dim3(512), LDS3_BYTES, st, g);
-    } else if (ver == 5 && !probe) {
-        // persistent kernel unless the 224-row tiling of the non-persistent one is the better deal for this shape
-        static const char* bm_s = getenv("TNR_GEMM_BM");
-        const int64_t t256 = ((M + 255) / 256) * (N / 256), t224 = ((M + 223) / 224) * (N / 256);
-        const int64_t c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
-        bool use224 = c224 * 108 < c256 * 100 && !(flags & TNR_EPI_COLSUM);
-        if (bm_s) use224 = atoi(bm_s) == 224 && !(flags & TNR_EPI_COLSUM);
-        if (use224) {
-            hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 7>), dim3((int)t224), dim3(512), LDS3_BYTES, st, g);
-        } else {
-            int nwg = (int)(t256 < n_cu ? t256 : n_cu);
-            hipLaunchKernelGGL(gemm_nt256x256_v5_kernel, dim3(nwg), dim3(512), RING3 + LUT_N * 8, st, g);
-        }
-    } else if (ver == 3 || probe) {
-        // tile height: 256 or 224 rows, whichever needs less (rounds of workgroups) x (rows per tile)
-        static const char* bm_s = getenv("TNR_GEMM_BM");
-        const int64_t t256 = ((M + 255) / 256) * (N / 256), t224 = ((M + 223) / 224) * (N / 256);
-        const int64_t c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
-        bool use224 = c224 * 108 < c256 * 100 && !(flags & TNR_EPI_COLSUM);   // per-tile fixed costs: need a clear win
-        if (bm_s) use224 = atoi(bm_s) == 224 && !(flags & TNR_EPI_COLSUM);
-        // TNR_GEMM_ROUNDS=1: one launch per round of workgroups, so that every round starts in lock-step again
-        const char* rounds_s = getenv("TNR_GEMM_ROUNDS");
-        const bool by_round = rounds_s && rounds_s[0] == '1' && !probe;
-        const int64_t total = use224 ? t224 : t256;
-        const int64_t per = by_round ? n_cu : total;
-        for (int64_t t0 = 0; t0 < total; t0 += per) {
-            const int nlaunch = (int)(total - t0 < per ? total - t0 : per);
-            g.tile0 = (int)t0;
-            if (probe) hipLaunchKernelGGL((gemm_nt256x256_kernel<1, 8>), dim3(nlaunch), dim3(512), LDS3_BYTES, st, g);
-            else if (use224) hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 7>), dim3(nlaunch), dim3(512), LDS3_BYTES, st, g);
-            else hipLaunchKernelGGL((gemm_nt256x256_kernel<0, 8>), dim3(nlaunch), dim3(512), LDS3_BYTES, st, g);
-        }
-    } else {
-        int ntile = (int)(((M + 255) / 256) * (N / 256));
-        int nwg = ntile < n_cu ? ntile : n_cu;
-        hipLaunchKernelGGL(gemm_nt256x256_persistent_kernel, dim3(nwg), dim3(512), RING3, st, g);
+    switch (nt_route(M, N, K, flags, device_cus())) {
+    case TNR_ROUTE_128x128:
+        hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(((M + 127) / 128) * (N / 128))), dim3(256), 2 * BUF_BYTES + LUT_N * 8, st, g);
+        break;
+    case TNR_ROUTE_256x128:
+        hipLaunchKernelGGL(gemm_nt256_kernel, dim3((unsigned)(((M + 255) / 256) * (N / 128))), dim3(512), RING2, st, g);
+        break;
+    case TNR_ROUTE_224x256:
+        hipLaunchKernelGGL((gemm_nt256x256_kernel<7>), dim3((unsigned)(((M + 223) / 224) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
+        break;
+    default:
+        hipLaunchKernelGGL((gemm_nt256x256_kernel<8>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
+        break;
     }
     TNR_CHECK_LAUNCH("tnr_gemm_nt");
     return TNR_OK;
@@ -1545,12 +1016,11 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad)(const void* dY, int64_t lddy, const v
     int tps = (Mt + splits - 1) / splits;
     splits = (Mt + tps - 1) / tps;
     TNArgs g{(const bf16*)dY, lddy, (const bf16*)X, ldx, ws, Mt, (int)N, (int)K, tps, splits};
-    static const char* ver_s = getenv("TNR_GEMM_VER");
-    static const int ver = ver_s ? atoi(ver_s) : 3;
+    const int ver = tnr_gemm_opts()->ver;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
-        (void)hipFuncSetAttribute((const void*)gemm_tn256x256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         attr_set = true;
     }
     if (ver == 1 || (N % 256) != 0) {
@@ -1561,7 +1031,7 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad)(const void* dY, int64_t lddy, const v
         hipLaunchKernelGGL(gemm_tn256_kernel, grid, dim3(512), RING2, (hipStream_t)stream, g);
     } else {
         dim3 grid((unsigned)((N / 256) * (K / 256) * splits));
-        hipLaunchKernelGGL(gemm_tn256x256_kernel<0>, grid, dim3(512), RING3, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(gemm_tn256x256_kernel, grid, dim3(512), RING3, (hipStream_t)stream, g);
     }
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad");
     int64_t NK = N * K;

@@ -8,6 +8,7 @@ Every nn.Parameter is a view into the engine's flat fp32 buffers; total_loss.bac
 HIP backward and leaves gradients in the parameters' .grad (views of the flat gradient buffer).  The module is
 a thin shell: no arithmetic happens in torch, and construction fails if libtnr_hip.so is missing."""
 import json
+import logging
 
 import torch
 from torch import nn
@@ -15,15 +16,26 @@ from torch import nn
 import engine as E
 
 
+def read_model_config(path, synthetic=False):
+    """The tnlrv3 / BERT config json.  path None = UniLMv2-base sizes (tests, synthetic runs); a path that cannot be read
+    raises, as config_class.from_pretrained does (model_bert.py:110) -- a mistyped --config_name must not silently train a
+    768/12/3072 encoder.  Only --synthetic runs, which need no files at all, fall back (with a warning)."""
+    if path is None:
+        return {}
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError) as e:
+        if synthetic:
+            logging.warning("--config_name %s unreadable (%s): synthetic run, UniLMv2-base sizes assumed", path, e)
+            return {}
+        raise FileNotFoundError("--config_name %s cannot be read: %s" % (path, e)) from e
+
+
 def engine_config_from_args(args, num_teachers=None, is_teacher=False):
     """parameters.py flags -> EngineConfig.  Model sizes come from the tnlrv3 config json like
     config_class.from_pretrained(args.config_name, num_hidden_layers=...) at model_bert.py:110-113."""
-    cfg = {}
-    try:
-        with open(args.config_name) as f:
-            cfg = json.load(f)
-    except (OSError, TypeError, ValueError):
-        pass
+    cfg = read_model_config(getattr(args, "config_name", None), getattr(args, "synthetic", False))
     nl = args.num_teacher_layers if is_teacher else args.num_student_layers
     T_ = args.num_teachers if num_teachers is None else num_teachers
     return E.EngineConfig(
@@ -70,13 +82,20 @@ def reference_init(engine, seed=0):
     engine.refresh_shadows(all_layers=True)
 
 
-def load_pretrained_into(engine, path, seed=0):
+def load_pretrained_into(engine, path, seed=0, allow_missing=False):
     """model_class.from_pretrained(args.model_name, config=...) (model_bert.py:114) for the student's encoder of
     `engine`: convert the unilm2 checkpoint (tnlrv3/convert_state_dict.py), fit the position table, keep the first
-    n_layers layers.  -> (missing, unexpected), or None when there is no checkpoint at `path`."""
+    n_layers layers.  -> (missing, unexpected).  A path that does not exist raises like from_pretrained does, unless
+    allow_missing (--synthetic / --allow_random_init): then None is returned and the initialisation stays."""
     import os
-    if not path or not os.path.exists(path):
+    if not path:
         return None
+    if not os.path.exists(path):
+        if allow_missing:
+            logging.warning("pretrained encoder %s not found: keeping the construction-time initialisation", path)
+            return None
+        raise FileNotFoundError("--model_name %s does not exist (pass --allow_random_init True to train from the "
+                                "construction-time initialisation)" % path)
     from tnlrv3 import convert_state_dict as C
     cfg = engine.cfg
     wanted = {k: tuple(v.shape) for k, v in engine.params.items()}
@@ -130,7 +149,7 @@ class Model(_Shell):
         self.args = args
         dev = device or ("cuda:%d" % torch.cuda.current_device())
         self.engine = E.Engine(engine_config_from_args(args), dev, max_batch=max_batch or args.batch_size,
-                               dtype=getattr(args, "dtype", "bf16"))
+                               dtype=getattr(args, "dtype", "fp16"))
         self._adopt(self.engine, "")
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self._after_bucket = None
@@ -143,9 +162,14 @@ class Model(_Shell):
         reference_init(self.engine, seed)
 
     def load_pretrained(self, path):
-        """-> (missing, unexpected) or None when there is no checkpoint at `path` (synthetic / offline runs: the
-        construction-time initialisation stays)."""
-        return load_pretrained_into(self.engine, path)
+        """-> (missing, unexpected); None only for path None or (--synthetic / --allow_random_init) a missing file."""
+        a = self.args
+        allow = bool(getattr(a, "synthetic", False) or getattr(a, "allow_random_init", False))
+        rep = load_pretrained_into(self.engine, path, allow_missing=allow)
+        if rep is not None:      # the reference prints what it loaded / initialised (tnlrv3/modeling.py:53-130)
+            logging.info("pretrained encoder %s: %d missing keys %s, %d unexpected keys %s", path, len(rep[0]), list(rep[0])[:8],
+                         len(rep[1]), list(rep[1])[:8])
+        return rep
 
     def _engine_key(self, name):
         return name

@@ -59,7 +59,8 @@ def parse_args(argv=None):
     p.add_argument("--max_steps", type=int, default=0, help="stop an epoch early (0 = whole corpus)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--enable_hvd", type=b, default=True, help="data-parallel when launched by torch.distributed.run")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
+    p.add_argument("--allow_random_init", type=b, default=False, help="train from the construction-time initialisation when --model_name does not exist")
     p.add_argument("--synthetic", type=b, default=False, help="hash-initialised weights + synthetic corpus / teacher tables")
     p.add_argument("--synthetic_docs", type=int, default=20000)
     a = p.parse_args(argv)
@@ -115,13 +116,8 @@ def sample_indices(rng, positives, n_docs, k):
 
 
 def _model_dims(args):
-    import json
-    cfg = {}
-    try:
-        with open(args.config_name) as f:
-            cfg = json.load(f)
-    except (OSError, TypeError, ValueError):
-        pass
+    from model_bert import read_model_config
+    cfg = read_model_config(args.config_name, args.synthetic)
     return dict(hidden=cfg.get("hidden_size", 768), heads=cfg.get("num_attention_heads", 12), inter=cfg.get("intermediate_size", 3072),
                 vocab=cfg.get("vocab_size", 30522), max_pos=max(cfg.get("max_position_embeddings", 512), args.max_body_len),
                 type_vocab=cfg.get("type_vocab_size", 2), ln_eps=cfg.get("layer_norm_eps", 1e-12),
@@ -174,7 +170,7 @@ def train(args):
         eng.load_state_dict({k: torch.from_numpy(hashinit.init_tensor(1234, k, tuple(s))) for k, s in eng.shapes.items()})
     else:
         reference_init(eng.title, args.seed)
-        rep = load_pretrained_into(eng.title, args.model_name, args.seed)
+        rep = load_pretrained_into(eng.title, args.model_name, args.seed, allow_missing=args.allow_random_init)
         logging.info("pretrained encoder: %s", "not found, random init" if rep is None else "%d missing / %d unexpected keys" % (len(rep[0]), len(rep[1])))
         eng.body.refresh_rel()
     t_eng = eng.title
@@ -201,7 +197,8 @@ def train(args):
         order = list(range(n_docs))
         random.Random(args.seed + ep).shuffle(order)                               # DataLoader(shuffle=True), same on every rank
         order = order[rank::size]
-        steps = len(order) // B if not args.max_steps else min(args.max_steps, len(order) // B)
+        per_rank = (n_docs // size) // B                        # the same on every rank (len(order) differs by one across ranks)
+        steps = per_rank if not args.max_steps else min(args.max_steps, per_rank)
         sums = torch.zeros(5, device=dev)                                          # loss, target, distill, emb, acc
         t0 = time.time()
         for cnt in range(1, steps + 1):

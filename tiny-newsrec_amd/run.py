@@ -84,6 +84,7 @@ def train(args):
     if args.synthetic:
         import synth
         steps = min(args.max_steps_per_epoch, 200)
+        steps_cap = steps
         hidx, mask, cidx, label = [torch.from_numpy(x).cuda() for x in
                                    synth.impressions(77 + rank, steps * args.batch_size, len(news_index), args.user_log_length, args.npratio + 1)]
         B = args.batch_size
@@ -102,6 +103,11 @@ def train(args):
         paths = get_worker_files(args.train_data_dir, rank, size, args.filename_pat, args.enable_shuffle, 0)
         n = sum(stat[f] for f in paths)
         logging.info("[{}] contains {} samples {} steps".format(rank, n, n // args.batch_size))
+        # uneven shards: every rank runs the step count the shortest shard allows (the last batch may be short, streaming.py:76),
+        # otherwise the rank that finishes first leaves the others waiting in the gradient all-reduce
+        steps_cap = dist.min_over_ranks(-(-n // args.batch_size))
+        if size > 1:
+            logging.info("[{}] {} steps per epoch on every rank (shortest shard)".format(rank, steps_cap))
         loader = DataLoaderTrain(teacher_embs=teacher_embs, news_index=news_index, news_combined=news_combined, word_dict=None,
                                  data_dir=args.train_data_dir, filename_pat=args.filename_pat, args=args, world_size=size,
                                  worker_rank=rank, cuda_device_idx=local, enable_prefetch=True, enable_shuffle=True,
@@ -116,7 +122,7 @@ def train(args):
     for ep in range(args.start_epoch, args.epochs):
         loss_sum, acc_sum, t0 = torch.zeros((), device="cuda"), torch.zeros((), device="cuda"), time.time()
         for cnt, batch in enumerate(batches()):
-            if cnt > args.max_steps_per_epoch:
+            if cnt > args.max_steps_per_epoch or cnt >= steps_cap:
                 break
             if isinstance(batch, IndexBatch):
                 h, m, c, y, plan = batch
@@ -125,7 +131,8 @@ def train(args):
                 else:
                     total, distill, emb, target, y_student = model.forward_indexed(dev_news, h, m, c, y, dev_tab, plan)
             elif plmnr:
-                total, y_student = model(*batch[:4])
+                h, m, c, y = batch[:4]
+                total, y_student = model(h, m, c, y)
             else:
                 h, m, c, y, th, tc = batch
                 total, distill, emb, target, y_student = model(h, m, c, y, th, tc)
@@ -170,7 +177,7 @@ def _forward_engine(args, n_layers, sd, add_prefix=""):
     a = types.SimpleNamespace(**vars(args))
     a.num_student_layers, a.bert_trainable_layer = n_layers, []
     cfg = engine_config_from_args(a, num_teachers=0)
-    eng = E.Engine(cfg, "cuda:%d" % torch.cuda.current_device(), max_batch=args.batch_size, dtype=getattr(args, "dtype", "bf16"))
+    eng = E.Engine(cfg, "cuda:%d" % torch.cuda.current_device(), max_batch=args.batch_size, dtype=getattr(args, "dtype", "fp16"))
     src = {add_prefix + k: v for k, v in sd.items()}
     eng.load_state_dict({k: src[k] for k in eng.shapes})
     return eng

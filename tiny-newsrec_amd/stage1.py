@@ -27,7 +27,7 @@ from engine import Engine, EngineConfig
 
 class Stage1Engine:
     def __init__(self, n_layers=4, trainable_layers=(0, 1, 2, 3), num_teachers=4, npratio=4, title_len=30, body_len=256,
-                 device="cuda:0", batch=32, dtype="bf16", **dims):
+                 device="cuda:0", batch=32, dtype="fp16", **dims):
         """dims: hidden, heads, inter, news_dim, news_query, vocab, ... (EngineConfig keywords)."""
         # num_teachers = 0 is stage 0: TitleBodySimModel of Domian-specific_Post-train.ipynb (cells 10-11), plain CE
         common = dict(n_layers=n_layers, trainable_layers=trainable_layers, num_teachers=num_teachers, user_log_length=0,

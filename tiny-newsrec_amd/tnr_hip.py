@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtnr_hip.so")
 
 BF16, F16, F32 = 0, 1, 2
+ROUTE_128, ROUTE_256x128, ROUTE_256, ROUTE_224 = 128, 2128, 256, 224
 EPI_BIAS, EPI_GELU, EPI_TANH, EPI_RES, EPI_MULDGELU, EPI_OUTF32, EPI_AUXOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64, 128
 
 _c = ctypes
@@ -23,6 +24,8 @@ _SIG = {
     "tnr_gemm_nt": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P, _L, _I, _P],
     "tnr_gemm_nt_ex": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P, _L, _I, _P, _P],
     "tnr_gemm_colsum_rows": [_L],
+    "tnr_gemm_nt_route": [_L, _L, _L, _I],
+    "tnr_gemm_set_option": [_c.c_char_p, _I],
     "tnr_gemm_tn_wgrad": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _P],
     "tnr_gemm_tn_ws_elems": [_L, _L, _I],
     "tnr_ln_fwd": [_P, _P, _P, _F, _P, _P, _L, _I, _P],
@@ -62,7 +65,7 @@ _SIG = {
     "tnr_cast_bf16_to_f32": [_P, _P, _L, _P],
 }
 # entry points that exist twice: bf16 (plain name) and fp16 (suffix _f16)
-TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_colsum_rows",
+TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_colsum_rows", "tnr_gemm_nt_route",
          "tnr_gemm_tn_wgrad", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd",
          "tnr_colsum", "tnr_colsum_batched", "tnr_attpool_fwd", "tnr_attpool_bwd", "tnr_refresh_shadows",
          "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32", "tnr_pool_fwd", "tnr_pool_bwd"]
@@ -131,7 +134,7 @@ def call(name, *args):
     rc = getattr(L, name)(*conv, stream())
     if rec is not None:
         e1.record()
-        rec.append((e0, e1, _work(name, conv)))
+        rec.append((e0, e1, _work(name, conv), (conv[6], conv[7], conv[8], conv[14]) if "gemm_nt" in name else None))
     if rc != 0:
         raise TnrError("%s failed (%d): %s" % (name, rc, L.tnr_last_error().decode()))
 

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import engine as E, hashinit
-from helpers import FULL, state_shapes
+from schema import FULL, state_shapes
 from oracle import newsrec_oracle as O
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20

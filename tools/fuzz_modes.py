@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd")); sys.path.insert(0, o
 import numpy as np, torch
 import engine as E, hashinit, synth
 from dedup import build_plan
-from helpers import FULL, state_shapes
+from schema import FULL, state_shapes
 from oracle import newsrec_oracle as O
 from stage1 import Stage1Engine
 
