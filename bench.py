@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--frozen-cache", action="store_true",
                     help="with --dedup only: also take the frozen lower layers from the per-news cache in the headline loop "
                          "(run.py's default mode; not the BASELINE workload, which recomputes every layer)")
+    ap.add_argument("--gemm-opt", action="append", default=[], metavar="KEY=INT",
+                    help="tools only: tnr_gemm_set_option(KEY, INT) before the run (A/B profiles; the default is the shipped configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -144,6 +146,9 @@ def main():
     import tnr_hip as T
     from schema import FULL, state_shapes
 
+    for kv in a.gemm_opt:
+        k_, v_ = kv.split("=")
+        assert T.lib().tnr_gemm_set_option(k_.encode(), int(v_)) == 0, kv
     if a.force_dp and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

@@ -41,6 +41,7 @@ struct TnrGemmOpts {
     int bm;          // 0 = pick the tile height per launch ; 224 / 256 = force it
     int nt;          // 1 = non-temporal accesses for once-touched epilogue operands
     int pp;          // 1 = ping-pong main loop (two wave groups staggered by a barrier), 0 = two-phase loop
+    int probe;       // timing probes of the ping-pong kernel (only in -DTNR_PROBES builds, tools/probe_build.sh)
 };
 TnrGemmOpts* tnr_gemm_opts();
 

@@ -9,6 +9,8 @@
 // address and again on the read address (cdna_hip_programming.md section 5.4 rule 21).  Two LDS buffers,
 // next tile's loads issued before the current tile's MFMAs, one barrier per K tile; 64 KB LDS per
 // workgroup -> 2 workgroups per CU overlap each other's barrier stalls.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -26,6 +28,8 @@ struct NTArgs {
     int gm;                    // rasterisation group height
     int nt;                    // 1: streaming (non-temporal) accesses for once-touched epilogue operands
     int tile0;                 // first logical tile of this launch (0: one launch per GEMM)
+    int probe;                 // timing probes (tools only, TNR_PROBES builds): 1 no staging loads in the K loop, 2 no
+                               // fragment reads / MFMAs, 4 every row tile reads A rows 0-255 (A resident in L2), 8 no epilogue
 };
 
 constexpr int TILE_BYTES = 128 * 128;   // one operand tile: 128 rows x 64 bf16
@@ -789,6 +793,405 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
     nt_epilogue_coalesced<MI>(g, acc, smem, lut, bm, bn, wm, wn, lane);
 }
 
+// ---- register-transposed epilogue of the ping-pong kernel -------------------------------------------
+// The accumulator layout gives lane (m = lane & 15, q = lane >> 4) four consecutive columns 16 j + 4 q + r of row m in block
+// j = 0..3.  A 4 x 4 transpose between the four q-lanes of a row and the four j registers (two v_permlane32_swap + two
+// v_permlane16_swap per dword: lane bit 5 <-> j bit 1, lane bit 4 <-> j bit 0) leaves lane q' with columns 16 q' .. 16 q' + 15
+// of its row: 64 contiguous bytes of fp32, 32 of 16-bit output, i.e. every row of a 16-row block is written as one full
+// 128-byte line by two 16-byte stores per lane -- no LDS staging, no barriers (the LDS-staged epilogue of the two-phase kernel
+// cost 6.8-10 us of a 28 us tile at K = 768: tools/gemm_probe.py), and the stage ring is free for the next tile's loads.
+// Residual / pre-activation operands are read in the same layout (prefetched one block ahead); bias, table GELU, GELU',
+// tanh, residual and the optional pre-activation side output work on the lane's 16 columns; column sums (bias gradient of
+// the producing Linear) are reduced over the 16 rows of a block by row-wise shuffles and over blocks in registers.
+// v_permlane32_swap a, b: lanes 32-63 of a <-> lanes 0-31 of b ; v_permlane16_swap: odd 16-lane rows of a <-> even rows of b
+// (checked on MI355X: tools/scratch/permlane_test.hip, transpose_test.hip).  NB never __builtin_bit_cast an ext-vector ELEMENT
+// (bit_cast(unsigned, acc[i][j][d]) reads element 0 for every d on hipcc 7.2): copy the element to a float first.
+__device__ __forceinline__ void lane_swap32(float& a, float& b) {
+    auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(t[0]);
+    b = __uint_as_float(t[1]);
+}
+__device__ __forceinline__ void lane_swap16(float& a, float& b) {
+    auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(t[0]);
+    b = __uint_as_float(t[1]);
+}
+
+template <int MI>
+__device__ __forceinline__ void nt_epilogue_direct(const NTArgs& g, f32x4 (&acc)[MI][4], const f32x2* lut, int bm, int bn,
+                                                   int wm, int wn, int lane) {
+    constexpr int PR = 16 * MI, BM = 2 * PR;
+    const int flags = g.flags;
+    const int m16 = lane & 15, qd = lane >> 4;
+    const int n0 = bn * 256 + wn * 64 + qd * 16;                 // this lane's 16 columns after the transpose
+    const int row0 = bm * BM + wm * PR + m16;
+#if defined(TNR_PROBES) && TNR_PROBES >= 2
+    const int n0s = (g.probe & 32) ? wn * 64 + qd * 16 : n0, row0s = (g.probe & 32) ? wm * PR + m16 : row0;
+    const bool do_store = !(g.probe & 16);
+#else
+    const int n0s = n0, row0s = row0;
+    constexpr bool do_store = true;
+#endif
+    float bb[16];
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+        f32x4 t = (flags & TNR_EPI_BIAS) ? *(const f32x4*)(g.bias + n0 + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bb[e] = t[0]; bb[e + 1] = t[1]; bb[e + 2] = t[2]; bb[e + 3] = t[3];
+    }
+    float cs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.f;
+    const bool pre_aux = (flags & TNR_EPI_MULDGELU) != 0;
+    const bool pre_res = !pre_aux && (flags & TNR_EPI_RES) != 0;
+    // one prefetched 16-bit operand row segment per block (the engine never combines RES with MULDGELU)
+    const bf16* xsrc = pre_aux ? (const bf16*)g.aux : g.res;
+    const int64_t xld = pre_aux ? g.ldaux : g.ldres;
+    bf16x8 x0 = {}, x1 = {};
+    auto xload = [&](int i, bf16x8& a, bf16x8& b) {
+        int m = row0 + i * 16;
+        m = m < g.M ? m : g.M - 1;
+        const bf16* p = xsrc + (int64_t)m * xld + n0;
+        a = *(const bf16x8*)p;
+        b = *(const bf16x8*)(p + 8);
+    };
+    if (pre_aux | pre_res) xload(0, x0, x1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        bf16x8 y0 = x0, y1 = x1;
+        if ((pre_aux | pre_res) && i + 1 < MI) xload(i + 1, x0, x1);
+        float R[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 t = acc[i][j];
+            R[j][0] = t[0]; R[j][1] = t[1]; R[j][2] = t[2]; R[j][3] = t[3];
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            lane_swap32(R[0][d], R[2][d]);                         // lane bit 5 <-> j bit 1
+            lane_swap32(R[1][d], R[3][d]);
+            lane_swap16(R[0][d], R[1][d]);                         // lane bit 4 <-> j bit 0
+            lane_swap16(R[2][d], R[3][d]);
+        }
+        const int m = row0 + i * 16;
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = R[e >> 2][e & 3] + bb[e];
+        const bool live = m < g.M;
+        if (flags & TNR_EPI_AUXOUT) {
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o0[e] = (bf16)v[e]; o1[e] = (bf16)v[8 + e]; }
+            if (live && do_store) {
+                bf16* p = g.aux + (int64_t)(row0s + i * 16) * g.ldaux + n0s;
+                *(bf16x8*)p = o0;
+                *(bf16x8*)(p + 8) = o1;
+            }
+        }
+        if (flags & TNR_EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = lut_eval<false>(lut, v[e]);
+        }
+        if (flags & TNR_EPI_TANH) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = tanhf(v[e]);
+        }
+        if (flags & TNR_EPI_MULDGELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] *= lut_eval<true>(lut, (float)y0[e]);
+                v[8 + e] *= lut_eval<true>(lut, (float)y1[e]);
+            }
+        }
+        if (flags & TNR_EPI_RES) {
+            bf16x8 r0 = y0, r1 = y1;
+            if (pre_aux) {                 // both operands in one launch: the residual is read where it is used
+                const bf16* p = g.res + (int64_t)(live ? m : g.M - 1) * g.ldres + n0;
+                r0 = *(const bf16x8*)p;
+                r1 = *(const bf16x8*)(p + 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] += (float)r0[e];
+                v[8 + e] += (float)r1[e];
+            }
+        }
+        if (flags & TNR_EPI_OUTF32) {
+            if (live && do_store) {
+                float* c = (float*)g.C + (int64_t)(row0s + i * 16) * g.ldc + n0s;
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) *(f32x4*)(c + e) = (f32x4){v[e], v[e + 1], v[e + 2], v[e + 3]};
+            }
+        } else {
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o0[e] = (bf16)v[e]; o1[e] = (bf16)v[8 + e]; }
+            if (live && do_store) {
+                bf16* c = (bf16*)g.C + (int64_t)(row0s + i * 16) * g.ldc + n0s;
+                *(bf16x8*)c = o0;
+                *(bf16x8*)(c + 8) = o1;
+            }
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { cs[e] += (float)o0[e]; cs[8 + e] += (float)o1[e]; }
+            }
+        }
+    }
+    if (flags & TNR_EPI_COLSUM) {
+        // column sums over this wave's 128 rows: 16 lanes (one row of the wave) hold the same 16 columns
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float t = cs[e];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 8, 64);
+            cs[e] = t;
+        }
+        if (m16 == 0) {
+            // four partial rows per row tile (tnr_gemm_colsum_rows): rows 0, 1 = the two 128-row halves, rows 2, 3 = 0
+            float* pr = g.colsum_part + ((int64_t)(bm * 4) + wm) * g.N + n0;
+            float* pz = g.colsum_part + ((int64_t)(bm * 4) + 2 + wm) * g.N + n0;
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) {
+                *(f32x4*)(pr + e) = (f32x4){cs[e], cs[e + 1], cs[e + 2], cs[e + 3]};
+                *(f32x4*)(pz + e) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// v8 "ping-pong": the v3 tile (256 x 256 x 64, 8 waves of 128 x 64, two 64 KB K stages) with the two wave groups of a
+// SIMD staggered by one barrier.  Waves w and w + 4 share a SIMD; group 0 (w < 4, rows 0-127) and group 1 (rows 128-255)
+// alternate between a LOAD segment (fragment ds_reads + the LDS-DMA of a later half tile) and an MFMA segment (16 MFMAs:
+// one 64 x 32 quadrant of the wave's 128 x 64 over K = 64), so that while one wave of a SIMD issues MFMAs its partner's
+// memory instructions run beside them:
+//      interval      0    1    2    3    4    5    6    7   | 8 ...
+//      group 0       L0   M0   L1   M1   L2   M2   L3   M3  | L0' ...
+//      group 1       -    L0   M0   L1   M1   L2   M2   L3  | M3  L0' ...
+// K tile = 4 phases: L0 reads A rows 0-63 + B cols 0-31, L1 B cols 32-63, L2 A rows 64-127, L3 nothing (B kept in registers);
+// M0..M3 = quadrants (A lo, B lo), (A lo, B hi), (A hi, B hi), (A hi, B lo).
+// The LDS-DMA stream runs 5 half tiles (16 KB each: A0 = rows 0-127, A1 = rows 128-255, B0, B1) ahead of the phase
+// counter, in the order A0 A1 B0 B1 per K tile: phase p of tile t issues A1(t+1), B0(t+1), B1(t+1), A0(t+2).  Hazards:
+//   WAR  a half tile is re-staged only after its last reader's lgkmcnt(0) AND a barrier both groups have passed
+//        (A0(t): group 0's L2 -> free from interval 8t+6 = this phase 3; A1(t): group 1's L2 -> free from 8t+7 < tile t+1's
+//        phase 0; B(t): L1 of both groups -> free from 8t+5);
+//   RAW  phase 3 waits vmcnt(2) (everything but the A0(t+2) pieces just issued; the streamed operand A gets 6 intervals,
+//        the L2-resident weights B 2) and both groups pass a barrier before tile t+1's first read.
+// All waves execute the same number of barriers (group 1 one extra before the loop, group 0 one extra after it).
+template <int MI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PR = 16 * MI, BM = 2 * PR;
+    constexpr int APIECES = PR / 8;                         // 1 KiB pieces (8 rows) per A half tile: 16 or 14
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the stagger branches are scalar
+    const int wm = w >> 2, wn = w & 3;
+    const int nbn = g.N >> 8;
+    const int nbm = (g.M + BM - 1) / BM;
+    // Persistent: one workgroup per CU walks its XCD's contiguous run of the tile order (blocks b and b + 8 share an XCD;
+    // the 32 workgroups of an XCD take consecutive tiles, i.e. a GM x (32 / GM) patch that shares A / B panels through
+    // that XCD's L2 -- the order a plain launch of one workgroup per tile produces, without relying on dispatch order).
+    const int ntile = nbm * nbn;
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per = (G - xcd + 7) >> 3;                  // workgroups on this XCD label
+    const int q8 = ntile >> 3, r8 = ntile & 7;
+    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
+    int tile = c0 + slot;
+    if (tile >= c1) return;                              // whole workgroup, before any barrier
+#ifdef TNR_PROBES
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();   // shader clock probe
+#endif
+
+    // staging: every wave issues pieces 2w, 2w+1 of every half tile (wave 7 has no A pieces in the 224-row variant)
+    const bf16* srcA[2][2];
+    const bf16* srcB[2][2];
+    const bool a_live = MI == 8 || 2 * w + 1 < APIECES;
+    auto set_src = [&](int t) {
+        int bm_, bn_;
+        tile_coords(t, nbm, nbn, g.gm, bm_, bn_);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = (2 * w + q) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ (row & 7);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int gm = bm_ * BM + h * PR + row;
+#if defined(TNR_PROBES) && TNR_PROBES >= 2
+                if (g.probe & 4) gm = h * PR + row;
+#endif
+                gm = gm < g.M ? gm : g.M - 1;
+                srcA[h][q] = g.A + (int64_t)gm * g.lda + chunk * 8;
+                srcB[h][q] = g.B + (int64_t)(bn_ * 256 + h * 128 + row) * g.ldb + chunk * 8;
+            }
+        }
+    };
+    // half tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of K tile kt into stage buffer kt & 1
+    auto issue = [&](int which, int kt) {
+#if defined(TNR_PROBES) && TNR_PROBES >= 2
+        if ((g.probe & 1) && kt > 1) return;
+#endif
+        char* base = smem + (kt & 1) * STAGE3 + which * TILE_BYTES + (2 * w) * 1024;
+        if (which < 2) {
+            if (a_live) {
+                glds16(srcA[which][0] + kt * 64, base);
+                glds16(srcA[which][1] + kt * 64, base + 1024);
+            }
+        } else {
+            glds16(srcB[which - 2][0] + kt * 64, base);
+            glds16(srcB[which - 2][1] + kt * 64, base + 1024);
+        }
+    };
+    const int nk = g.K >> 6;
+    auto prologue = [&](int t) {                         // the first five half tiles of tile t's K loop
+        set_src(t);
+        issue(0, 0);
+        issue(1, 0);
+        issue(2, 0);
+        issue(3, 0);
+        if (nk > 1) issue(0, 1);
+    };
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    f32x2* lut = (f32x2*)(smem + EPI_BYTES);             // own LDS region, built while the first loads fly
+    prologue(tile);
+    if (g.flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (g.flags & TNR_EPI_MULDGELU) != 0);
+    bool first = true;
+
+    constexpr int ILO = MI < 4 ? MI : 4, IHI = MI - ILO; // 16-row blocks of the wave's lower / upper A half
+    bf16x8 af[4][2], bfr[4][2];
+#define TNR_PP_SEG_END()                                            \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    __builtin_amdgcn_s_barrier();                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    __builtin_amdgcn_s_setprio(1)
+#define TNR_PP_MFMA_END()                                           \
+    __builtin_amdgcn_s_setprio(0);                                  \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    __builtin_amdgcn_s_barrier();                                   \
+    __builtin_amdgcn_sched_barrier(0)
+#if defined(TNR_PROBES) && TNR_PROBES >= 2
+    const bool compute = !(g.probe & 2);
+#else
+    constexpr bool compute = true;
+#endif
+  while (true) {
+    const int next = tile + per < c1 ? tile + per : -1;
+    int bm, bn;
+    tile_coords(tile, nbm, nbn, g.gm, bm, bn);
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // K tile 0 (and 1's A0) of this tile were issued by the prologue -- before the previous tile's epilogue for all but
+    // the first tile, so only that epilogue's own (younger) operations may still be in flight here
+    // (a counted wait that leaves the previous epilogue's stores in flight measured the same as waiting for everything,
+    // tools/gemm_ab.py, so the simple form stays: it assumes nothing about the completion order of loads and stores)
+    if (first && nk > 1 && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);
+    first = false;
+    __builtin_amdgcn_s_barrier();                        // K tile 0 is in LDS
+    if (wm == 1) __builtin_amdgcn_s_barrier();           // the stagger: group 1 runs one interval behind
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sa = smem + (kt & 1) * STAGE3 + wm * TILE_BYTES;
+        const char* sb = smem + (kt & 1) * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
+        const bool more = kt + 1 < nk;
+        // ---- phase 0: A rows 0-63, B cols 0-31 ; quadrant (lo, lo)
+        if (compute)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j][s] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+#pragma unroll
+            for (int i = 0; i < ILO; ++i) af[i][s] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
+        }
+        if (more) issue(1, kt + 1);
+        TNR_PP_SEG_END();
+        if (compute)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < ILO; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[i][j], 0, 0, 0);
+        TNR_PP_MFMA_END();
+        // ---- phase 1: B cols 32-63 ; quadrant (lo, hi)
+        if (compute)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 2; j < 4; ++j) bfr[j][s] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+        if (more) issue(2, kt + 1);
+        TNR_PP_SEG_END();
+        if (compute)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < ILO; ++i)
+#pragma unroll
+                for (int j = 2; j < 4; ++j) acc[i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[i][j], 0, 0, 0);
+        TNR_PP_MFMA_END();
+        // ---- phase 2: A rows 64-127 ; quadrant (hi, hi)
+        if (compute)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < IHI; ++i) af[i][s] = *(const bf16x8*)(sa + (ILO + i) * 16 * 128 + foff[s]);
+        if (more) issue(3, kt + 1);
+        TNR_PP_SEG_END();
+        if (compute)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < IHI; ++i)
+#pragma unroll
+                for (int j = 2; j < 4; ++j) acc[ILO + i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[ILO + i][j], 0, 0, 0);
+        TNR_PP_MFMA_END();
+        // ---- phase 3: no reads ; quadrant (hi, lo) ; K tile kt+1 must have landed before the next phase 0
+        if (kt + 2 < nk) {
+            issue(0, kt + 2);
+            if (a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);
+        } else {
+            TNR_WAIT_VMCNT(0);
+        }
+        TNR_PP_SEG_END();
+        if (compute)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < IHI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[ILO + i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[ILO + i][j], 0, 0, 0);
+        TNR_PP_MFMA_END();
+    }
+#undef TNR_PP_SEG_END
+#undef TNR_PP_MFMA_END
+    if (wm == 0) __builtin_amdgcn_s_barrier();           // group 0 waits for group 1's last MFMA segment
+    // every fragment read of this tile has completed (group 1's last MFMA segment is behind the barrier above): the stage
+    // ring is free, so the next tile's first loads go out BEFORE this tile's epilogue and land under it
+    if (next >= 0) prologue(next);
+#if defined(TNR_PROBES) && TNR_PROBES >= 2
+    if (g.probe & 8) {                                   // no epilogue: keep the accumulators alive, store nothing
+        if (acc[0][0][0] == 12345.678f) *(f32x4*)g.C = acc[1][1];
+    } else
+#endif
+    nt_epilogue_direct<MI>(g, acc, lut, bm, bn, wm, wn, lane);
+#ifdef TNR_PROBES
+    if ((g.probe & 64) && next < 0 && g.colsum_part && tid == 0) {   // shader cycles / 100 MHz ticks of this workgroup's life
+        unsigned long long* o = (unsigned long long*)g.colsum_part + 2 * blockIdx.x;
+        o[0] = __builtin_amdgcn_s_memtime() - pt0;
+        o[1] = __builtin_amdgcn_s_memrealtime() - pr0;
+    }
+#endif
+    if (next < 0) break;
+    tile = next;
+  }
+}
+
 // wgrad v3: output tile 256 (n) x 256 (k); stage = [dY cols 0-127 | dY cols 128-255 | X cols 0-127 | X cols 128-255]
 __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -970,17 +1373,23 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
                   "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
     const TnrGemmOpts& o = *tnr_gemm_opts();
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0};
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0, 0};
+#ifdef TNR_PROBES
+    g.probe = o.probe;
+#endif
     static bool attr_set = false;       // function attributes are per code object, not per device
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + LUT_N * 8);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    switch (nt_route(M, N, K, flags, device_cus())) {
+    const int n_cu = device_cus();
+    switch (nt_route(M, N, K, flags, n_cu)) {
     case TNR_ROUTE_128x128:
         hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(((M + 127) / 128) * (N / 128))), dim3(256), 2 * BUF_BYTES + LUT_N * 8, st, g);
         break;
@@ -988,10 +1397,12 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         hipLaunchKernelGGL(gemm_nt256_kernel, dim3((unsigned)(((M + 255) / 256) * (N / 128))), dim3(512), RING2, st, g);
         break;
     case TNR_ROUTE_224x256:
-        hipLaunchKernelGGL((gemm_nt256x256_kernel<7>), dim3((unsigned)(((M + 223) / 224) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
+        if (o.pp) hipLaunchKernelGGL((gemm_nt_pp_kernel<7>), dim3((unsigned)std::min<int64_t>(((M + 223) / 224) * (N / 256), n_cu)), dim3(512), LDS3_BYTES, st, g);
+        else hipLaunchKernelGGL((gemm_nt256x256_kernel<7>), dim3((unsigned)(((M + 223) / 224) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;
     default:
-        hipLaunchKernelGGL((gemm_nt256x256_kernel<8>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
+        if (o.pp) hipLaunchKernelGGL((gemm_nt_pp_kernel<8>), dim3((unsigned)std::min<int64_t>(((M + 255) / 256) * (N / 256), n_cu)), dim3(512), LDS3_BYTES, st, g);
+        else hipLaunchKernelGGL((gemm_nt256x256_kernel<8>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;
     }
     TNR_CHECK_LAUNCH("tnr_gemm_nt");
