@@ -95,9 +95,13 @@ int tnr_gemm_set_option(const char* key, int value);
 /* dW[N,K] (fp32) = dY[M,N]^T . X[M,K] : weight gradient of a Linear.  Reduction over M is split into
  * `splits` slabs in `ws` (fp32, splits*N*K elements) and summed in fixed order (deterministic).
  * Rows [M, Mpad) of dY and X must be zero, Mpad = roundup(M, 64) ; N % 128 == 0, K % 128 == 0.
- * accumulate != 0 adds into dW. */
+ * accumulate != 0 adds into dW.  _ex: dW (+)= out_scale * dY^T X (the fp16 build's backward runs on loss-scaled
+ * gradients; 1 / scale is applied here so that parameter gradients are the true ones, run.py:194). */
 int tnr_gemm_tn_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
                       int64_t M, int64_t N, int64_t K, float* ws, int splits, int accumulate, void* stream);
+int tnr_gemm_tn_wgrad_ex(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
+                         int64_t M, int64_t N, int64_t K, float* ws, int splits, int accumulate, float out_scale,
+                         void* stream);
 int64_t tnr_gemm_tn_ws_elems(int64_t N, int64_t K, int splits);
 
 /* LayerNorm over the last dim (H % 256 == 0), eps inside the sqrt (torch.nn.LayerNorm).
@@ -245,9 +249,12 @@ int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, int64_t n, 
                     void* stream);
 
 /* many fixed-order row reductions in ONE launch: desc = n_blocks x 6 int64 on the device, one per workgroup,
- * {src ptr, rows, row stride in floats, ncols <= 64, dst ptr, accumulate}: dst[c] (+)= sum_r src[r*stride + c].
+ * {src ptr, rows, row stride in floats, ncols <= 64, dst ptr, accumulate | (fp32 bits of scale) << 32}:
+ * dst[c] (+)= scale * sum_r src[r*stride + c] ; upper half 0 = scale 1.
  * Callers reduce tall partial matrices in two launches (row chunks in place, then the chunk rows). */
 int tnr_reduce_multi(const int64_t* desc, int n_blocks, void* stream);
+/* x[i] *= s , i < n (fp32) */
+int tnr_scale_inplace(float* x, int64_t n, float s, void* stream);
 
 /* ---- optimiser ------------------------------------------------------------------------------- */
 
@@ -287,6 +294,9 @@ int64_t tnr_gemm_colsum_rows_f16(int64_t M);
 int tnr_gemm_nt_route_f16(int64_t M, int64_t N, int64_t K, int flags);
 int tnr_gemm_tn_wgrad_f16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
                       int64_t M, int64_t N, int64_t K, float* ws, int splits, int accumulate, void* stream);
+int tnr_gemm_tn_wgrad_ex_f16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
+                         int64_t M, int64_t N, int64_t K, float* ws, int splits, int accumulate, float out_scale,
+                         void* stream);
 int64_t tnr_gemm_tn_ws_elems_f16(int64_t N, int64_t K, int splits);
 int tnr_ln_fwd_f16(const void* x, const float* gamma, const float* beta, float eps, void* y, float* stats,
                int64_t M, int H, void* stream);

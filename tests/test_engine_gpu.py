@@ -109,7 +109,7 @@ def test_training_step_matches_reference_and_oracle(name, dtype):
     k = E.layer_param_order(max(cfg["trainable_layers"]))[10]           # intermediate.dense.weight
     p = p0[k].cpu().numpy().copy()
     m, v, vm = np.zeros_like(p), np.zeros_like(p), np.zeros_like(p)
-    O.amsgrad_step(p, g0[eng.off(k):eng.off(k) + p.size].view(p.shape).cpu().numpy() / eng.gscale, m, v, vm, 1, lr=1e-4)
+    O.amsgrad_step(p, g0[eng.off(k):eng.off(k) + p.size].view(p.shape).cpu().numpy(), m, v, vm, 1, lr=1e-4)
     np.testing.assert_allclose(eng.params[k].cpu().numpy(), p, rtol=1e-5, atol=1e-7)
     sh = eng.sh[max(cfg["trainable_layers"])]
     assert torch.equal(sh["w1"], eng.params[k].to(eng.tdt)) and torch.equal(sh["w1T"], eng.params[k].t().to(eng.tdt))

@@ -793,50 +793,47 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
     nt_epilogue_coalesced<MI>(g, acc, smem, lut, bm, bn, wm, wn, lane);
 }
 
-// ---- register-transposed epilogue of the ping-pong kernel -------------------------------------------
-// The accumulator layout gives lane (m = lane & 15, q = lane >> 4) four consecutive columns 16 j + 4 q + r of row m in block
-// j = 0..3.  A 4 x 4 transpose between the four q-lanes of a row and the four j registers (two v_permlane32_swap + two
-// v_permlane16_swap per dword: lane bit 5 <-> j bit 1, lane bit 4 <-> j bit 0) leaves lane q' with columns 16 q' .. 16 q' + 15
-// of its row: 64 contiguous bytes of fp32, 32 of 16-bit output, i.e. every row of a 16-row block is written as one full
-// 128-byte line by two 16-byte stores per lane -- no LDS staging, no barriers (the LDS-staged epilogue of the two-phase kernel
-// cost 6.8-10 us of a 28 us tile at K = 768: tools/gemm_probe.py), and the stage ring is free for the next tile's loads.
-// Residual / pre-activation operands are read in the same layout (prefetched one block ahead); bias, table GELU, GELU',
-// tanh, residual and the optional pre-activation side output work on the lane's 16 columns; column sums (bias gradient of
-// the producing Linear) are reduced over the 16 rows of a block by row-wise shuffles and over blocks in registers.
-// v_permlane32_swap a, b: lanes 32-63 of a <-> lanes 0-31 of b ; v_permlane16_swap: odd 16-lane rows of a <-> even rows of b
-// (checked on MI355X: tools/scratch/permlane_test.hip, transpose_test.hip).  NB never __builtin_bit_cast an ext-vector ELEMENT
-// (bit_cast(unsigned, acc[i][j][d]) reads element 0 for every d on hipcc 7.2): copy the element to a float first.
-__device__ __forceinline__ void lane_swap32(float& a, float& b) {
-    auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(t[0]);
-    b = __uint_as_float(t[1]);
-}
-__device__ __forceinline__ void lane_swap16(float& a, float& b) {
-    auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(t[0]);
-    b = __uint_as_float(t[1]);
-}
-
-template <int MI>
-__device__ __forceinline__ void nt_epilogue_direct(const NTArgs& g, f32x4 (&acc)[MI][4], const f32x2* lut, int bm, int bn,
-                                                   int wm, int wn, int lane) {
+// ---- epilogue of the ping-pong kernel: no transposes, no LDS staging ----------------------------------
+// The MFMA is called with the B fragment first, so lane (m = lane & 15, q = lane >> 4) holds, in register r of block j,
+// the output of row m and of the B row that lane 4 q + r fed into block j.  WHICH B row that is is free: the kernel's
+// fragment reads take row 32 (j >> 1) + 8 q' + 4 (j & 1) + r' for lane q' r' (pp_brow), so lane q ends up with columns
+// 8 q .. 8 q + 7 (blocks 0, 1) and 32 + 8 q .. 32 + 8 q + 7 (blocks 2, 3) of the wave's 64: two 16-byte stores per row and
+// lane, four lanes writing 64 contiguous bytes of a row per instruction.  (The first version of this kernel kept the
+// natural row order and moved the data with 128 v_permlane swaps per wave and tile; those and the runtime flag tests
+// made the epilogue 8 of the 30 us of a K = 768 tile, tools/gemm_probe.py.)  CF >= 0: the epilogue flags at compile time
+// (one instance per combination the engine uses), CF < 0: runtime flags (anything else).
+// Bias comes from LDS (staged by the prologue's LDS-DMA: an ordinary global load here would make the compiler wait
+// vmcnt(0), i.e. for the next tile's first operand loads); residual / pre-activation operands are read in the same
+// layout, prefetched one block ahead; column sums (bias gradient of the producing Linear) are reduced over the 16 rows
+// of a block by row-wise shuffles and over blocks in registers.
+template <int MI, int CF>
+__device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[MI][4], const f32x2* lut, const float* bias_lds,
+                                                 int bm, int bn, int wm, int wn, int lane) {
     constexpr int PR = 16 * MI, BM = 2 * PR;
-    const int flags = g.flags;
+    const int flags = CF >= 0 ? CF : g.flags;
     const int m16 = lane & 15, qd = lane >> 4;
-    const int n0 = bn * 256 + wn * 64 + qd * 16;                 // this lane's 16 columns after the transpose
+    const int n0 = bn * 256 + wn * 64 + qd * 8;                  // this lane's columns: n0 .. n0 + 7 and n0 + 32 .. n0 + 39
     const int row0 = bm * BM + wm * PR + m16;
 #if defined(TNR_PROBES) && TNR_PROBES >= 2
-    const int n0s = (g.probe & 32) ? wn * 64 + qd * 16 : n0, row0s = (g.probe & 32) ? wm * PR + m16 : row0;
+    const int n0s = (g.probe & 32) ? wn * 64 + qd * 8 : n0, row0s = (g.probe & 32) ? wm * PR + m16 : row0;
     const bool do_store = !(g.probe & 16);
 #else
     const int n0s = n0, row0s = row0;
     constexpr bool do_store = true;
 #endif
     float bb[16];
+    if (flags & TNR_EPI_BIAS) {
+        const float* bl = bias_lds + wn * 64 + qd * 8;
 #pragma unroll
-    for (int e = 0; e < 16; e += 4) {
-        f32x4 t = (flags & TNR_EPI_BIAS) ? *(const f32x4*)(g.bias + n0 + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        bb[e] = t[0]; bb[e + 1] = t[1]; bb[e + 2] = t[2]; bb[e + 3] = t[3];
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                f32x4 t = *(const f32x4*)(bl + 32 * h + e);
+                bb[8 * h + e] = t[0]; bb[8 * h + e + 1] = t[1]; bb[8 * h + e + 2] = t[2]; bb[8 * h + e + 3] = t[3];
+            }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bb[e] = 0.f;
     }
     float cs[16];
 #pragma unroll
@@ -852,30 +849,21 @@ __device__ __forceinline__ void nt_epilogue_direct(const NTArgs& g, f32x4 (&acc)
         m = m < g.M ? m : g.M - 1;
         const bf16* p = xsrc + (int64_t)m * xld + n0;
         a = *(const bf16x8*)p;
-        b = *(const bf16x8*)(p + 8);
+        b = *(const bf16x8*)(p + 32);
     };
     if (pre_aux | pre_res) xload(0, x0, x1);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         bf16x8 y0 = x0, y1 = x1;
         if ((pre_aux | pre_res) && i + 1 < MI) xload(i + 1, x0, x1);
-        float R[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 t = acc[i][j];
-            R[j][0] = t[0]; R[j][1] = t[1]; R[j][2] = t[2]; R[j][3] = t[3];
-        }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            lane_swap32(R[0][d], R[2][d]);                         // lane bit 5 <-> j bit 1
-            lane_swap32(R[1][d], R[3][d]);
-            lane_swap16(R[0][d], R[1][d]);                         // lane bit 4 <-> j bit 0
-            lane_swap16(R[2][d], R[3][d]);
-        }
         const int m = row0 + i * 16;
         float v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = R[e >> 2][e & 3] + bb[e];
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 t = acc[i][j];
+            v[4 * j] = t[0] + bb[4 * j]; v[4 * j + 1] = t[1] + bb[4 * j + 1];
+            v[4 * j + 2] = t[2] + bb[4 * j + 2]; v[4 * j + 3] = t[3] + bb[4 * j + 3];
+        }
         const bool live = m < g.M;
         if (flags & TNR_EPI_AUXOUT) {
             bf16x8 o0, o1;
@@ -884,7 +872,7 @@ __device__ __forceinline__ void nt_epilogue_direct(const NTArgs& g, f32x4 (&acc)
             if (live && do_store) {
                 bf16* p = g.aux + (int64_t)(row0s + i * 16) * g.ldaux + n0s;
                 *(bf16x8*)p = o0;
-                *(bf16x8*)(p + 8) = o1;
+                *(bf16x8*)(p + 32) = o1;
             }
         }
         if (flags & TNR_EPI_GELU) {
@@ -907,7 +895,7 @@ __device__ __forceinline__ void nt_epilogue_direct(const NTArgs& g, f32x4 (&acc)
             if (pre_aux) {                 // both operands in one launch: the residual is read where it is used
                 const bf16* p = g.res + (int64_t)(live ? m : g.M - 1) * g.ldres + n0;
                 r0 = *(const bf16x8*)p;
-                r1 = *(const bf16x8*)(p + 8);
+                r1 = *(const bf16x8*)(p + 32);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -919,7 +907,10 @@ __device__ __forceinline__ void nt_epilogue_direct(const NTArgs& g, f32x4 (&acc)
             if (live && do_store) {
                 float* c = (float*)g.C + (int64_t)(row0s + i * 16) * g.ldc + n0s;
 #pragma unroll
-                for (int e = 0; e < 16; e += 4) *(f32x4*)(c + e) = (f32x4){v[e], v[e + 1], v[e + 2], v[e + 3]};
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 8; e += 4)
+                        *(f32x4*)(c + 32 * h + e) = (f32x4){v[8 * h + e], v[8 * h + e + 1], v[8 * h + e + 2], v[8 * h + e + 3]};
             }
         } else {
             bf16x8 o0, o1;
@@ -928,16 +919,16 @@ __device__ __forceinline__ void nt_epilogue_direct(const NTArgs& g, f32x4 (&acc)
             if (live && do_store) {
                 bf16* c = (bf16*)g.C + (int64_t)(row0s + i * 16) * g.ldc + n0s;
                 *(bf16x8*)c = o0;
-                *(bf16x8*)(c + 8) = o1;
+                *(bf16x8*)(c + 32) = o1;
             }
-            if (live) {
+            if ((flags & TNR_EPI_COLSUM) && live) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { cs[e] += (float)o0[e]; cs[8 + e] += (float)o1[e]; }
             }
         }
     }
     if (flags & TNR_EPI_COLSUM) {
-        // column sums over this wave's 128 rows: 16 lanes (one row of the wave) hold the same 16 columns
+        // column sums over this wave's 16 MI rows: 16 lanes (one row of the wave) hold the same 16 columns
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float t = cs[e];
@@ -948,14 +939,16 @@ __device__ __forceinline__ void nt_epilogue_direct(const NTArgs& g, f32x4 (&acc)
             cs[e] = t;
         }
         if (m16 == 0) {
-            // four partial rows per row tile (tnr_gemm_colsum_rows): rows 0, 1 = the two 128-row halves, rows 2, 3 = 0
+            // four partial rows per row tile (tnr_gemm_colsum_rows): rows 0, 1 = the two row halves, rows 2, 3 = 0
             float* pr = g.colsum_part + ((int64_t)(bm * 4) + wm) * g.N + n0;
             float* pz = g.colsum_part + ((int64_t)(bm * 4) + 2 + wm) * g.N + n0;
 #pragma unroll
-            for (int e = 0; e < 16; e += 4) {
-                *(f32x4*)(pr + e) = (f32x4){cs[e], cs[e + 1], cs[e + 2], cs[e + 3]};
-                *(f32x4*)(pz + e) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; e += 4) {
+                    *(f32x4*)(pr + 32 * h + e) = (f32x4){cs[8 * h + e], cs[8 * h + e + 1], cs[8 * h + e + 2], cs[8 * h + e + 3]};
+                    *(f32x4*)(pz + 32 * h + e) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
         }
     }
 }
@@ -979,10 +972,18 @@ __device__ __forceinline__ void nt_epilogue_direct(const NTArgs& g, f32x4 (&acc)
 //   RAW  phase 3 waits vmcnt(2) (everything but the A0(t+2) pieces just issued; the streamed operand A gets 6 intervals,
 //        the L2-resident weights B 2) and both groups pass a barrier before tile t+1's first read.
 // All waves execute the same number of barriers (group 1 one extra before the loop, group 0 one extra after it).
-template <int MI>
+// B rows are staged with their own swizzle (pp_bswz) and read in the permuted order of nt_epilogue_cols:
+//   fragment row of lane n' = lane & 15 in block j:  32 (j >> 1) + 8 (n' >> 2) + 4 (j & 1) + (n' & 3)
+//   16-byte slot of (row, chunk):  chunk ^ pp_bswz(row),  pp_bswz(row) = row bit 1 | row bits 3-4 << 1
+// which keeps every 16-lane group of a ds_read_b128 on 16 distinct slots of the 256-byte bank row (the rows of a group
+// differ in bits 0-1 and 3-4; bit 0 selects the 128-byte half by itself, the other three go through the XOR).
+__device__ __forceinline__ int pp_bswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+
+template <int MI, int CF>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PR = 16 * MI, BM = 2 * PR;
+    const int flags = CF >= 0 ? CF : g.flags;
     constexpr int APIECES = PR / 8;                         // 1 KiB pieces (8 rows) per A half tile: 16 or 14
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the stagger branches are scalar
@@ -1014,7 +1015,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int row = (2 * w + q) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ (row & 7);
+            const int chunk = (lane & 7) ^ (row & 7), chunkb = (lane & 7) ^ pp_bswz(row);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int gm = bm_ * BM + h * PR + row;
@@ -1023,9 +1024,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 #endif
                 gm = gm < g.M ? gm : g.M - 1;
                 srcA[h][q] = g.A + (int64_t)gm * g.lda + chunk * 8;
-                srcB[h][q] = g.B + (int64_t)(bn_ * 256 + h * 128 + row) * g.ldb + chunk * 8;
+                srcB[h][q] = g.B + (int64_t)(bn_ * 256 + h * 128 + row) * g.ldb + chunkb * 8;
             }
         }
+        return bn_;
     };
     // half tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of K tile kt into stage buffer kt & 1
     auto issue = [&](int which, int kt) {
@@ -1044,8 +1046,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         }
     };
     const int nk = g.K >> 6;
-    auto prologue = [&](int t) {                         // the first five half tiles of tile t's K loop
-        set_src(t);
+    // bias of the tile's 256 columns: 1 KiB by one LDS-DMA of wave 0 into one of two buffers behind the stage ring (tile
+    // parity), oldest operation of the prologue so that every later counted wait covers it
+    float* const bias_lds = (float*)(smem + RING3);
+    auto prologue = [&](int t, int par) {                // the first five half tiles of tile t's K loop
+        const int bn_ = set_src(t);
+        if ((flags & TNR_EPI_BIAS) && w == 0) glds16(g.bias + bn_ * 256 + lane * 4, bias_lds + par * 256);
         issue(0, 0);
         issue(1, 0);
         issue(2, 0);
@@ -1055,10 +1061,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     int foff[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) foff[s] = (lane & 15) * 128 + ((((4 * s) + (lane >> 4)) ^ (lane & 7)) << 4);
+    int boff[2];
+    {
+        const int rb = 8 * ((lane & 15) >> 2) + (lane & 3);      // + 32 (j >> 1) + 4 (j & 1): bits the swizzle does not use
+#pragma unroll
+        for (int s = 0; s < 2; ++s) boff[s] = rb * 128 + ((((4 * s) + (lane >> 4)) ^ pp_bswz(rb)) << 4);
+    }
 
     f32x2* lut = (f32x2*)(smem + EPI_BYTES);             // own LDS region, built while the first loads fly
-    prologue(tile);
-    if (g.flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (g.flags & TNR_EPI_MULDGELU) != 0);
+    int par = 0;
+    prologue(tile, par);
+    if (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (flags & TNR_EPI_MULDGELU) != 0);
     bool first = true;
 
     constexpr int ILO = MI < 4 ? MI : 4, IHI = MI - ILO; // 16-row blocks of the wave's lower / upper A half
@@ -1105,7 +1118,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j][s] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+            for (int j = 0; j < 2; ++j) bfr[j][s] = *(const bf16x8*)(sb + j * 4 * 128 + boff[s]);
 #pragma unroll
             for (int i = 0; i < ILO; ++i) af[i][s] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
         }
@@ -1124,7 +1137,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 2; j < 4; ++j) bfr[j][s] = *(const bf16x8*)(sb + j * 16 * 128 + foff[s]);
+            for (int j = 2; j < 4; ++j) bfr[j][s] = *(const bf16x8*)(sb + (32 + (j - 2) * 4) * 128 + boff[s]);
         if (more) issue(2, kt + 1);
         TNR_PP_SEG_END();
         if (compute)
@@ -1173,13 +1186,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     if (wm == 0) __builtin_amdgcn_s_barrier();           // group 0 waits for group 1's last MFMA segment
     // every fragment read of this tile has completed (group 1's last MFMA segment is behind the barrier above): the stage
     // ring is free, so the next tile's first loads go out BEFORE this tile's epilogue and land under it
-    if (next >= 0) prologue(next);
+    if (next >= 0) prologue(next, par ^ 1);
 #if defined(TNR_PROBES) && TNR_PROBES >= 2
     if (g.probe & 8) {                                   // no epilogue: keep the accumulators alive, store nothing
         if (acc[0][0][0] == 12345.678f) *(f32x4*)g.C = acc[1][1];
     } else
 #endif
-    nt_epilogue_direct<MI>(g, acc, lut, bm, bn, wm, wn, lane);
+    nt_epilogue_cols<MI, CF>(g, acc, lut, bias_lds + par * 256, bm, bn, wm, wn, lane);
+    par ^= 1;
 #ifdef TNR_PROBES
     if ((g.probe & 64) && next < 0 && g.colsum_part && tid == 0) {   // shader cycles / 100 MHz ticks of this workgroup's life
         unsigned long long* o = (unsigned long long*)g.colsum_part + 2 * blockIdx.x;
@@ -1292,13 +1306,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
 }
 
 __global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t NK, int K, float* out,
-                                   int64_t ldo, int accumulate) {
+                                   int64_t ldo, int accumulate, float out_scale) {
     int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= NK) return;
     f32x4 s = *(const f32x4*)(ws + i4);
     for (int z = 1; z < splits; ++z) s += *(const f32x4*)(ws + (int64_t)z * NK + i4);
     int64_t n = i4 / K, k = i4 - n * K;
     float* o = out + n * ldo + k;
+    s *= out_scale;
     if (accumulate) s += *(const f32x4*)o;
     *(f32x4*)o = s;
 }
@@ -1350,6 +1365,23 @@ static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
     return use224 ? TNR_ROUTE_224x256 : TNR_ROUTE_256x256;
 }
 
+// the epilogue flag combinations of engine.py get an instance each with the flags at compile time (forward: QKV / pooled query,
+// attention output + FFN down, FFN up with and without the pre-activation side output, pooling fc1 ; backward: the four dgrads)
+#define TNR_PP_FLAG_SETS(X)                                                                                              \
+    X(0) X(TNR_EPI_BIAS) X(TNR_EPI_RES) X(TNR_EPI_BIAS | TNR_EPI_RES) X(TNR_EPI_BIAS | TNR_EPI_GELU)                      \
+    X(TNR_EPI_BIAS | TNR_EPI_GELU | TNR_EPI_AUXOUT) X(TNR_EPI_MULDGELU) X(TNR_EPI_MULDGELU | TNR_EPI_COLSUM)              \
+    X(TNR_EPI_BIAS | TNR_EPI_TANH | TNR_EPI_OUTF32)
+template <int MI>
+static void pp_launch(const NTArgs& g, unsigned grid, hipStream_t st) {
+    switch (g.flags) {
+#define TNR_PP_CASE(CF) \
+    case (CF): hipLaunchKernelGGL((gemm_nt_pp_kernel<MI, (CF)>), dim3(grid), dim3(512), LDS3_BYTES, st, g); break;
+        TNR_PP_FLAG_SETS(TNR_PP_CASE)
+#undef TNR_PP_CASE
+    default: hipLaunchKernelGGL((gemm_nt_pp_kernel<MI, -1>), dim3(grid), dim3(512), LDS3_BYTES, st, g); break;
+    }
+}
+
 extern "C" int TNR_NAME(tnr_gemm_nt_route)(int64_t M, int64_t N, int64_t K, int flags) {
     return nt_route(M, N, K, flags, device_cus());
 }
@@ -1383,8 +1415,12 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+#define TNR_PP_ATTR(CF)                                                                                                     \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<8, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES); \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<7, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        TNR_PP_FLAG_SETS(TNR_PP_ATTR)
+        TNR_PP_ATTR(-1)
+#undef TNR_PP_ATTR
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1397,11 +1433,11 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
         hipLaunchKernelGGL(gemm_nt256_kernel, dim3((unsigned)(((M + 255) / 256) * (N / 128))), dim3(512), RING2, st, g);
         break;
     case TNR_ROUTE_224x256:
-        if (o.pp) hipLaunchKernelGGL((gemm_nt_pp_kernel<7>), dim3((unsigned)std::min<int64_t>(((M + 223) / 224) * (N / 256), n_cu)), dim3(512), LDS3_BYTES, st, g);
+        if (o.pp) pp_launch<7>(g, (unsigned)std::min<int64_t>(((M + 223) / 224) * (N / 256), n_cu), st);
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<7>), dim3((unsigned)(((M + 223) / 224) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;
     default:
-        if (o.pp) hipLaunchKernelGGL((gemm_nt_pp_kernel<8>), dim3((unsigned)std::min<int64_t>(((M + 255) / 256) * (N / 256), n_cu)), dim3(512), LDS3_BYTES, st, g);
+        if (o.pp) pp_launch<8>(g, (unsigned)std::min<int64_t>(((M + 255) / 256) * (N / 256), n_cu), st);
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<8>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;
     }
@@ -1411,9 +1447,9 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
 
 extern "C" int64_t TNR_NAME(tnr_gemm_tn_ws_elems)(int64_t N, int64_t K, int splits) { return N * K * (int64_t)splits; }
 
-extern "C" int TNR_NAME(tnr_gemm_tn_wgrad)(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
-                                 int64_t lddw, int64_t M, int64_t N, int64_t K, float* ws, int splits,
-                                 int accumulate, void* stream) {
+extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
+                                    int64_t lddw, int64_t M, int64_t N, int64_t K, float* ws, int splits,
+                                    int accumulate, float out_scale, void* stream) {
     TNR_CHECK_ARG(dY && X && dW && ws, "tnr_gemm_tn_wgrad: null operand");
     TNR_CHECK_ARG(M >= 1 && (N % 128) == 0 && (K % 128) == 0 && N >= 128 && K >= 128,
                   "tnr_gemm_tn_wgrad: need N%%128==0, K%%128==0 (N=%ld K=%ld)", (long)N, (long)K);
@@ -1447,7 +1483,13 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad)(const void* dY, int64_t lddy, const v
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad");
     int64_t NK = N * K;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((NK / 4 + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)ws, splits, NK, (int)K, dW, lddw, accumulate);
+                       (hipStream_t)stream, (const float*)ws, splits, NK, (int)K, dW, lddw, accumulate, out_scale);
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad/reduce");
     return TNR_OK;
+}
+
+extern "C" int TNR_NAME(tnr_gemm_tn_wgrad)(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
+                                 int64_t lddw, int64_t M, int64_t N, int64_t K, float* ws, int splits,
+                                 int accumulate, void* stream) {
+    return TNR_NAME(tnr_gemm_tn_wgrad_ex)(dY, lddy, X, ldx, dW, lddw, M, N, K, ws, splits, accumulate, 1.0f, stream);
 }

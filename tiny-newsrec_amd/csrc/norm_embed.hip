@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 // many reductions in one launch: one descriptor per BLOCK on the device, 6 int64
-// {src ptr, rows, row stride (floats), ncols <= 64, dst ptr, accumulate}: dst[c] (+)= sum_r src[r*stride + c].
+// {src ptr, rows, row stride (floats), ncols <= 64, dst ptr, accumulate | scale bits << 32}: dst[c] (+)= scale * sum_r src[r*stride + c]
+// (scale = the fp32 whose bit pattern sits in the upper half of the last word; upper half 0 means 1.0).
 // Fixed order (4 row lanes, each a strided subsequence, combined as ((0+1)+(2+3))).  The host builds two tables
 // per batch: level 1 sums row chunks IN PLACE (dst = first row of the chunk), level 2 sums the chunk rows.
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const int64_t* __restrict__ desc) {
@@ -220,7 +221,9 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const int64_t* __rest
     __syncthreads();
     if (rl == 0 && c < ncols) {
         float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-        dst[c] = d[5] ? dst[c] + t : t;
+        const unsigned sb = (unsigned)((uint64_t)d[5] >> 32);
+        if (sb) t *= __uint_as_float(sb);
+        dst[c] = (d[5] & 1) ? dst[c] + t : t;
     }
 }
 
@@ -468,6 +471,16 @@ extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, 
 #endif
 
 #ifndef TNR_BUILD_F16
+__global__ void scale_inplace_kernel(float* __restrict__ x, int64_t n, float s) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+extern "C" int tnr_scale_inplace(float* x, int64_t n, float s, void* stream) {
+    TNR_CHECK_ARG(x && n >= 1, "tnr_scale_inplace: bad argument");
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+    TNR_CHECK_LAUNCH("tnr_scale_inplace");
+    return TNR_OK;
+}
 extern "C" int tnr_reduce_multi(const int64_t* desc, int n_blocks, void* stream) {
     TNR_CHECK_ARG(desc && n_blocks >= 1, "tnr_reduce_multi: bad argument");
     hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, desc);

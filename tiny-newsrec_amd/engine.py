@@ -11,6 +11,7 @@ buffers of the trainable size, bf16 (and transposed bf16) weight copies are refr
 kernel after each update, activations of the trainable layers stay resident for backward.
 """
 import math
+import struct
 
 import torch
 
@@ -153,9 +154,11 @@ class _ReduceBatch:
     def __init__(self, dev):
         self.dev, self.jobs, self.table = dev, [], None
 
-    def add(self, part, rows, stride, n, out, accumulate=0):
+    def add(self, part, rows, stride, n, out, accumulate=0, scale=1.0):
+        """out (+)= scale * column sums of part ; the scale rides in the upper half of the descriptor's last word."""
         if self.table is None:
-            self.jobs.append((part.data_ptr(), rows, stride, n, out.data_ptr(), accumulate))
+            sb = 0 if scale == 1.0 else struct.unpack("<I", struct.pack("<f", scale))[0]
+            self.jobs.append((part.data_ptr(), rows, stride, n, out.data_ptr(), int(accumulate) | (sb << 32)))
 
     def flush(self):
         if not self.jobs:
@@ -183,20 +186,23 @@ class _ReduceBatch:
                 T.call("tnr_reduce_multi", t[0], t[1])
 
 
-LOSS_SCALE = 1024.0     # static scale of the 16-bit backward in fp16 mode (gradients of ~1e-6 would underflow)
+LOSS_SCALE = 1024.0     # static scale of the 16-bit backward in fp16 mode (gradients of ~1e-6 would underflow); it enters at
+                        # the pooling backward and leaves in the kernels that write parameter gradients (weight-gradient slab
+                        # reduce, bias / LayerNorm partial reductions), so flat_g always holds the true gradients
 
 
 class Engine:
     def __init__(self, cfg, device="cuda:0", max_batch=32, dtype="fp16", share=None):
         """dtype: 16-bit activation / weight-copy type, "fp16" (default: meets the 1e-3 logit / loss bound) or "bf16".
-        fp16 has the same MFMA rate and 3 more mantissa bits; its backward runs on gradients scaled by LOSS_SCALE from the pooling backward down
-        (everything 16-bit), un-scaled inside the AMSGrad kernel."""
+        fp16 has the same MFMA rate and 3 more mantissa bits; its backward runs on activation gradients scaled by LOSS_SCALE from the
+        pooling backward down (everything 16-bit); the kernels that write parameter gradients multiply by 1 / LOSS_SCALE (exact)."""
         T.lib()                      # fail loudly if the HIP library is missing
         assert dtype in ("bf16", "fp16")
         self.f16 = dtype == "fp16"
         self.dtype = dtype
         self.tdt = torch.float16 if self.f16 else torch.bfloat16
         self.gscale = LOSS_SCALE if self.f16 else 1.0
+        self.ginv = 1.0 / self.gscale
         self.cfg, self.dev = cfg, torch.device(device)
         self.step_count = 0
         self._n_alloc = 0
@@ -448,6 +454,7 @@ class Engine:
                              T.query("tnr_colsum_part_elems", 128, I),
                              T.query("tnr_colsum_part_elems", max(B * cfg.U, 1), 3 * D),
                              T_ * T.query("tnr_colsum_part_elems", Rt, D)))
+        self.cs_tmp, self.cs_tmp2 = f(I), f(3 * H)                        # column sums of the unfused fallbacks, before 1 / loss scale
         self.gcs_part = f(T.query("tnr_gemm_colsum_rows", Mp), I)        # b1 gradient partials from the dgrad epilogue
         self.qkvb_part = f(N, 3 * H)                                       # q/k/v bias gradient partials from attention bwd
         self.db1p = f(N, QPAD)
@@ -475,8 +482,8 @@ class Engine:
 
     def _wgrad(self, dy, x, dw, M, acc=0):
         N, K = dw.shape
-        self._c("tnr_gemm_tn_wgrad", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws,
-               self._wgrad_splits(N, K)[0], acc)
+        self._c("tnr_gemm_tn_wgrad_ex", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws,
+               self._wgrad_splits(N, K)[0], acc, self.ginv)
 
     def _colsum(self, x, out, M, dtype=T.BF16):   # dtype BF16 = "the 16-bit type of the build"
         self._c("tnr_colsum", x, x.stride(0), dtype, M, x.shape[1], out, self.cs_part, 0)
@@ -813,6 +820,7 @@ class Engine:
         L, D, H, I = cfg.L, cfg.D, cfg.H, cfg.I
         M = N * L
         g, gr = self.p, self.grads
+        gi = self.ginv                     # parameter gradients below the pooling backward: 1 / loss scale on the way out
         rb = self.red.setdefault(("heads", acc, N), _ReduceBatch(self.dev))
         # dense + pooling of the news encoder
         wd = g(PFX + "dense.weight")
@@ -824,9 +832,9 @@ class Engine:
         if cfg.pooling == "att":
             self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
                    self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
-            rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], acc)
-            rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], acc)
-            rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), acc)
+            rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], acc, gi)
+            rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], acc, gi)
+            rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), acc, gi)
         rb.flush()
         if cfg.pooling == "att":
             self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M, acc)
@@ -855,17 +863,18 @@ class Engine:
             self._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None,
                     self.ln_part if tr else None, M, H)
             if tr:
-                rb.add(self.ln_part, nblk, 3 * H, 2 * H, self._view(names[14], 2 * H, (2 * H,), grad=True), acc)   # [dgamma | dbeta]
-                rb.add(self.ln_part[2 * H:], nblk, 3 * H, H, gr[names[13]], acc)                                 # output.dense.bias
+                rb.add(self.ln_part, nblk, 3 * H, 2 * H, self._view(names[14], 2 * H, (2 * H,), grad=True), acc, gi)   # [dgamma | dbeta]
+                rb.add(self.ln_part[2 * H:], nblk, 3 * H, H, gr[names[13]], acc, gi)                                 # output.dense.bias
                 self._wgrad(self.dypre, a["g"], gr[names[12]], M, acc)
             fused_cs = tr and M > 128            # the column-sum epilogue needs more than one 128-row strip
             self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if fused_cs else 0),
                        colsum=self.gcs_part if fused_cs else None)
             if tr:
                 if fused_cs:
-                    rb.add(self.gcs_part, self._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], acc)
+                    rb.add(self.gcs_part, self._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], acc, gi)
                 else:
-                    self._c("tnr_colsum", self.du, I, T.BF16, M, I, gr[names[11]], self.cs_part, acc)
+                    self._c("tnr_colsum", self.du, I, T.BF16, M, I, self.cs_tmp[:I], self.cs_part, 0)
+                    rb.add(self.cs_tmp, 1, I, I, gr[names[11]], acc, gi)
                 self._wgrad(self.du, a["h1"], gr[names[10]], M, acc)
                 rb.flush()
                 if after_bucket:
@@ -875,21 +884,21 @@ class Engine:
             self._c("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, None, None, None,
                     self.ln_part1 if tr else None, M, H)
             if tr:
-                rba.add(self.ln_part1, nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True), acc)
-                rba.add(self.ln_part1[2 * H:], nblk, 3 * H, H, gr[names[7]], acc)                               # attention.output.dense.bias
+                rba.add(self.ln_part1, nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True), acc, gi)
+                rba.add(self.ln_part1[2 * H:], nblk, 3 * H, H, gr[names[7]], acc, gi)                               # attention.output.dense.bias
                 self._wgrad(self.dh1pre, a["ctx"], gr[names[6]], M, acc)
             self._gemm(self.dh1pre, sh["oT"], self.dctx, M)
             if L <= 32:
                 self._c("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv,
                         self.qkvb_part if tr else None, N, L, cfg.A)
                 if tr:
-                    rba.add(self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc)
+                    rba.add(self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
             else:
                 self._c("tnr_attn_long_bwd", a["qkv"], self.mask_add, self.rel, a["ctx"], self.dctx, a["lse"], self.delta,
                         self.dqkv, N, L, cfg.A)
                 if tr:
-                    self._c("tnr_colsum", self.dqkv, 3 * H, T.BF16, M, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True),
-                            self.cs_part, acc)
+                    self._c("tnr_colsum", self.dqkv, 3 * H, T.BF16, M, 3 * H, self.cs_tmp2[:3 * H], self.cs_part, 0)
+                    rba.add(self.cs_tmp2, 1, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
             if tr:
                 self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M, acc)
                 rba.flush()
@@ -902,10 +911,8 @@ class Engine:
                 bucket += 1
 
     def grad(self, name):
-        """Gradient of a trainable parameter with the fp16 loss scale removed (flat_g itself stays scaled until
-        the AMSGrad kernel divides it out)."""
-        g = self.grads[name]
-        return g / self.gscale if (self.gscale != 1.0 and self.off(name) < self.off(PFX + "dense.weight")) else g
+        """Gradient of a trainable parameter (a view into flat_g; the fp16 loss scale never reaches it)."""
+        return self.grads[name]
 
     def bucket_ranges(self):
         """Contiguous [start, end) slices of flat_g in the order their gradients complete."""
@@ -926,13 +933,13 @@ class Engine:
         use 1e-6 for bert_model and 1e-5 for the rest).  amsgrad=False: plain Adam (Post-train_KD.ipynb cell 18)."""
         self.step_count += 1
         head0 = self.off(PFX + ("attn.att_fc1.weight" if self.cfg.pooling == "att" else "dense.weight"))   # end of the BERT layers
-        cut = self.off(PFX + "dense.weight")     # [0, cut): encoder layers + pooling head = gradients carrying the loss scale
         e = self.off(PFX + "dense.bias") + self.slot[PFX + "dense.bias"][2]
         rest0 = min(_rup(e, 64), self.n_train)   # user encoders / transform matrices start here
         lb = lr if lr_bert is None else lr_bert
         lh = lr if lr_news_head is None else lr_news_head
-        for lo_, hi_, sc, rate in ((0, head0, grad_scale / self.gscale, lb), (head0, cut, grad_scale / self.gscale, lh),
-                                   (cut, rest0, grad_scale, lh), (rest0, self.n_train, grad_scale, lr)):
+        ranges = [(0, self.n_train, lr)] if (lb == lr and lh == lr) else [(0, head0, lb), (head0, rest0, lh), (rest0, self.n_train, lr)]
+        for lo_, hi_, rate in ranges:
+            sc = grad_scale
             if hi_ > lo_:
                 T.call("tnr_amsgrad_step", self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_],
                        self.adam_v[lo_:hi_], self.adam_vmax[lo_:hi_] if amsgrad else None, hi_ - lo_, self.step_count, rate,

@@ -181,7 +181,7 @@ class Model(_Shell):
     def _bind_grads(self):
         for k, p in self.named_parameters():
             if p.requires_grad and p.grad is None:
-                p.grad = self.engine.grads[self._engine_key(k)]      # NB fp16 mode: encoder/pooling grads carry engine.gscale until step()
+                p.grad = self.engine.grads[self._engine_key(k)]      # true gradients in both 16-bit modes
 
     def load_state_dict(self, sd, strict=True):
         out = super().load_state_dict(sd, strict=strict)

@@ -27,6 +27,7 @@ _SIG = {
     "tnr_gemm_nt_route": [_L, _L, _L, _I],
     "tnr_gemm_set_option": [_c.c_char_p, _I],
     "tnr_gemm_tn_wgrad": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _P],
+    "tnr_gemm_tn_wgrad_ex": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _F, _P],
     "tnr_gemm_tn_ws_elems": [_L, _L, _I],
     "tnr_ln_fwd": [_P, _P, _P, _F, _P, _P, _L, _I, _P],
     "tnr_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
@@ -59,6 +60,7 @@ _SIG = {
     "tnr_kd_embed_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "tnr_reduce_rows": [_P, _L, _L, _L, _P, _I, _P],
     "tnr_reduce_multi": [_P, _I, _P],
+    "tnr_scale_inplace": [_P, _L, _F, _P],
     "tnr_amsgrad_step": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "tnr_refresh_shadows": [_P, _I, _L, _P, _P],
     "tnr_cast_f32_to_bf16": [_P, _P, _L, _P],
@@ -66,7 +68,7 @@ _SIG = {
 }
 # entry points that exist twice: bf16 (plain name) and fp16 (suffix _f16)
 TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_colsum_rows", "tnr_gemm_nt_route",
-         "tnr_gemm_tn_wgrad", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd",
+         "tnr_gemm_tn_wgrad", "tnr_gemm_tn_wgrad_ex", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd",
          "tnr_colsum", "tnr_colsum_batched", "tnr_attpool_fwd", "tnr_attpool_bwd", "tnr_refresh_shadows",
          "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32", "tnr_pool_fwd", "tnr_pool_bwd"]
 for _n in TYPED:
@@ -118,7 +120,7 @@ TIMED = {}
 def _work(name, conv):
     if name in ("tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_nt_f16", "tnr_gemm_nt_ex_f16"):
         return 2.0 * conv[6] * conv[7] * conv[8]
-    if name == "tnr_gemm_tn_wgrad":
+    if name.startswith("tnr_gemm_tn_wgrad"):
         return 2.0 * conv[6] * conv[7] * conv[8]
     return 0.0
 
