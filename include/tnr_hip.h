@@ -41,6 +41,19 @@ extern "C" {
 #define TNR_EPI_OUTF32 32    /* C is fp32 instead of bf16 */
 #define TNR_EPI_AUXOUT 64    /* also store the pre-activation (acc+bias) to aux (bf16) */
 #define TNR_EPI_COLSUM 128   /* tnr_gemm_nt_ex: also emit per-64-row-strip column sums of the bf16 output (bias grads) */
+#define TNR_EPI_DROPOUT 256  /* internal: set by tnr_gemm_nt_do when a dropout site is passed (never by the caller) */
+
+/* Dropout site for the *_do entry points (train-mode semantics of the stage-0 / stage-1 notebooks, which call .train():
+ * Post-train_KD.ipynb cell 19, Domian-specific_Post-train.ipynb cell 16; sites tnlrv3/modeling.py:177, 224 and
+ * BertSelfOutput / BertOutput at :287, :306).  A host struct, read at launch; NULL or p <= 0 = no dropout (bit-identical to
+ * the entry point without the suffix).  Masks are counter-based (Philox4x32-10, csrc/dropout.h): nothing is stored, the
+ * backward entry points regenerate them from the same (seed, site, call). */
+typedef struct tnr_dropout {
+    uint64_t seed;   /* run seed = Philox key */
+    uint32_t site;   /* kind | layer << 8 ; kinds: 0 embeddings, 1 attention probabilities, 2 attention-output dense, 3 FFN-output dense */
+    uint32_t call;   /* number of the forward pass (distinct per encoder pass and step) */
+    double p;        /* drop probability ; kept elements are scaled by 1 / (1 - p) */
+} tnr_dropout_t;
 
 int tnr_version(void);
 const char* tnr_last_error(void);
@@ -256,6 +269,39 @@ int tnr_reduce_multi(const int64_t* desc, int n_blocks, void* stream);
 /* x[i] *= s , i < n (fp32) */
 int tnr_scale_inplace(float* x, int64_t n, float s, void* stream);
 
+/* ---- dropout (train-mode) variants: the same operations with a dropout site, see tnr_dropout_t ------------------ */
+int tnr_embed_ln_fwd_do(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
+                        const float* type0, const float* gamma, const float* beta, float eps, void* out, float* mask_add,
+                        const tnr_dropout_t* drop, void* stream);                       /* mask after the LayerNorm, :177 */
+int tnr_embed_ln_fwd_indexed_do(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
+                                const float* word, const float* pos, const float* type0, const float* gamma,
+                                const float* beta, float eps, void* out, float* mask_add, const tnr_dropout_t* drop,
+                                void* stream);
+/* C = epilogue(A . B^T) with the site's mask on (acc + bias [-> activation]) BEFORE the residual add:
+ * BertSelfOutput / BertOutput = dense -> dropout -> LayerNorm(x + residual).  Mask element index = m * N + n. */
+int tnr_gemm_nt_do(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                   void* aux, int64_t ldaux, int flags, float* colsum_part, const tnr_dropout_t* drop, void* stream);
+/* LayerNorm backward behind such a Linear: dx (the residual branch's gradient) and dxm = dx * mask / (1 - p) (the Linear's
+ * output gradient: what its weight gradient, dgrad and bias gradient consume; the dxsum partials are sums of dxm). */
+int tnr_ln_bwd_do(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                  float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* dxm,
+                  const tnr_dropout_t* drop, void* stream);
+/* attention with dropout on the normalised probabilities (:224); backward regenerates the mask */
+int tnr_attn_l32_fwd_do(const void* qkv, const float* mask_add, const float* rel, void* ctx, int64_t n_seq, int L, int A,
+                        const tnr_dropout_t* drop, void* stream);
+int tnr_attn_l32_bwd_do(const void* qkv, const float* mask_add, const float* rel, const void* dctx, void* dqkv,
+                        float* bias_part, int64_t n_seq, int L, int A, const tnr_dropout_t* drop, void* stream);
+int tnr_attn_long_fwd_do(const void* qkv, const float* mask_add, const float* rel, void* ctx, float* lse, int64_t n_seq,
+                         int L, int A, const tnr_dropout_t* drop, void* stream);
+int tnr_attn_long_bwd_do(const void* qkv, const float* mask_add, const float* rel, const void* ctx, const void* dctx,
+                         const float* lse, float* delta, void* dqkv, int64_t n_seq, int L, int A,
+                         const tnr_dropout_t* drop, void* stream);
+/* the multipliers (0 or 1 / (1 - p)) of a site as fp32, for tests: row-major (rows, cols) sites, and the attention
+ * probabilities (pairs = n_seq * A, L, L) through the per-query (by_columns = 0) or per-key (1) device accessor */
+int tnr_dropout_mask(const tnr_dropout_t* drop, int64_t rows, int64_t cols, float* out, void* stream);
+int tnr_dropout_mask_probs(const tnr_dropout_t* drop, int64_t pairs, int L, int by_columns, float* out, void* stream);
+
 /* ---- optimiser ------------------------------------------------------------------------------- */
 
 /* torch.optim.Adam(amsgrad=True) (run.py:134) on a flat fp32 parameter buffer ; step = 1-based count.
@@ -325,6 +371,29 @@ int tnr_refresh_shadows_f16(const int64_t* desc, int n_desc, int64_t total_tiles
                         void* stream);
 int tnr_cast_f32_to_bf16_f16(const float* src, void* dst, int64_t n, void* stream);
 int tnr_cast_bf16_to_f32_f16(const void* src, float* dst, int64_t n, void* stream);
+
+int tnr_embed_ln_fwd_do_f16(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
+                        const float* type0, const float* gamma, const float* beta, float eps, void* out, float* mask_add,
+                        const tnr_dropout_t* drop, void* stream);
+int tnr_embed_ln_fwd_indexed_do_f16(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
+                                const float* word, const float* pos, const float* type0, const float* gamma,
+                                const float* beta, float eps, void* out, float* mask_add, const tnr_dropout_t* drop,
+                                void* stream);
+int tnr_gemm_nt_do_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                   void* aux, int64_t ldaux, int flags, float* colsum_part, const tnr_dropout_t* drop, void* stream);
+int tnr_ln_bwd_do_f16(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                  float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* dxm,
+                  const tnr_dropout_t* drop, void* stream);
+int tnr_attn_l32_fwd_do_f16(const void* qkv, const float* mask_add, const float* rel, void* ctx, int64_t n_seq, int L, int A,
+                        const tnr_dropout_t* drop, void* stream);
+int tnr_attn_l32_bwd_do_f16(const void* qkv, const float* mask_add, const float* rel, const void* dctx, void* dqkv,
+                        float* bias_part, int64_t n_seq, int L, int A, const tnr_dropout_t* drop, void* stream);
+int tnr_attn_long_fwd_do_f16(const void* qkv, const float* mask_add, const float* rel, void* ctx, float* lse, int64_t n_seq,
+                         int L, int A, const tnr_dropout_t* drop, void* stream);
+int tnr_attn_long_bwd_do_f16(const void* qkv, const float* mask_add, const float* rel, const void* ctx, const void* dctx,
+                         const float* lse, float* delta, void* dqkv, int64_t n_seq, int L, int A,
+                         const tnr_dropout_t* drop, void* stream);
 
 #ifdef __cplusplus
 }

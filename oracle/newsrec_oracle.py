@@ -110,14 +110,19 @@ def linear(x, w, b=None):
 # --------------------------------------------------------------------------- #
 # encoder  (tnlrv3/modeling.py:133-178, 181-342, 421-476)
 # --------------------------------------------------------------------------- #
-def embeddings_fwd(P, ids, eps=1e-12):
-    """BertEmbeddings.forward tnlrv3/modeling.py:153-178: word + pos[arange] + type[0] -> LN."""
+def embeddings_fwd(P, ids, eps=1e-12, drop=None):
+    """BertEmbeddings.forward tnlrv3/modeling.py:153-178: word + pos[arange] + type[0] -> LN [-> dropout, train mode, :177].
+    drop: oracle/dropout_oracle.Dropout (the masks of this forward call) or None."""
     L = ids.shape[1]
     e = (P[BERT + "embeddings.word_embeddings.weight"][ids]
          + P[BERT + "embeddings.position_embeddings.weight"][:L][None]
          + P[BERT + "embeddings.token_type_embeddings.weight"][0][None, None])
     y, _ = layer_norm_fwd(e.astype(F32), P[BERT + "embeddings.LayerNorm.weight"],
                           P[BERT + "embeddings.LayerNorm.bias"], eps)
+    if drop is not None:
+        m = drop.hidden(0, 0, y.shape[0] * y.shape[1], y.shape[2])
+        if m is not None:
+            y = (y * m.reshape(y.shape)).astype(F32)
     return y
 
 
@@ -125,10 +130,12 @@ def _lp(l):
     return BERT + "encoder.layer.%d." % l
 
 
-def bert_layer_fwd(P, l, x, mask_add, rel, A, eps=1e-12):
+def bert_layer_fwd(P, l, x, mask_add, rel, A, eps=1e-12, drop=None):
     """BertLayer.forward tnlrv3/modeling.py:299-308 (+ BertSelfAttention :205-272).
 
-    x (N,L,H); mask_add (N,L) = (1-mask)*-10000 (:454); rel (A,L,L)."""
+    x (N,L,H); mask_add (N,L) = (1-mask)*-10000 (:454); rel (A,L,L).
+    drop (train mode only): dropout on the attention probabilities (:224) and on the two output Linears before their residual
+    adds (transformers BertSelfOutput / BertOutput, call sites :287, :306); masks from oracle/dropout_oracle.py."""
     p = _lp(l)
     N, L, H = x.shape
     d = H // A
@@ -141,16 +148,24 @@ def bert_layer_fwd(P, l, x, mask_add, rel, A, eps=1e-12):
     s = (qh @ kh.transpose(0, 1, 3, 2)) / F32(math.sqrt(d))
     s = s + mask_add[:, None, None, :] + rel[None]
     pr = softmax(s, -1)
-    ctx = (pr @ vh).transpose(0, 2, 1, 3).reshape(N, L, H)
+    mp = drop.probs(l, N, A, L) if drop is not None else None
+    mo = drop.hidden(2, l, N * L, H) if drop is not None else None
+    mf = drop.hidden(3, l, N * L, H) if drop is not None else None
+    prd = (pr * mp).astype(F32) if mp is not None else pr           # what multiplies V
+    ctx = (prd @ vh).transpose(0, 2, 1, 3).reshape(N, L, H)
     ao = linear(ctx, P[p + "attention.output.dense.weight"], P[p + "attention.output.dense.bias"])
+    if mo is not None:
+        ao = ao * mo.reshape(N, L, H)
     h1, ln1 = layer_norm_fwd((ao + x).astype(F32), P[p + "attention.output.LayerNorm.weight"],
                              P[p + "attention.output.LayerNorm.bias"], eps)
     u = linear(h1, P[p + "intermediate.dense.weight"], P[p + "intermediate.dense.bias"]).astype(F32)
     g = gelu(u)
     f = linear(g, P[p + "output.dense.weight"], P[p + "output.dense.bias"])
+    if mf is not None:
+        f = f * mf.reshape(N, L, H)
     y, ln2 = layer_norm_fwd((f + h1).astype(F32), P[p + "output.LayerNorm.weight"],
                             P[p + "output.LayerNorm.bias"], eps)
-    cache = dict(x=x, qh=qh, kh=kh, vh=vh, pr=pr, ctx=ctx, ln1=ln1, h1=h1, u=u, g=g, ln2=ln2)
+    cache = dict(x=x, qh=qh, kh=kh, vh=vh, pr=pr, ctx=ctx, ln1=ln1, h1=h1, u=u, g=g, ln2=ln2, mp=mp, mo=mo, mf=mf)
     return y, cache
 
 
@@ -164,15 +179,25 @@ def bert_layer_bwd(P, l, dy, c, A, need_dx=True, need_dw=True):
     M = N * L
     r2 = lambda t: t.reshape(M, -1)
     dypre, dg2, db2 = layer_norm_bwd(dy, c["ln2"], P[p + "output.LayerNorm.weight"])
+    dres2 = dypre                                                  # gradient of the residual branch (h1)
+    if c.get("mf") is not None:                                    # gradient of the Linear's output: through its dropout
+        dypre = (dypre * c["mf"].reshape(dypre.shape)).astype(F32)
     dgact = dypre @ P[p + "output.dense.weight"]
     du = (dgact * gelu_grad(c["u"])).astype(F32)
-    dh1 = dypre + du @ P[p + "intermediate.dense.weight"]
+    dh1 = dres2 + du @ P[p + "intermediate.dense.weight"]
     dh1pre, dg1, db1 = layer_norm_bwd(dh1.astype(F32), c["ln1"], P[p + "attention.output.LayerNorm.weight"])
+    dres1 = dh1pre                                                 # residual branch (x)
+    if c.get("mo") is not None:
+        dh1pre = (dh1pre * c["mo"].reshape(dh1pre.shape)).astype(F32)
     dctx = dh1pre @ P[p + "attention.output.dense.weight"]
     dch = dctx.reshape(N, L, A, d).transpose(0, 2, 1, 3)
     pr, qh, kh, vh = c["pr"], c["qh"], c["kh"], c["vh"]
     dp = dch @ vh.transpose(0, 1, 3, 2)
-    dvh = pr.transpose(0, 1, 3, 2) @ dch
+    if c.get("mp") is not None:
+        dp = dp * c["mp"]
+        dvh = (pr * c["mp"]).transpose(0, 1, 3, 2) @ dch
+    else:
+        dvh = pr.transpose(0, 1, 3, 2) @ dch
     ds = pr * (dp - (dp * pr).sum(-1, keepdims=True))
     sc = F32(1.0 / math.sqrt(d))
     dqh = (ds @ kh) * sc
@@ -194,7 +219,7 @@ def bert_layer_bwd(P, l, dy, c, A, need_dx=True, need_dw=True):
         G = {k_: v_.astype(F32) for k_, v_ in G.items()}
     dx = None
     if need_dx:
-        dx = (dh1pre + dq @ P[p + "attention.self.query.weight"] + dk @ P[p + "attention.self.key.weight"]
+        dx = (dres1 + dq @ P[p + "attention.self.query.weight"] + dk @ P[p + "attention.self.key.weight"]
               + dv @ P[p + "attention.self.value.weight"]).astype(F32)
     return dx, G
 
@@ -240,28 +265,28 @@ def split_tokens(x2l):
     return x2l[:, :L], x2l[:, L:]
 
 
-def encoder_fwd(P, ids, mask, n_layers, A, keep_from=None):
+def encoder_fwd(P, ids, mask, n_layers, A, keep_from=None, drop=None):
     """TuringNLRv3Model.forward tnlrv3/modeling.py:421-476 -> last hidden state.
 
     keep_from: first layer whose cache is kept for backward (None = keep none)."""
     mask_add = ((1.0 - mask.astype(F32)) * F32(-10000.0)).astype(F32)
-    x = embeddings_fwd(P, ids)
+    x = embeddings_fwd(P, ids, drop=drop)
     rel = relpos_bias_table(P[BERT + "rel_pos_bias.weight"], ids.shape[1])
     caches = {}
     hidden = [x]
     for l in range(n_layers):
-        x, c = bert_layer_fwd(P, l, x, mask_add, rel, A)
+        x, c = bert_layer_fwd(P, l, x, mask_add, rel, A, drop=drop)
         hidden.append(x)
         if keep_from is not None and l >= keep_from:
             caches[l] = c
     return x, caches, hidden
 
 
-def news_encoder_fwd(P, x2l, n_layers, A, keep_from=None, pooling="att"):
+def news_encoder_fwd(P, x2l, n_layers, A, keep_from=None, pooling="att", drop=None):
     """NewsEncoder.forward model_bert.py:119-137: pooling 'att' (additive attention, no mask) | 'cls' (token 0) |
     anything else = mean over ALL L positions (padding included, :135), then dense."""
     ids, mask = split_tokens(x2l)
-    h, caches, hidden = encoder_fwd(P, ids, mask, n_layers, A, keep_from)
+    h, caches, hidden = encoder_fwd(P, ids, mask, n_layers, A, keep_from, drop=drop)
     pc = None
     if pooling == "att":
         nv, pc = att_pool_fwd(h, P[PFX + "attn.att_fc1.weight"], P[PFX + "attn.att_fc1.bias"],
@@ -497,15 +522,16 @@ def model_bwd(P, cfg, out):
 # As published the cell multiplies a Python list by a tensor (cell 14:41); restated with the evident intent
 # torch.stack(teacher_MSEs, -1), the form model_bert.py:300 uses.
 # --------------------------------------------------------------------------- #
-def distill_fwd(P, cfg, title, body, label, teacher_titles, teacher_bodies, keep=True):
+def distill_fwd(P, cfg, title, body, label, teacher_titles, teacher_bodies, keep=True, drop_title=None, drop_body=None):
     """title (B,1+K,2Lt) int, body (B,2Lb) int, label (B,), teacher_titles T x (B,1+K,D), teacher_bodies T x (B,D).
-    cfg: n_layers, heads, trainable_layers.  loss = target + distill(tau=1) + emb."""
+    cfg: n_layers, heads, trainable_layers.  loss = target + distill(tau=1) + emb.
+    drop_title / drop_body: dropout masks of the two encoder passes (the notebook trains under .train(), cell 19:6)."""
     B, C, W2 = title.shape
     A, nl = cfg["heads"], cfg["n_layers"]
     tr = sorted(cfg["trainable_layers"])
     keep_from = (min(tr) if tr else nl) if keep else None
-    bvec, bc = news_encoder_fwd(P, body, nl, A, keep_from)                     # cell 12: body first
-    tvec, tc = news_encoder_fwd(P, title.reshape(B * C, W2), nl, A, keep_from)
+    bvec, bc = news_encoder_fwd(P, body, nl, A, keep_from, drop=drop_body)                     # cell 12: body first
+    tvec, tc = news_encoder_fwd(P, title.reshape(B * C, W2), nl, A, keep_from, drop=drop_title)
     D = bvec.shape[1]
     tv = tvec.reshape(B, C, D)
     score = np.einsum("bcd,bd->bc", tv, bvec).astype(F32)

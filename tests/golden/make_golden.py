@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
+sys.path.insert(0, ROOT)
 import hashinit  # noqa: E402
 import ref_shim  # noqa: E402
 
@@ -294,7 +295,51 @@ def _notebook_distill_classes(R, cfg_json):
     return ns
 
 
-def golden_stage1(R, only=None):
+def _patch_dropouts(bert, p_hidden, p_attn, seed):
+    """Replace the forward of every nn.Dropout the encoder runs in train mode (tnlrv3/modeling.py:177 embeddings, :224 attention
+    probabilities, transformers BertSelfOutput / BertOutput at :287 / :306) by a multiplication with the counter-based mask of
+    oracle/dropout_oracle.py: the reference's OWN modules then decide where a mask acts and how it is scaled, and the oracle /
+    the HIP path are checked against that with the same bits.  DistillModel.forward encodes the bodies first, then the titles
+    (Post-train_KD.ipynb cell 12): the n-th call of a module is pass 1 (body) for even n, pass 0 (title) for odd n, forward call
+    number = 2 * (n // 2) + pass."""
+    from oracle import dropout_oracle as DO
+    sites = {"embeddings.dropout": (DO.KIND_EMB, 0)}
+    for l in range(len(bert.encoder.layer)):
+        sites["encoder.layer.%d.attention.self.dropout" % l] = (DO.KIND_PROB, l)
+        sites["encoder.layer.%d.attention.output.dropout" % l] = (DO.KIND_ATTN_OUT, l)
+        sites["encoder.layer.%d.output.dropout" % l] = (DO.KIND_FFN_OUT, l)
+    mods = dict(bert.named_modules())
+    seen = []
+    for name, (kind, layer) in sites.items():
+        m = mods[name]
+        assert isinstance(m, torch.nn.Dropout), name
+        state = {"n": 0}
+
+        def fwd(x, kind=kind, layer=layer, state=state, m=m):
+            assert m.training
+            n = state["n"]
+            state["n"] += 1
+            call = 2 * (n // 2) + (1 if n % 2 == 0 else 0)
+            site = DO.site_id(kind, layer)
+            if kind == DO.KIND_PROB:
+                N, A, L, _ = x.shape
+                mask = DO.probs_mask(p_attn, seed, site, call, N, A, L)
+            else:
+                N, L, H = x.shape
+                mask = DO.rows_mask(p_hidden, seed, site, call, N * L, H).reshape(N, L, H)
+            return x * torch.from_numpy(mask)
+        m.forward = fwd
+        seen.append(name)
+    return seen
+
+
+def golden_stage1_dropout(R):
+    """Stage 1 under .train() (Post-train_KD.ipynb cell 19:6) with the masks of oracle/dropout_oracle.py: a tiny case with every
+    gradient and the BASELINE configs[4] shapes."""
+    golden_stage1(R, only=("tiny", "cfg4"), dropout=(0.1, 0.1, 777))
+
+
+def golden_stage1(R, only=None, dropout=None):
     import types
     cases = [("tiny", dict(ref_shim.BASE_CFG, hidden_size=64, num_attention_heads=4, intermediate_size=256, vocab_size=128,
                            max_position_embeddings=64, num_hidden_layers=2), dict(news_dim=32, news_query_vector_dim=16),
@@ -311,6 +356,13 @@ def golden_stage1(R, only=None):
         args = types.SimpleNamespace(num_hidden_layers=cfg_json["num_hidden_layers"], num_teachers=T, **dims)
         model = ns["DistillModel"](args)
         fill(model, seed)
+        if dropout is not None:
+            model.train()
+            patched = _patch_dropouts(model.student.news_encoder.bert_model.bert, *dropout)
+            others = [k for k, m in model.named_modules() if isinstance(m, torch.nn.Dropout) and
+                      k.replace("student.news_encoder.bert_model.bert.", "") not in patched]
+            # anything else must not sit on the path (the dead pooler / classifier head's dropout is never reached)
+            assert all(k.endswith("bert_model.dropout") for k in others), others
         for p in model.student.news_encoder.bert_model.parameters():
             p.requires_grad = False
         for i, layer in enumerate(model.student.news_encoder.bert_model.bert.encoder.layer):
@@ -336,6 +388,8 @@ def golden_stage1(R, only=None):
                    in_title=title, in_body=body, in_label=label,
                    meta=np.array([seed, B, T, C, Lt, Lb, D, cfg_json["num_attention_heads"], cfg_json["num_hidden_layers"]]),
                    trainable=np.array(sorted(trainable)))
+        if dropout is not None:
+            rec["dropout"] = np.array(dropout, dtype=np.float64)      # p_hidden, p_attn, seed
         for i in range(T):
             rec["in_tt%d" % i], rec["in_tb%d" % i] = tt[i], tb[i]
         gn = []
@@ -351,8 +405,8 @@ def golden_stage1(R, only=None):
                 idx, val = grad_samples(seed, k, g)
                 rec["gidx." + k], rec["gval." + k] = idx, val
         rec["grad_names"] = np.array(gn)
-        np.savez_compressed(os.path.join(HERE, "stage1_%s.npz" % name), **rec)
-        print("stage1", name, rec["total"], rec["target"], rec["distill"], rec["emb"])
+        np.savez_compressed(os.path.join(HERE, "stage1_%s%s.npz" % (name, "_drop" if dropout is not None else "")), **rec)
+        print("stage1", name, "dropout" if dropout is not None else "", rec["total"], rec["target"], rec["distill"], rec["emb"])
 
 
 from helpers import unilm_checkpoint as _unilm_checkpoint  # noqa: E402
@@ -536,5 +590,7 @@ def golden_interface():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "configs":       # only the round-2 additions (the other fixtures are unchanged)
         golden_configs(ref_shim.load_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == "dropout":
+        golden_stage1_dropout(ref_shim.load_reference())
     else:
         main()

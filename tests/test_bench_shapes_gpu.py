@@ -129,6 +129,20 @@ def test_gemm_nt_epilogues_at_bench_shape(dtype, name, N, K, flags):
         np.testing.assert_allclose(cs.sum(0).cpu().numpy(), want_cs, rtol=1e-4, atol=1e-2, err_msg=name + "/colsum")
 
 
+def test_gemm_nt_plain_loop_variant_bit_exact():
+    """The 256-row routes have two main loops in the library (tnr_gemm_set_option "pp": 1 = the persistent ping-pong kernel, the
+    default; 0 = the plain two-buffer loop with the LDS-staged epilogue): the other one stays pinned on every launch shape too."""
+    L = T.lib()
+    try:
+        assert L.tnr_gemm_set_option(b"pp", 0) == 0
+        for name, N, K, flags in NT_LAUNCHES:
+            test_gemm_nt_main_loop_bit_exact_at_bench_shape("fp16", name, N, K, flags)
+            test_gemm_nt_epilogues_at_bench_shape("fp16", name, N, K, flags)
+        test_gemm_nt_epilogues_at_bench_shape("bf16", *NT_LAUNCHES[2])
+    finally:
+        L.tnr_gemm_set_option(b"pp", 1)
+
+
 def test_gemm_nt_routes_cover_every_tile_variant():
     """The three routes the engine's shapes can take, each pinned on a small integer-exact case as well."""
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
@@ -164,6 +178,18 @@ def test_gemm_tn_wgrad_bit_exact_at_bench_shape(dtype, name, N, K):
     T.call("tnr_gemm_tn_wgrad" + _sfx(dtype), dy, N, x, K, dW, K, M, N, K, ws, splits, 1)
     torch.cuda.synchronize()
     assert np.array_equal(dW.cpu().numpy(), 2 * want), name + "/accumulate"
+
+
+def test_gemm_tn_wgrad_plain_loop_variant_bit_exact():
+    """The weight-gradient kernel's other main loop (tnr_gemm_set_option "tnpp" = 0: plain two-buffer loop; the default is the
+    ping-pong schedule) on the same launches."""
+    L = T.lib()
+    try:
+        assert L.tnr_gemm_set_option(b"tnpp", 0) == 0
+        for name, N, K in WGRAD_LAUNCHES:
+            test_gemm_tn_wgrad_bit_exact_at_bench_shape("fp16", name, N, K)
+    finally:
+        L.tnr_gemm_set_option(b"tnpp", 1)
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])

@@ -150,6 +150,63 @@ def test_stage1_distill_forward_backward(name):
             np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-10, err_msg=n)
 
 
+def stage1_dropouts(z):
+    """The two encoder passes' mask sets of a *_drop golden: titles = pass 0, bodies = pass 1, first forward call."""
+    from oracle import dropout_oracle as DO
+    p_h, p_a, seed = [float(x) for x in z["dropout"]]
+    return DO.Dropout(p_h, p_a, int(seed), 0), DO.Dropout(p_h, p_a, int(seed), 1)
+
+
+@pytest.mark.parametrize("name", ["stage1_tiny_drop.npz", "stage1_cfg4_drop.npz"])
+def test_stage1_distill_train_mode_dropout(name):
+    """Stage 1 as the notebook trains it -- .train(), dropout live (Post-train_KD.ipynb cell 19:6) -- against the notebook's own
+    modules run with their nn.Dropout forwards replaced by the counter-based masks of oracle/dropout_oracle.py: pins WHERE the
+    four dropout sites act and how they scale, forward and backward."""
+    from helpers import load_stage1_case
+    z, P, cfg, inp = load_stage1_case(name)
+    dt, db = stage1_dropouts(z)
+    out = O.distill_fwd(P, cfg, *inp, drop_title=dt, drop_body=db)
+    for k, g in (("total_loss", "total"), ("target_loss", "target"), ("distill_loss", "distill"), ("emb_loss", "emb")):
+        np.testing.assert_allclose(out[k], z[g], rtol=RTOL, atol=ATOL, err_msg=k)
+    np.testing.assert_allclose(out["student_score"], z["score"], rtol=1e-3, atol=ATOL)
+    # the masks matter: the eval-mode forward of the same inputs is somewhere else
+    plain = O.distill_fwd(P, cfg, *inp, keep=False)
+    assert np.abs(plain["student_score"] - z["score"]).max() > 20 * ATOL
+    G = O.distill_bwd(P, cfg, out)
+    for n in [str(x) for x in z["grad_names"]]:
+        g = G[n]
+        ref_norm = float(z["gnorm." + n])
+        if n.endswith("self.key.bias") or n.endswith("att_fc2.bias"):
+            assert np.sqrt((g.astype(np.float64) ** 2).sum()) < 1e-4 and ref_norm < 1e-4
+            continue
+        np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), ref_norm, rtol=1e-3, atol=1e-9, err_msg=n)
+        if "grad." + n in z.files:
+            ref = z["grad." + n]
+            np.testing.assert_allclose(g, ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-10, err_msg=n)
+        else:
+            ref = z["gval." + n]
+            np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-10, err_msg=n)
+
+
+def test_philox_known_answers_and_mask_statistics():
+    """Philox4x32-10 against the Random123 known-answer vectors, and the keep rate / scaling of the masks built on it."""
+    from oracle import dropout_oracle as DO
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in DO.philox4x32_10(*ctr, *key)) == want
+    m = DO.rows_mask(0.1, 99, DO.site_id(DO.KIND_FFN_OUT, 3), 5, 2048, 768)
+    assert set(np.unique(m)) == {np.float32(0.0), np.float32(1.0 / 0.9)}
+    assert abs((m == 0).mean() - DO.threshold(0.1) / 65536.0) < 1e-3 and abs(m.mean() - 1.0) < 2e-3
+    pm = DO.probs_mask(0.1, 99, DO.site_id(DO.KIND_PROB, 1), 5, 8, 12, 30)
+    assert abs((pm == 0).mean() - 0.1) < 3e-3
+    # different sites / calls / seeds are different streams
+    for other in (DO.rows_mask(0.1, 99, DO.site_id(DO.KIND_FFN_OUT, 2), 5, 2048, 768), DO.rows_mask(0.1, 99, DO.site_id(DO.KIND_FFN_OUT, 3), 6, 2048, 768),
+                  DO.rows_mask(0.1, 98, DO.site_id(DO.KIND_FFN_OUT, 3), 5, 2048, 768)):
+        assert 0.15 < ((m == 0) != (other == 0)).mean() < 0.21          # 2 p (1 - p) = 0.18 for independent masks
+
+
 def test_nrms_self_attention_backward_matches_finite_differences():
     """The NRMS goldens carry little gradient through the user encoder (see the noise-floor note above), so the
     hand-derived backward of model_bert.py:37-100 is also checked against central differences of its own forward."""

@@ -53,7 +53,7 @@ __device__ __forceinline__ void acc_to_lds(char* tile, const f32x16& x, int ct, 
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                        const float* __restrict__ rel, bf16* __restrict__ ctx,
-                                                       int64_t n_pairs, int L, int A) {
+                                                       int64_t n_pairs, int L, int A, TnrDrop drop) {
     __shared__ __attribute__((aligned(16))) char lds[4][4096];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t pair = (int64_t)blockIdx.x * 4 + w;
@@ -109,6 +109,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] *= inv;
+    if (drop.thresh) {                                   // tnlrv3/modeling.py:224: dropout on the normalised probabilities
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float dm[4];
+            tnr_drop_prob_row(drop, (uint64_t)pair, 8, row, 8 * g + 4 * h, dm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[4 * g + e] *= dm[e];
+        }
+    }
     bf16x8 pf[2];
     acc_to_frags(st, pf);
 
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                        const float* __restrict__ rel, const bf16* __restrict__ dctx,
                                                        bf16* __restrict__ dqkv, float* __restrict__ bias_part,
-                                                       int64_t n_pairs, int L, int A) {
+                                                       int64_t n_pairs, int L, int A, TnrDrop drop) {
     // per wave: K tile, dO tile, Q tile (each 4 KB, row-major [32][64]) + 256 B of row statistics
     __shared__ __attribute__((aligned(16))) char lds[4][3 * 4096 + 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -203,6 +212,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
         float dsum = 0.f;
+        if (drop.thresh) {                               // d/dP of (P * mask / (1 - p)) . V : the mask multiplies dP
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float dm[4];
+                tnr_drop_prob_row(drop, (uint64_t)pair, 8, row, 8 * g + 4 * h, dm);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dpt[4 * g + e] *= dm[e];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             st[r] *= inv;
@@ -241,12 +259,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         for (int g = 0; g < 4; ++g) {
             f32x4 lse = *(const f32x4*)(stat + 8 * g + 4 * h);
             f32x4 dd = *(const f32x4*)(stat + 32 + 8 * g + 4 * h);
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thresh) tnr_drop_prob_col(drop, (uint64_t)pair, 8, 8 * g + 4 * h, row, dm);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int qi = 8 * g + 4 * h + e;
                 float p = __expf(sn[4 * g + e] * 0.125f + mk + relc[qi * 32] - lse[e]);
-                sn[4 * g + e] = p;
-                dpn[4 * g + e] = p * (dpn[4 * g + e] - dd[e]);           // dS
+                sn[4 * g + e] = p * dm[e];                                // what multiplied V in the forward pass
+                dpn[4 * g + e] = p * (dpn[4 * g + e] * dm[e] - dd[e]);    // dS
             }
         }
     }
@@ -318,7 +338,8 @@ __device__ __forceinline__ bf16x8 ld_frag(const bf16* base, int64_t ld, int row,
 
 __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                             const float* __restrict__ rel, bf16* __restrict__ ctx,
-                                                            float* __restrict__ lse, int64_t n_items, int L, int Lr, int A) {
+                                                            float* __restrict__ lse, int64_t n_items, int L, int Lr, int A,
+                                                            TnrDrop drop) {
     __shared__ __attribute__((aligned(16))) char lds[4][4096];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t item = (int64_t)blockIdx.x * 4 + w;
@@ -383,6 +404,15 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restri
         sum += __shfl_xor(sum, 32, 64);
         l_run = l_run * alpha + sum;
         m_run = m_new;
+        if (drop.thresh) {                               // the normaliser keeps every key; only what multiplies V is masked
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float dm[4];
+                tnr_drop_prob_row(drop, (uint64_t)na, Lr >> 2, qi < Lr ? qi : Lr - 1, kt * 32 + 8 * g + 4 * h, dm);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st[4 * g + e] *= dm[e];
+            }
+        }
         bf16x8 pf[2];
         acc_to_frags(st, pf);
 #pragma unroll
@@ -416,7 +446,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
                                                                const float* __restrict__ rel, const bf16* __restrict__ ctx,
                                                                const bf16* __restrict__ dctx, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                               int64_t n_items, int L, int Lr, int A) {
+                                                               int64_t n_items, int L, int Lr, int A, TnrDrop drop) {
     __shared__ __attribute__((aligned(16))) char lds[4][4096];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t item = (int64_t)blockIdx.x * 4 + w;
@@ -477,10 +507,12 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
         for (int g = 0; g < 4; ++g) {
             f32x4 mk = *(const f32x4*)(mp + kt * 32 + 8 * g + 4 * h);
             f32x4 rl = *(const f32x4*)(relq + kt * 32 + 8 * g + 4 * h);
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thresh) tnr_drop_prob_row(drop, (uint64_t)na, Lr >> 2, qi < Lr ? qi : Lr - 1, kt * 32 + 8 * g + 4 * h, dm);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float p = __expf(st[4 * g + e] * 0.125f + mk[e] + rl[e] - lse_i);
-                st[4 * g + e] = p * (dpt[4 * g + e] - dl);                       // dS^T
+                st[4 * g + e] = p * (dpt[4 * g + e] * dm[e] - dl);               // dS^T
             }
         }
         bf16x8 dsf[2];
@@ -504,7 +536,8 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
 __global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                                 const float* __restrict__ rel, const bf16* __restrict__ dctx,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                bf16* __restrict__ dqkv, int64_t n_items, int L, int Lr, int A) {
+                                                                bf16* __restrict__ dqkv, int64_t n_items, int L, int Lr, int A,
+                                                                TnrDrop drop) {
     __shared__ __attribute__((aligned(16))) char lds[4][2 * 4096];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t item = (int64_t)blockIdx.x * 4 + w;
@@ -561,12 +594,14 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const bf16* __re
         for (int g = 0; g < 4; ++g) {
             f32x4 ls = *(const f32x4*)(lsep + qt * 32 + 8 * g + 4 * h);
             f32x4 dd = *(const f32x4*)(dlp + qt * 32 + 8 * g + 4 * h);
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thresh) tnr_drop_prob_col(drop, (uint64_t)na, Lr >> 2, qt * 32 + 8 * g + 4 * h, kj < Lr ? kj : Lr - 1, dm);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int q = qt * 32 + 8 * g + 4 * h + e;
                 float p = __expf(sn[4 * g + e] * 0.125f + mk + relc[(int64_t)q * Lr] - ls[e]);
-                sn[4 * g + e] = p;
-                dpn[4 * g + e] = p * (dpn[4 * g + e] - dd[e]);
+                sn[4 * g + e] = p * dm[e];
+                dpn[4 * g + e] = p * (dpn[4 * g + e] * dm[e] - dd[e]);
             }
         }
         bf16x8 pnf[2], dsf[2];
@@ -600,37 +635,55 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const bf16* __re
 
 extern "C" int TNR_NAME(tnr_attn_l32_fwd)(const void* qkv, const float* mask_add, const float* rel, void* ctx, int64_t n_seq,
                                 int L, int A, void* stream) {
+    return TNR_NAME(tnr_attn_l32_fwd_do)(qkv, mask_add, rel, ctx, n_seq, L, A, nullptr, stream);
+}
+extern "C" int TNR_NAME(tnr_attn_l32_fwd_do)(const void* qkv, const float* mask_add, const float* rel, void* ctx, int64_t n_seq,
+                                   int L, int A, const tnr_dropout_t* drop, void* stream) {
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_attn_l32_fwd")) return rc;
     TNR_CHECK_ARG(qkv && mask_add && rel && ctx, "tnr_attn_l32_fwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 32 && A >= 1 && n_seq >= 1, "tnr_attn_l32_fwd: need 1<=L<=32");
     TNR_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 16) == 0, "tnr_attn_l32_fwd: 16-byte alignment");
     int64_t pairs = n_seq * A;
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)qkv, mask_add, rel, (bf16*)ctx, pairs, L, A);
+                       (const bf16*)qkv, mask_add, rel, (bf16*)ctx, pairs, L, A, dd);
     TNR_CHECK_LAUNCH("tnr_attn_l32_fwd");
     return TNR_OK;
 }
 
 extern "C" int TNR_NAME(tnr_attn_l32_bwd)(const void* qkv, const float* mask_add, const float* rel, const void* dctx, void* dqkv,
                                 float* bias_part, int64_t n_seq, int L, int A, void* stream) {
+    return TNR_NAME(tnr_attn_l32_bwd_do)(qkv, mask_add, rel, dctx, dqkv, bias_part, n_seq, L, A, nullptr, stream);
+}
+extern "C" int TNR_NAME(tnr_attn_l32_bwd_do)(const void* qkv, const float* mask_add, const float* rel, const void* dctx, void* dqkv,
+                                   float* bias_part, int64_t n_seq, int L, int A, const tnr_dropout_t* drop, void* stream) {
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_attn_l32_bwd")) return rc;
     TNR_CHECK_ARG(qkv && mask_add && rel && dctx && dqkv, "tnr_attn_l32_bwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 32 && A >= 1 && n_seq >= 1, "tnr_attn_l32_bwd: need 1<=L<=32");
     TNR_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)dctx % 16) == 0 && ((uintptr_t)dqkv % 16) == 0,
                   "tnr_attn_l32_bwd: 16-byte alignment");
     int64_t pairs = n_seq * A;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)qkv, mask_add, rel, (const bf16*)dctx, (bf16*)dqkv, bias_part, pairs, L, A);
+                       (const bf16*)qkv, mask_add, rel, (const bf16*)dctx, (bf16*)dqkv, bias_part, pairs, L, A, dd);
     TNR_CHECK_LAUNCH("tnr_attn_l32_bwd");
     return TNR_OK;
 }
 
 extern "C" int TNR_NAME(tnr_attn_long_fwd)(const void* qkv, const float* mask_add, const float* rel, void* ctx, float* lse,
                                            int64_t n_seq, int L, int A, void* stream) {
+    return TNR_NAME(tnr_attn_long_fwd_do)(qkv, mask_add, rel, ctx, lse, n_seq, L, A, nullptr, stream);
+}
+extern "C" int TNR_NAME(tnr_attn_long_fwd_do)(const void* qkv, const float* mask_add, const float* rel, void* ctx, float* lse,
+                                              int64_t n_seq, int L, int A, const tnr_dropout_t* drop, void* stream) {
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_attn_long_fwd")) return rc;
     TNR_CHECK_ARG(qkv && mask_add && rel && ctx && lse, "tnr_attn_long_fwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 512 && A >= 1 && n_seq >= 1, "tnr_attn_long_fwd: need 1<=L<=512");
     const int Lr = (L + 31) / 32 * 32;
     int64_t items = n_seq * A * (Lr / 32);
     hipLaunchKernelGGL(attn_long_fwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)qkv, mask_add, rel, (bf16*)ctx, lse, items, L, Lr, A);
+                       (const bf16*)qkv, mask_add, rel, (bf16*)ctx, lse, items, L, Lr, A, dd);
     TNR_CHECK_LAUNCH("tnr_attn_long_fwd");
     return TNR_OK;
 }
@@ -638,16 +691,23 @@ extern "C" int TNR_NAME(tnr_attn_long_fwd)(const void* qkv, const float* mask_ad
 extern "C" int TNR_NAME(tnr_attn_long_bwd)(const void* qkv, const float* mask_add, const float* rel, const void* ctx,
                                            const void* dctx, const float* lse, float* delta, void* dqkv, int64_t n_seq,
                                            int L, int A, void* stream) {
+    return TNR_NAME(tnr_attn_long_bwd_do)(qkv, mask_add, rel, ctx, dctx, lse, delta, dqkv, n_seq, L, A, nullptr, stream);
+}
+extern "C" int TNR_NAME(tnr_attn_long_bwd_do)(const void* qkv, const float* mask_add, const float* rel, const void* ctx,
+                                              const void* dctx, const float* lse, float* delta, void* dqkv, int64_t n_seq,
+                                              int L, int A, const tnr_dropout_t* drop, void* stream) {
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_attn_long_bwd")) return rc;
     TNR_CHECK_ARG(qkv && mask_add && rel && ctx && dctx && lse && delta && dqkv, "tnr_attn_long_bwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 512 && A >= 1 && n_seq >= 1, "tnr_attn_long_bwd: need 1<=L<=512");
     const int Lr = (L + 31) / 32 * 32;
     int64_t items = n_seq * A * (Lr / 32);
     dim3 grid((unsigned)((items + 3) / 4)), blk(256);
     hipLaunchKernelGGL(attn_long_bwd_dq_kernel, grid, blk, 0, (hipStream_t)stream, (const bf16*)qkv, mask_add, rel,
-                       (const bf16*)ctx, (const bf16*)dctx, lse, delta, (bf16*)dqkv, items, L, Lr, A);
+                       (const bf16*)ctx, (const bf16*)dctx, lse, delta, (bf16*)dqkv, items, L, Lr, A, dd);
     TNR_CHECK_LAUNCH("tnr_attn_long_bwd/dq");
     hipLaunchKernelGGL(attn_long_bwd_dkv_kernel, grid, blk, 0, (hipStream_t)stream, (const bf16*)qkv, mask_add, rel,
-                       (const bf16*)dctx, lse, delta, (bf16*)dqkv, items, L, Lr, A);
+                       (const bf16*)dctx, lse, delta, (bf16*)dqkv, items, L, Lr, A, dd);
     TNR_CHECK_LAUNCH("tnr_attn_long_bwd/dkv");
     return TNR_OK;
 }

@@ -40,7 +40,8 @@ struct TnrGemmOpts {
     int allow_fine;  // 0 = never fall back to the 128x128 kernel for sparse grids
     int bm;          // 0 = pick the tile height per launch ; 224 / 256 = force it
     int nt;          // 1 = non-temporal accesses for once-touched epilogue operands
-    int pp;          // 1 = ping-pong main loop (two wave groups staggered by a barrier), 0 = two-phase loop
+    int pp;          // 1 = ping-pong main loop (two wave groups staggered by a barrier), 0 = plain two-buffer loop
+    int tnpp;        // weight gradient: 1 = ping-pong main loop, 0 = plain two-buffer loop
     int probe;       // timing probes of the ping-pong kernel (only in -DTNR_PROBES builds, tools/probe_build.sh)
 };
 TnrGemmOpts* tnr_gemm_opts();
@@ -52,6 +53,21 @@ TnrGemmOpts* tnr_gemm_opts();
             return TNR_EINVAL;            \
         }                                 \
     } while (0)
+
+// public dropout descriptor (host memory, may be NULL = off) -> kernel argument
+#include "dropout.h"
+static inline int tnr_make_drop(const tnr_dropout_t* d, TnrDrop* o, const char* who) {
+    *o = TnrDrop{0u, 0u, 0u, 0u, 0u, 1.0f};
+    if (!d || d->p <= 0.0) return TNR_OK;
+    if (!(d->p < 1.0)) { tnr_set_error("%s: dropout p must be in [0, 1)", who); return TNR_EINVAL; }
+    o->k0 = (uint32_t)d->seed;
+    o->k1 = (uint32_t)(d->seed >> 32);
+    o->site = d->site;
+    o->call = d->call;
+    o->thresh = (uint32_t)(d->p * 65536.0 + 0.5);
+    o->scale = (float)(1.0 / (1.0 - d->p));
+    return TNR_OK;
+}
 
 #define TNR_CHECK_LAUNCH(name)                                                   \
     do {                                                                         \

@@ -28,6 +28,7 @@ struct NTArgs {
     int gm;                    // rasterisation group height
     int nt;                    // 1: streaming (non-temporal) accesses for once-touched epilogue operands
     int tile0;                 // first logical tile of this launch (0: one launch per GEMM)
+    TnrDrop drop;              // TNR_EPI_DROPOUT: the site whose mask multiplies (acc + bias [-> activation]) before the residual add
     int probe;                 // timing probes (tools only, TNR_PROBES builds): 1 no staging loads in the K loop, 2 no
                                // fragment reads / MFMAs, 4 every row tile reads A rows 0-255 (A resident in L2), 8 no epilogue
 };
@@ -156,6 +157,12 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& g, f32x4 (&acc)[4][4],
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)uu[i][j][r]);
                 }
+            }
+            if (flags & TNR_EPI_DROPOUT) {      // BertSelfOutput / BertOutput: dense -> dropout -> + residual
+                float dm[4];
+                tnr_drop4(g.drop, (uint64_t)m * g.N + n, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= dm[r];
             }
             if (flags & TNR_EPI_RES) {
 #pragma unroll
@@ -668,6 +675,12 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= lut_eval<true>(lut, (float)xx[pass][it][e]);
             }
+            if (flags & TNR_EPI_DROPOUT) {
+                float dm[8];
+                tnr_drop8(g.drop, ((uint64_t)m * g.N + n) >> 3, dm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dm[e];
+            }
             if (flags & TNR_EPI_RES) {
                 bf16x8 r = pre_res ? xx[pass][it] : *(const bf16x8*)(g.res + (int64_t)m * g.ldres + n);
 #pragma unroll
@@ -890,6 +903,15 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
                 v[8 + e] *= lut_eval<true>(lut, (float)y1[e]);
             }
         }
+        if (flags & TNR_EPI_DROPOUT) {
+            float dm[8];
+            tnr_drop8(g.drop, ((uint64_t)m * g.N + n0) >> 3, dm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= dm[e];
+            tnr_drop8(g.drop, ((uint64_t)m * g.N + n0 + 32) >> 3, dm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[8 + e] *= dm[e];
+        }
         if (flags & TNR_EPI_RES) {
             bf16x8 r0 = y0, r1 = y1;
             if (pre_aux) {                 // both operands in one launch: the residual is read where it is used
@@ -1103,8 +1125,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // K tile 0 (and 1's A0) of this tile were issued by the prologue -- before the previous tile's epilogue for all but
     // the first tile, so only that epilogue's own (younger) operations may still be in flight here
-    // (a counted wait that leaves the previous epilogue's stores in flight measured the same as waiting for everything,
-    // tools/gemm_ab.py, so the simple form stays: it assumes nothing about the completion order of loads and stores)
+    // (a counted wait that leaves the previous epilogue's stores in flight -- vmcnt(number of stores the epilogue issued
+    // after the prologue), full tiles only -- measured the same as waiting for everything both with the first epilogue and with
+    // this one (tools/gemm_ab.py, +-0.3 % per shape), so the simple form stays)
     if (first && nk > 1 && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);
     first = false;
     __builtin_amdgcn_s_barrier();                        // K tile 0 is in LDS
@@ -1305,6 +1328,181 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
     }
 }
 
+// wgrad v4 "ping-pong": the v3 tile and stage image (256 n x 256 k output, 64-row m steps, [dY0 | dY1 | X0 | X1] sub-tiles of
+// [64 m][256 B]) under the schedule of gemm_nt_pp_kernel: the two wave groups (wn = 0 / 1: the two 128-column halves of dY)
+// run one interval apart, each alternating a LOAD segment (transposed fragment reads + the LDS-DMA of a later sub-tile)
+// with an MFMA segment of 16 MFMAs; dY0 / dY1 are private to a group (the A0 / A1 of the NT kernel), X0 / X1 shared (its
+// B0 / B1).  m step = 4 phases: L0 reads dY blocks 0-3 + X blocks 0-1, L1 X blocks 2-3, L2 dY blocks 4-7, L3 nothing;
+// M0..M3 = quadrants (y lo, x lo), (y lo, x hi), (y hi, x hi), (y hi, x lo).  DMA runs 5 sub-tiles ahead in the order
+// dY0 dY1 X0 X1: phase p of step t issues dY1(t+1), X0(t+1), X1(t+1), dY0(t+2); phase 3 waits vmcnt(2).  Hazards as there.
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w >> 2, wk = w & 3;          // wave tile: 128 n x 64 k
+    const int nbk = g.K >> 8;
+    const int ntile = (g.N >> 8) * nbk;
+    const int wg = xcd_remap(blockIdx.x, ntile * g.splits);
+    const int z = wg / ntile, tile = wg - z * ntile;
+    const int bn = tile / nbk, bk = tile - bn * nbk;
+    const int mt0 = z * g.tiles_per_split;
+    int mt1 = mt0 + g.tiles_per_split;
+    if (mt1 > g.Mt) mt1 = g.Mt;
+    const int nk = mt1 - mt0;
+
+    // staging: every wave issues pieces 2w, 2w+1 (4 rows x 256 B each) of every sub-tile
+    const bf16* srcY[2][2];
+    const bf16* srcX[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (2 * w + q) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ tn_swz(row);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            srcY[h][q] = g.dY + (int64_t)(mt0 * 64 + row) * g.lddy + bn * 256 + h * 128 + chunk * 8;
+            srcX[h][q] = g.X + (int64_t)(mt0 * 64 + row) * g.ldx + bk * 256 + h * 128 + chunk * 8;
+        }
+    }
+    const int64_t stepY = 64 * g.lddy, stepX = 64 * g.ldx;
+    auto issue = [&](int which, int t) {        // sub-tile `which` (0 dY0, 1 dY1, 2 X0, 3 X1) of m step t into stage t & 1
+        char* base = smem + (t & 1) * STAGE3 + which * TILE_BYTES + (2 * w) * 1024;
+        if (which < 2) {
+            glds16(srcY[which][0] + t * stepY, base);
+            glds16(srcY[which][1] + t * stepY, base + 1024);
+        } else {
+            glds16(srcX[which - 2][0] + t * stepX, base);
+            glds16(srcX[which - 2][1] + t * stepX, base + 1024);
+        }
+    };
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    int roff[2][2], rswz[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = 32 * s + 8 * g16 + q4 + 4 * h;
+            roff[s][h] = row * 256 + (p4 & 1) * 8;
+            rswz[s][h] = tn_swz(row);
+        }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        issue(0, 0);
+        issue(1, 0);
+        issue(2, 0);
+        issue(3, 0);
+        if (nk > 1) issue(0, 1);
+        bf16x8 yf[4][2], xf[4][2];
+        auto read_y = [&](const char* sy, int blk, bf16x8 (&dst)[2]) {      // dY block blk (16 n) of the group's 128, both m halves
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int cy = 2 * blk + (p4 >> 1);
+                bf16x4 y0 = ds_read_tr16(sy + roff[s][0] + ((cy ^ rswz[s][0]) << 4));
+                bf16x4 y1 = ds_read_tr16(sy + roff[s][1] + ((cy ^ rswz[s][1]) << 4));
+                dst[s] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+        auto read_x = [&](const char* sx, int blk, bf16x8 (&dst)[2]) {      // X block blk (16 k) of the wave's 64
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int cx = 2 * ((wk & 1) * 4 + blk) + (p4 >> 1);
+                bf16x4 x0 = ds_read_tr16(sx + roff[s][0] + ((cx ^ rswz[s][0]) << 4));
+                bf16x4 x1 = ds_read_tr16(sx + roff[s][1] + ((cx ^ rswz[s][1]) << 4));
+                dst[s] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+#define TNR_PP_SEG_END()                                            \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    __builtin_amdgcn_s_barrier();                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    __builtin_amdgcn_s_setprio(1)
+#define TNR_PP_MFMA_END()                                           \
+    __builtin_amdgcn_s_setprio(0);                                  \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    __builtin_amdgcn_s_barrier();                                   \
+    __builtin_amdgcn_sched_barrier(0)
+        if (nk > 1) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();                    // m step 0 is in LDS
+        if (wn == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one interval behind
+        for (int t = 0; t < nk; ++t) {
+            const char* sy = smem + (t & 1) * STAGE3 + wn * TILE_BYTES;
+            const char* sx = smem + (t & 1) * STAGE3 + (2 + (wk >> 1)) * TILE_BYTES;
+            const bool more = t + 1 < nk;
+            // ---- phase 0: dY blocks 0-3, X blocks 0-1 ; quadrant (lo, lo)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) read_x(sx, j, xf[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) read_y(sy, i, yf[i]);
+            if (more) issue(1, t + 1);
+            TNR_PP_SEG_END();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = TNR_MFMA_16x16x32(xf[j][s], yf[i][s], acc[i][j], 0, 0, 0);
+            TNR_PP_MFMA_END();
+            // ---- phase 1: X blocks 2-3 ; quadrant (lo, hi)
+#pragma unroll
+            for (int j = 2; j < 4; ++j) read_x(sx, j, xf[j]);
+            if (more) issue(2, t + 1);
+            TNR_PP_SEG_END();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 2; j < 4; ++j) acc[i][j] = TNR_MFMA_16x16x32(xf[j][s], yf[i][s], acc[i][j], 0, 0, 0);
+            TNR_PP_MFMA_END();
+            // ---- phase 2: dY blocks 4-7 ; quadrant (hi, hi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) read_y(sy, 4 + i, yf[i]);
+            if (more) issue(3, t + 1);
+            TNR_PP_SEG_END();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 2; j < 4; ++j) acc[4 + i][j] = TNR_MFMA_16x16x32(xf[j][s], yf[i][s], acc[4 + i][j], 0, 0, 0);
+            TNR_PP_MFMA_END();
+            // ---- phase 3: no reads ; quadrant (hi, lo) ; m step t+1 must have landed before the next phase 0
+            if (t + 2 < nk) {
+                issue(0, t + 2);
+                TNR_WAIT_VMCNT(2);
+            } else {
+                TNR_WAIT_VMCNT(0);
+            }
+            TNR_PP_SEG_END();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[4 + i][j] = TNR_MFMA_16x16x32(xf[j][s], yf[i][s], acc[4 + i][j], 0, 0, 0);
+            TNR_PP_MFMA_END();
+        }
+#undef TNR_PP_SEG_END
+#undef TNR_PP_MFMA_END
+        if (wn == 0) __builtin_amdgcn_s_barrier();       // all waves execute the same number of barriers
+    }
+    float* slab = g.ws + (int64_t)z * g.N * g.K;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int n = bn * 256 + wn * 128 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k = bk * 256 + wk * 64 + j * 16 + (lane >> 4) * 4;
+            *(f32x4*)(slab + (int64_t)n * g.K + k) = acc[i][j];
+        }
+    }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t NK, int K, float* out,
                                    int64_t ldo, int accumulate, float out_scale) {
     int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1320,9 +1518,10 @@ __global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int
 
 }  // namespace
 
-extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
-                              void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream);
+                              void* aux, int64_t ldaux, int flags, float* colsum_part, const tnr_dropout_t* drop,
+                              void* stream);
 
 extern "C" int TNR_NAME(tnr_gemm_nt)(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                            int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
@@ -1370,7 +1569,7 @@ static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
 #define TNR_PP_FLAG_SETS(X)                                                                                              \
     X(0) X(TNR_EPI_BIAS) X(TNR_EPI_RES) X(TNR_EPI_BIAS | TNR_EPI_RES) X(TNR_EPI_BIAS | TNR_EPI_GELU)                      \
     X(TNR_EPI_BIAS | TNR_EPI_GELU | TNR_EPI_AUXOUT) X(TNR_EPI_MULDGELU) X(TNR_EPI_MULDGELU | TNR_EPI_COLSUM)              \
-    X(TNR_EPI_BIAS | TNR_EPI_TANH | TNR_EPI_OUTF32)
+    X(TNR_EPI_BIAS | TNR_EPI_TANH | TNR_EPI_OUTF32) X(TNR_EPI_BIAS | TNR_EPI_RES | TNR_EPI_DROPOUT)
 template <int MI>
 static void pp_launch(const NTArgs& g, unsigned grid, hipStream_t st) {
     switch (g.flags) {
@@ -1389,6 +1588,17 @@ extern "C" int TNR_NAME(tnr_gemm_nt_route)(int64_t M, int64_t N, int64_t K, int 
 extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                               void* aux, int64_t ldaux, int flags, float* colsum_part, void* stream) {
+    return TNR_NAME(tnr_gemm_nt_do)(A, lda, B, ldb, C, ldc, M, N, K, bias, res, ldres, aux, ldaux, flags, colsum_part, nullptr, stream);
+}
+
+extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                              int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
+                              void* aux, int64_t ldaux, int flags, float* colsum_part, const tnr_dropout_t* drop,
+                              void* stream) {
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_gemm_nt")) return rc;
+    TNR_CHECK_ARG(!(flags & TNR_EPI_DROPOUT), "tnr_gemm_nt: TNR_EPI_DROPOUT is set by passing a dropout site");
+    if (dd.thresh) flags |= TNR_EPI_DROPOUT;
     TNR_CHECK_ARG(A && B && C, "tnr_gemm_nt: null operand");
     TNR_CHECK_ARG(M >= 1 && N >= 128 && (N % 128) == 0 && K >= 64 && (K % 64) == 0,
                   "tnr_gemm_nt: need N%%128==0, K%%64==0 (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
@@ -1405,7 +1615,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_ex)(const void* A, int64_t lda, const void* 
                   "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
     const TnrGemmOpts& o = *tnr_gemm_opts();
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0, 0};
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0, dd, 0};
 #ifdef TNR_PROBES
     g.probe = o.probe;
 #endif
@@ -1468,6 +1678,7 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_tn256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         attr_set = true;
     }
     if (ver == 1 || (N % 256) != 0) {
@@ -1478,7 +1689,8 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
         hipLaunchKernelGGL(gemm_tn256_kernel, grid, dim3(512), RING2, (hipStream_t)stream, g);
     } else {
         dim3 grid((unsigned)((N / 256) * (K / 256) * splits));
-        hipLaunchKernelGGL(gemm_tn256x256_kernel, grid, dim3(512), RING3, (hipStream_t)stream, g);
+        if (tnr_gemm_opts()->tnpp) hipLaunchKernelGGL(gemm_tn_pp_kernel, grid, dim3(512), RING3, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(gemm_tn256x256_kernel, grid, dim3(512), RING3, (hipStream_t)stream, g);
     }
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad");
     int64_t NK = N * K;

@@ -2,6 +2,7 @@
 // One wave per row of H = 256*V elements; each lane owns V runs of 4 consecutive elements
 // (8-byte bf16 / 16-byte fp32 accesses, 512 B coalesced per wave-instruction).
 #include "common.h"
+#include "dropout.h"
 
 namespace {
 
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const TokT* __restrict__ 
                                                        const float* __restrict__ word, const float* __restrict__ pos,
                                                        const float* __restrict__ type0, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, bf16* __restrict__ out,
-                                                       float* __restrict__ mask_add) {
+                                                       float* __restrict__ mask_add, TnrDrop drop) {
     const int H = 256 * V;
     const int lane = threadIdx.x & 63;
     int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -64,9 +65,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const TokT* __restrict__ 
         int c = v * 256 + lane * 4;
         f32x4 gm = *(const f32x4*)(gamma + c);
         f32x4 bt = *(const f32x4*)(beta + c);
+        float dm[4] = {1.f, 1.f, 1.f, 1.f};
+        if (drop.thresh) tnr_drop4(drop, (uint64_t)t * H + c, dm);          // tnlrv3/modeling.py:177
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)((x[v][r] - mean) * rstd * gm[r] + bt[r]);
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)(((x[v][r] - mean) * rstd * gm[r] + bt[r]) * dm[r]);
         *(bf16x4*)(out + t * H + c) = o;
     }
 }
@@ -112,7 +115,7 @@ template <int V>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ xin,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      bf16* __restrict__ dx, float* __restrict__ part, int64_t M,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, bf16* __restrict__ dxm, TnrDrop drop) {
     const int H = 256 * V;
     __shared__ float red[4][3][256 * V];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -154,10 +157,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             bf16x4 o;
+            if (dxm) {
+                // the Linear in front of this LayerNorm was followed by dropout (BertSelfOutput / BertOutput): its output
+                // gradient is dx * mask / (1 - p) (second output, what its wgrad / dgrad / bias gradient consume), the
+                // residual branch takes dx itself
+                float dm[4];
+                tnr_drop4(drop, (uint64_t)m * H + v * 256 + lane * 4, dm);
+                bf16x4 om;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[r] = (bf16)(rstd * (g[v][r] - s1 - xh[v][r] * s2));
-                dxs[v][r] += (float)o[r];          // the rounded value the wgrad kernels will see
+                for (int r = 0; r < 4; ++r) {
+                    const float t = rstd * (g[v][r] - s1 - xh[v][r] * s2);
+                    o[r] = (bf16)t;
+                    om[r] = (bf16)(t * dm[r]);
+                    dxs[v][r] += (float)om[r];
+                }
+                *(bf16x4*)(dxm + m * H + v * 256 + lane * 4) = om;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = (bf16)(rstd * (g[v][r] - s1 - xh[v][r] * s2));
+                    dxs[v][r] += (float)o[r];          // the rounded value the wgrad kernels will see
+                }
             }
             *(bf16x4*)(dx + m * H + v * 256 + lane * 4) = o;
         }
@@ -258,21 +278,23 @@ __global__ __launch_bounds__(256) void reduce_rows_narrow_kernel(const float* __
     if (threadIdx.x == 0) out[i] = accumulate ? out[i] + red[0] : red[0];
 }
 
-// column sums: block (256 threads) owns 256 columns? no: 64 columns x 4 row-lanes, CS_ROWS rows per block
+// column sums: block = 256 columns (64 threads x 4) x 4 row lanes over `rows_per_block` rows: 512 for tall inputs, 64 for short
+// ones (a 1792-row input on 512-row blocks was 4 workgroups walking 128 dependent loads each: 33 us for 1.8 MB)
 constexpr int CS_ROWS = 512;
+static inline int cs_rows(int64_t M) { return M >= 32768 ? CS_ROWS : 64; }
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Xb, int64_t ldx, int64_t M, int64_t N,
-                                                     float* __restrict__ partb, int64_t sX, int64_t sPart) {
+                                                     float* __restrict__ partb, int64_t sX, int64_t sPart, int rows_per_block) {
     const T* X = Xb + (int64_t)blockIdx.z * sX;
     float* part = partb + (int64_t)blockIdx.z * sPart;
     // thread handles 4 consecutive columns; 64 threads across 256 columns, 4 row groups
     __shared__ float red[4][256];
     const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int64_t c = (int64_t)blockIdx.x * 256 + cg * 4;
-    const int64_t m0 = (int64_t)blockIdx.y * CS_ROWS;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per_block;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < N) {
-        int64_t mend = m0 + CS_ROWS < M ? m0 + CS_ROWS : M;
+        int64_t mend = m0 + rows_per_block < M ? m0 + rows_per_block : M;
         for (int64_t m = m0 + rg; m < mend; m += 4) {
             if constexpr (sizeof(T) == 2) {
                 bf16x4 a = *(const bf16x4*)((const bf16*)X + m * ldx + c);
@@ -370,25 +392,35 @@ extern "C" int tnr_relpos_table(const float* weight, int A, int L, float* table,
 
 #endif
 
-extern "C" int TNR_NAME(tnr_embed_ln_fwd)(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
-                                const float* type0, const float* gamma, const float* beta, float eps, void* out,
-                                float* mask_add, void* stream) {
+extern "C" int TNR_NAME(tnr_embed_ln_fwd_do)(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
+                                   const float* type0, const float* gamma, const float* beta, float eps, void* out,
+                                   float* mask_add, const tnr_dropout_t* drop, void* stream) {
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_embed_ln_fwd")) return rc;
     TNR_CHECK_ARG(tok && word && pos && type0 && gamma && beta && out && mask_add, "tnr_embed_ln_fwd: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 512 && n_seq >= 1, "tnr_embed_ln_fwd: need 1<=L<=512");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_embed_ln_fwd: H must be 256/512/768/1024");
     int64_t n_tok = n_seq * L;
     dim3 grid((unsigned)((n_tok + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int64_t>), grid, blk, 0, st, tok, (const int32_t*)nullptr, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add)
+#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int64_t>), grid, blk, 0, st, tok, (const int32_t*)nullptr, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add, dd)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     TNR_CHECK_LAUNCH("tnr_embed_ln_fwd");
     return TNR_OK;
 }
+extern "C" int TNR_NAME(tnr_embed_ln_fwd)(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
+                                const float* type0, const float* gamma, const float* beta, float eps, void* out,
+                                float* mask_add, void* stream) {
+    return TNR_NAME(tnr_embed_ln_fwd_do)(tok, n_seq, L, H, word, pos, type0, gamma, beta, eps, out, mask_add, nullptr, stream);
+}
 
-extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed)(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
-                                        const float* word, const float* pos, const float* type0, const float* gamma,
-                                        const float* beta, float eps, void* out, float* mask_add, void* stream) {
+extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed_do)(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
+                                           const float* word, const float* pos, const float* type0, const float* gamma,
+                                           const float* beta, float eps, void* out, float* mask_add,
+                                           const tnr_dropout_t* drop, void* stream) {
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_embed_ln_fwd_indexed")) return rc;
     TNR_CHECK_ARG(news_combined && nidx && word && pos && type0 && gamma && beta && out && mask_add,
                   "tnr_embed_ln_fwd_indexed: null pointer");
     TNR_CHECK_ARG(L >= 1 && L <= 512 && n_seq >= 1, "tnr_embed_ln_fwd_indexed: need 1<=L<=512");
@@ -396,11 +428,17 @@ extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed)(const int32_t* news_combined, 
     int64_t n_tok = n_seq * L;
     dim3 grid((unsigned)((n_tok + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int32_t>), grid, blk, 0, st, news_combined, nidx, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add)
+#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int32_t>), grid, blk, 0, st, news_combined, nidx, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add, dd)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     TNR_CHECK_LAUNCH("tnr_embed_ln_fwd_indexed");
     return TNR_OK;
+}
+extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed)(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
+                                        const float* word, const float* pos, const float* type0, const float* gamma,
+                                        const float* beta, float eps, void* out, float* mask_add, void* stream) {
+    return TNR_NAME(tnr_embed_ln_fwd_indexed_do)(news_combined, nidx, n_seq, L, H, word, pos, type0, gamma, beta, eps, out, mask_add,
+                                                 nullptr, stream);
 }
 
 extern "C" int TNR_NAME(tnr_pool_fwd)(const void* y, float* nv, int64_t n_seq, int L, int H, int mean, void* stream) {
@@ -471,6 +509,55 @@ extern "C" int tnr_reduce_rows(const float* part, int64_t rows, int64_t stride, 
 #endif
 
 #ifndef TNR_BUILD_F16
+// the multipliers of a dropout site as fp32 (tests: statistics, bit equality with oracle/dropout_oracle.py)
+__global__ void dropout_mask_rows_kernel(float* __restrict__ out, int64_t n4, TnrDrop d) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float m[4];
+    tnr_drop4(d, (uint64_t)i * 4, m);
+    *(f32x4*)(out + i * 4) = (f32x4){m[0], m[1], m[2], m[3]};
+}
+// attention probabilities (pairs, L, L): thread = (pair, query, key group of 4) through the row accessor, or (cols != 0) the
+// column accessor (four queries of one key), so both device paths are pinned
+__global__ void dropout_mask_probs_kernel(float* __restrict__ out, int64_t pairs, int L, int Lr, int cols, TnrDrop d) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = Lr / 4;
+    if (i >= pairs * Lr * g) return;
+    const int64_t pair = i / ((int64_t)Lr * g);
+    const int rem = (int)(i - pair * Lr * g);
+    float m[4];
+    if (!cols) {
+        const int q = rem / g, k0 = (rem - q * g) * 4;
+        tnr_drop_prob_row(d, (uint64_t)pair, g, q, k0, m);
+        for (int e = 0; e < 4; ++e)
+            if (q < L && k0 + e < L) out[(pair * L + q) * L + k0 + e] = m[e];
+    } else {
+        const int k = rem / g, q0 = (rem - k * g) * 4;
+        tnr_drop_prob_col(d, (uint64_t)pair, g, q0, k, m);
+        for (int e = 0; e < 4; ++e)
+            if (k < L && q0 + e < L) out[(pair * L + q0 + e) * L + k] = m[e];
+    }
+}
+extern "C" int tnr_dropout_mask(const tnr_dropout_t* drop, int64_t rows, int64_t cols, float* out, void* stream) {
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_dropout_mask")) return rc;
+    TNR_CHECK_ARG(out && rows >= 1 && cols >= 4 && (cols % 4) == 0, "tnr_dropout_mask: need cols %% 4 == 0");
+    int64_t n4 = rows * cols / 4;
+    hipLaunchKernelGGL(dropout_mask_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n4, dd);
+    TNR_CHECK_LAUNCH("tnr_dropout_mask");
+    return TNR_OK;
+}
+extern "C" int tnr_dropout_mask_probs(const tnr_dropout_t* drop, int64_t pairs, int L, int by_columns, float* out, void* stream) {
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_dropout_mask_probs")) return rc;
+    TNR_CHECK_ARG(out && pairs >= 1 && L >= 1 && L <= 512, "tnr_dropout_mask_probs: bad argument");
+    const int Lr = (L + 31) / 32 * 32;
+    int64_t n = pairs * Lr * (Lr / 4);
+    hipLaunchKernelGGL(dropout_mask_probs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, pairs, L,
+                       Lr, by_columns, dd);
+    TNR_CHECK_LAUNCH("tnr_dropout_mask_probs");
+    return TNR_OK;
+}
 __global__ void scale_inplace_kernel(float* __restrict__ x, int64_t n, float s) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] *= s;
@@ -489,9 +576,13 @@ extern "C" int tnr_reduce_multi(const int64_t* desc, int n_blocks, void* stream)
 }
 #endif
 
-extern "C" int TNR_NAME(tnr_ln_bwd)(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
-                          float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream) {
+extern "C" int TNR_NAME(tnr_ln_bwd_do)(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                             float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* dxm,
+                             const tnr_dropout_t* drop, void* stream) {
     // dgamma == dbeta == dxsum == NULL with part != NULL: partials only, the caller reduces them (tnr_reduce_multi)
+    TnrDrop dd;
+    if (int rc = tnr_make_drop(drop, &dd, "tnr_ln_bwd")) return rc;
+    TNR_CHECK_ARG(dxm || !dd.thresh, "tnr_ln_bwd: an active dropout site needs the masked second output");
     TNR_CHECK_ARG(dy && x && stats && gamma && dx && M >= 1, "tnr_ln_bwd: null pointer");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_ln_bwd: H must be 256/512/768/1024");
     TNR_CHECK_ARG(!(dgamma || dbeta || dxsum) || part, "tnr_ln_bwd: part workspace required for dgamma/dbeta/dxsum");
@@ -500,7 +591,7 @@ extern "C" int TNR_NAME(tnr_ln_bwd)(const void* dy, const void* x, const float* 
     dim3 grid((unsigned)nblk), blk(256);
     hipStream_t st = (hipStream_t)stream;
     float* p = part;
-#define LAUNCH(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, blk, 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, p, M, rows)
+#define LAUNCH(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, blk, 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, p, M, rows, (bf16*)dxm, dd)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     TNR_CHECK_LAUNCH("tnr_ln_bwd");
@@ -513,22 +604,32 @@ extern "C" int TNR_NAME(tnr_ln_bwd)(const void* dy, const void* x, const float* 
     if (dxsum) { int rc = tnr_reduce_rows(part + 2 * H, nblk, 3 * H, H, dxsum, 0, stream); if (rc) return rc; }
     return TNR_OK;
 }
+extern "C" int TNR_NAME(tnr_ln_bwd)(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                          float* dgamma, float* dbeta, float* dxsum, float* part, int64_t M, int H, void* stream) {
+    return TNR_NAME(tnr_ln_bwd_do)(dy, x, stats, gamma, dx, dgamma, dbeta, dxsum, part, M, H, nullptr, nullptr, stream);
+}
 
 #ifndef TNR_BUILD_F16
-extern "C" int64_t tnr_colsum_part_elems(int64_t M, int64_t N) { return ((M + CS_ROWS - 1) / CS_ROWS) * N; }
+// monotone in M: a workspace sized for M rows serves every call with fewer rows
+extern "C" int64_t tnr_colsum_part_elems(int64_t M, int64_t N) {
+    int64_t tall = (M + CS_ROWS - 1) / CS_ROWS, small = (M + 63) / 64;
+    if (small > 32768 / 64) small = 32768 / 64;
+    return (tall > small ? tall : small) * N;
+}
 #endif
 
 extern "C" int TNR_NAME(tnr_colsum_batched)(const void* X, int64_t ldx, int64_t sX, int dtype, int64_t M, int64_t N, int batch,
                                   float* out, float* part, int accumulate, void* stream) {
     TNR_CHECK_ARG(X && out && part && M >= 1 && N >= 4 && (N % 4) == 0 && (ldx % 4) == 0 && batch >= 1, "tnr_colsum: bad argument");
     TNR_CHECK_ARG(dtype == TNR_BF16 || dtype == TNR_F16 || dtype == TNR_F32, "tnr_colsum: dtype");
-    int64_t nby = (M + CS_ROWS - 1) / CS_ROWS;
+    const int rpb = cs_rows(M);
+    int64_t nby = (M + rpb - 1) / rpb;
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)nby, (unsigned)batch), blk(256);
     // partials laid out (nby, batch, N) so that ONE row reduction yields out (batch, N)
     if (dtype != TNR_F32)      // the 16-bit type of this build
-        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, blk, 0, (hipStream_t)stream, (const bf16*)X, ldx, M, N, part, sX, N);
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, blk, 0, (hipStream_t)stream, (const bf16*)X, ldx, M, N, part, sX, N, rpb);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)X, ldx, M, N, part, sX, N);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)X, ldx, M, N, part, sX, N, rpb);
     TNR_CHECK_LAUNCH("tnr_colsum");
     return tnr_reduce_rows(part, nby, (int64_t)batch * N, (int64_t)batch * N, out, accumulate, stream);
 }

@@ -216,6 +216,8 @@ class Engine:
                       "grads", "lo", "sh", "sh_a1", "sh_a1T", "b_a1", "desc_all", "desc_train"):
                 setattr(self, k, getattr(share, k))
         self.max_batch = max_batch
+        self.drop = None             # set_dropout(): train-mode dropout of the stage-0 / stage-1 notebooks
+        self.drop_calls = 0
         self._alloc_workspace(max_batch)
         self.comm = None             # set by dist.attach()
 
@@ -331,6 +333,29 @@ class Engine:
     def state_dict(self):
         return {k: v.detach().clone() for k, v in self.params.items()}
 
+    # ------------------------------------------------------------------ dropout (train mode of the notebooks)
+    def set_dropout(self, p_hidden, p_attn, seed, pass_id=0):
+        """hidden_dropout_prob / attention_probs_dropout_prob of the UniLM config (tnlrv3/config/*.json:2,4), live in the
+        notebooks because they call .train() (Post-train_KD.ipynb cell 19:6): embeddings (tnlrv3/modeling.py:177), attention
+        probabilities (:224), BertSelfOutput / BertOutput (:287, :306).  run.py never calls .train(), so its path has none.
+        Counter-based masks (csrc/dropout.h): every encode() is one numbered forward call = 2 * count + pass_id (two engines that
+        share parameters -- titles and bodies -- take different pass_ids); backward regenerates the masks from that number.
+        p = 0 for both turns dropout off (bit-identical to never having called this)."""
+        if (p_hidden or 0.0) <= 0.0 and (p_attn or 0.0) <= 0.0:
+            self.drop = None
+            return
+        self.drop = dict(p_hidden=float(p_hidden or 0.0), p_attn=float(p_attn or 0.0), seed=int(seed), pass_id=int(pass_id))
+        if not hasattr(self, "dyprem"):
+            z = lambda *s_: torch.zeros(s_, device=self.dev, dtype=self.tdt)
+            self.dyprem, self.dh1prem = z(self.Mp, self.cfg.H), z(self.Mp, self.cfg.H)
+
+    def _dsite(self, kind, layer):
+        """tnr_dropout_t of one site of the CURRENT forward call (None when dropout is off for that kind)."""
+        d = self.drop_cur
+        if d is None:
+            return None
+        return T.Dropout.site_of(d["p_attn"] if kind == T.DROP_PROB else d["p_hidden"], d["seed"], kind, layer, d["call"])
+
     # ------------------------------------------------------------------ bf16 weight copies
     def _build_shadows(self):
         cfg, dev, bf = self.cfg, self.dev, self.tdt
@@ -411,6 +436,8 @@ class Engine:
         self.nv, self.alpha, self.den = f(N, H), f(N, Lr), f(N)
         Rt = N + B
         self.Rt = Rt
+        if hasattr(self, "dyprem"):
+            self.dyprem, self.dh1prem = z(Mp, H), z(Mp, H)
         self.S = f(Rt, D)                 # student rows: [B*U history | B*C candidate | B user]
         self.dS = f(Rt, D)
         self.Sv, self.dSv = f(N, D), f(N, D)      # vectors / gradients per DISTINCT news of the step (dedup.py)
@@ -475,10 +502,14 @@ class Engine:
         return splits, T.query("tnr_gemm_tn_ws_elems", N, K, splits)
 
     # ------------------------------------------------------------------ kernel wrappers
-    def _gemm(self, a, w, c, M, bias=None, res=None, aux=None, flags=0, colsum=None):
+    def _gemm(self, a, w, c, M, bias=None, res=None, aux=None, flags=0, colsum=None, drop=None):
         N, K = w.shape
-        self._c("tnr_gemm_nt_ex", a, a.stride(0), w, w.stride(0), c, c.stride(0), M, N, K, bias, res,
-               res.stride(0) if res is not None else 0, aux, aux.stride(0) if aux is not None else 0, flags, colsum)
+        args = (a, a.stride(0), w, w.stride(0), c, c.stride(0), M, N, K, bias, res,
+                res.stride(0) if res is not None else 0, aux, aux.stride(0) if aux is not None else 0, flags, colsum)
+        if drop is None:
+            self._c("tnr_gemm_nt_ex", *args)
+        else:
+            self._c("tnr_gemm_nt_do", *args, drop)
 
     def _wgrad(self, dy, x, dw, M, acc=0):
         N, K = dw.shape
@@ -510,13 +541,13 @@ class Engine:
         for s0 in range(0, n, cap):
             cnt = min(cap, n - s0)
             idx = torch.arange(s0, s0 + cnt, device=self.dev, dtype=torch.int32)
-            x = self.encode(news_combined, cnt, nidx=idx, stop_at=self.lo)
+            x = self.encode(news_combined, cnt, nidx=idx, stop_at=self.lo, train=False)
             fx[s0:s0 + cnt].copy_(x[:cnt * L].view(cnt, L * H))
             fm[s0:s0 + cnt].copy_(self.mask_add[:cnt])
         self.fcache = (fx.view(torch.float32), fm, news_combined.data_ptr(), n)
         return True
 
-    def encode(self, tok, n_seq, nidx=None, out=None, stop_at=None):
+    def encode(self, tok, n_seq, nidx=None, out=None, stop_at=None, train=True):
         """NewsEncoder.forward model_bert.py:119-137 -> news vectors S[:n_seq] (fp32).
         tok (n_seq, 2L) int64 on device, or (nidx given) tok = resident news_combined (n+1, 2L) int32 and
         nidx (n_seq,) int32 news indices.  stop_at = l: return the hidden states entering layer l instead."""
@@ -526,7 +557,12 @@ class Engine:
         g = self.p
         if self._rel_stale:
             self.refresh_rel()
-        fc = getattr(self, "fcache", None)
+        self.drop_cur = None
+        if self.drop is not None and train:
+            self.drop_cur = dict(self.drop, call=2 * self.drop_calls + self.drop["pass_id"])
+            self.drop_calls += 1
+        ds = self._dsite
+        fc = getattr(self, "fcache", None) if self.drop_cur is None else None      # a cached prefix has no fresh masks
         first = 0
         if fc is not None and nidx is not None and stop_at is None and tok.data_ptr() == fc[2]:
             # frozen prefix from the per-news cache (build_frozen_cache): two row gathers replace embedding + lo layers
@@ -537,10 +573,12 @@ class Engine:
             emb = (g(BERT + "embeddings.word_embeddings.weight"), g(BERT + "embeddings.position_embeddings.weight"),
                    g(BERT + "embeddings.token_type_embeddings.weight"), g(BERT + "embeddings.LayerNorm.weight"),
                    g(BERT + "embeddings.LayerNorm.bias"), cfg.ln_eps, self.x0, self.mask_add)
+            de = ds(T.DROP_EMB, 0)
             if nidx is None:
-                self._c("tnr_embed_ln_fwd", tok, n_seq, L, H, *emb)
+                self._c("tnr_embed_ln_fwd_do", tok, n_seq, L, H, *emb, de) if de else self._c("tnr_embed_ln_fwd", tok, n_seq, L, H, *emb)
             else:
-                self._c("tnr_embed_ln_fwd_indexed", tok, nidx, n_seq, L, H, *emb)
+                self._c("tnr_embed_ln_fwd_indexed_do", tok, nidx, n_seq, L, H, *emb, de) if de else \
+                    self._c("tnr_embed_ln_fwd_indexed", tok, nidx, n_seq, L, H, *emb)
         x = self.x0
         self.x_in = {}
         for l in range(first, cfg.n_layers):
@@ -554,16 +592,22 @@ class Engine:
             bqkv = self._view(names[3], 3 * H, (3 * H,))
             self.x_in[l] = x
             self._gemm(x, sh["qkv"], a["qkv"], M, bias=bqkv, flags=T.EPI_BIAS)
+            dp = ds(T.DROP_PROB, l)
             if L <= 32:
-                self._c("tnr_attn_l32_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A)
+                if dp:
+                    self._c("tnr_attn_l32_fwd_do", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A, dp)
+                else:
+                    self._c("tnr_attn_l32_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A)
             else:
-                self._c("tnr_attn_long_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], a["lse"] if kept else self.lse,
-                        n_seq, L, cfg.A)
-            self._gemm(a["ctx"], sh["o"], a["h1pre"], M, bias=g(names[7]), res=x, flags=T.EPI_BIAS | T.EPI_RES)
+                largs = (a["qkv"], self.mask_add, self.rel, a["ctx"], a["lse"] if kept else self.lse, n_seq, L, cfg.A)
+                self._c("tnr_attn_long_fwd_do", *largs, dp) if dp else self._c("tnr_attn_long_fwd", *largs)
+            self._gemm(a["ctx"], sh["o"], a["h1pre"], M, bias=g(names[7]), res=x, flags=T.EPI_BIAS | T.EPI_RES,
+                       drop=ds(T.DROP_ATTN_OUT, l))
             self._c("tnr_ln_fwd", a["h1pre"], g(names[8]), g(names[9]), cfg.ln_eps, a["h1"], a["st1"], M, H)
             fl = T.EPI_BIAS | T.EPI_GELU | (T.EPI_AUXOUT if kept else 0)
             self._gemm(a["h1"], sh["w1"], a["g"], M, bias=g(names[11]), aux=a["u"] if kept else None, flags=fl)
-            self._gemm(a["g"], sh["w2"], a["ypre"], M, bias=g(names[13]), res=a["h1"], flags=T.EPI_BIAS | T.EPI_RES)
+            self._gemm(a["g"], sh["w2"], a["ypre"], M, bias=g(names[13]), res=a["h1"], flags=T.EPI_BIAS | T.EPI_RES,
+                       drop=ds(T.DROP_FFN_OUT, l))
             self._c("tnr_ln_fwd", a["ypre"], g(names[14]), g(names[15]), cfg.ln_eps, y, a["st2"], M, H)
             x = y
         self.y_last = x
@@ -590,7 +634,7 @@ class Engine:
         for s0 in range(0, n, cap):
             cnt = min(cap, n - s0)
             idx = torch.arange(s0, s0 + cnt, device=self.dev, dtype=torch.int32)
-            out[s0:s0 + cnt].copy_(self.encode(news_combined, cnt, nidx=idx))
+            out[s0:s0 + cnt].copy_(self.encode(news_combined, cnt, nidx=idx, train=False))
         return out
 
     @torch.no_grad()
@@ -820,6 +864,7 @@ class Engine:
         L, D, H, I = cfg.L, cfg.D, cfg.H, cfg.I
         M = N * L
         g, gr = self.p, self.grads
+        ds = self._dsite                   # sites of the forward call this backward belongs to (self.drop_cur)
         gi = self.ginv                     # parameter gradients below the pooling backward: 1 / loss scale on the way out
         rb = self.red.setdefault(("heads", acc, N), _ReduceBatch(self.dev))
         # dense + pooling of the news encoder
@@ -860,14 +905,19 @@ class Engine:
             rb = self.red.setdefault((l, acc, N, "ffn"), _ReduceBatch(self.dev)) if tr else None
             rba = self.red.setdefault((l, acc, N, "att"), _ReduceBatch(self.dev)) if tr else None
             nblk = T.query("tnr_ln_bwd_blocks", M)
-            self._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None,
-                    self.ln_part if tr else None, M, H)
+            # with dropout behind the two output Linears the LayerNorm backward has two outputs: dx for the residual branch and
+            # dx * mask / (1 - p) = the Linear's output gradient (its weight gradient, dgrad and -- through the partials -- bias)
+            dF, dO, dPb = ds(T.DROP_FFN_OUT, l), ds(T.DROP_ATTN_OUT, l), ds(T.DROP_PROB, l)
+            dypre_lin = self.dyprem if dF else self.dypre
+            dh1pre_lin = self.dh1prem if dO else self.dh1pre
+            lnargs = (dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None, self.ln_part if tr else None, M, H)
+            self._c("tnr_ln_bwd_do", *lnargs, self.dyprem, dF) if dF else self._c("tnr_ln_bwd", *lnargs)
             if tr:
                 rb.add(self.ln_part, nblk, 3 * H, 2 * H, self._view(names[14], 2 * H, (2 * H,), grad=True), acc, gi)   # [dgamma | dbeta]
                 rb.add(self.ln_part[2 * H:], nblk, 3 * H, H, gr[names[13]], acc, gi)                                 # output.dense.bias
-                self._wgrad(self.dypre, a["g"], gr[names[12]], M, acc)
+                self._wgrad(dypre_lin, a["g"], gr[names[12]], M, acc)
             fused_cs = tr and M > 128            # the column-sum epilogue needs more than one 128-row strip
-            self._gemm(self.dypre, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if fused_cs else 0),
+            self._gemm(dypre_lin, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if fused_cs else 0),
                        colsum=self.gcs_part if fused_cs else None)
             if tr:
                 if fused_cs:
@@ -881,21 +931,21 @@ class Engine:
                     after_bucket(bucket)
                     bucket += 1
             self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
-            self._c("tnr_ln_bwd", self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, None, None, None,
-                    self.ln_part1 if tr else None, M, H)
+            lnargs = (self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, None, None, None, self.ln_part1 if tr else None, M, H)
+            self._c("tnr_ln_bwd_do", *lnargs, self.dh1prem, dO) if dO else self._c("tnr_ln_bwd", *lnargs)
             if tr:
                 rba.add(self.ln_part1, nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True), acc, gi)
                 rba.add(self.ln_part1[2 * H:], nblk, 3 * H, H, gr[names[7]], acc, gi)                               # attention.output.dense.bias
-                self._wgrad(self.dh1pre, a["ctx"], gr[names[6]], M, acc)
-            self._gemm(self.dh1pre, sh["oT"], self.dctx, M)
+                self._wgrad(dh1pre_lin, a["ctx"], gr[names[6]], M, acc)
+            self._gemm(dh1pre_lin, sh["oT"], self.dctx, M)
             if L <= 32:
-                self._c("tnr_attn_l32_bwd", a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv,
-                        self.qkvb_part if tr else None, N, L, cfg.A)
+                bargs = (a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv, self.qkvb_part if tr else None, N, L, cfg.A)
+                self._c("tnr_attn_l32_bwd_do", *bargs, dPb) if dPb else self._c("tnr_attn_l32_bwd", *bargs)
                 if tr:
                     rba.add(self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
             else:
-                self._c("tnr_attn_long_bwd", a["qkv"], self.mask_add, self.rel, a["ctx"], self.dctx, a["lse"], self.delta,
-                        self.dqkv, N, L, cfg.A)
+                bargs = (a["qkv"], self.mask_add, self.rel, a["ctx"], self.dctx, a["lse"], self.delta, self.dqkv, N, L, cfg.A)
+                self._c("tnr_attn_long_bwd_do", *bargs, dPb) if dPb else self._c("tnr_attn_long_bwd", *bargs)
                 if tr:
                     self._c("tnr_colsum", self.dqkv, 3 * H, T.BF16, M, 3 * H, self.cs_tmp2[:3 * H], self.cs_part, 0)
                     rba.add(self.cs_tmp2, 1, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)

@@ -60,6 +60,10 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--enable_hvd", type=b, default=True, help="data-parallel when launched by torch.distributed.run")
     p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
+    p.add_argument("--hidden_dropout_prob", type=float, default=None,
+                   help="train-mode dropout (the notebooks call .train(): cell 19:6 / cell 16:6); default = the value in --config_name "
+                        "(tnlrv3/config/*.json:4, 0.1), 0 turns it off")
+    p.add_argument("--attention_probs_dropout_prob", type=float, default=None, help="same for the attention probabilities (config json:2)")
     p.add_argument("--allow_random_init", type=b, default=False, help="train from the construction-time initialisation when --model_name does not exist")
     p.add_argument("--synthetic", type=b, default=False, help="hash-initialised weights + synthetic corpus / teacher tables")
     p.add_argument("--synthetic_docs", type=int, default=20000)
@@ -166,6 +170,13 @@ def train(args):
     eng = Stage1Engine(n_layers=args.num_hidden_layers, trainable_layers=[l for l in args.bert_trainable_layer if l < args.num_hidden_layers],
                        num_teachers=args.num_teachers, npratio=args.npratio, title_len=args.max_title_len,
                        body_len=args.max_body_len, device=dev, batch=args.batch_size, dtype=args.dtype, **_model_dims(args))
+    from model_bert import read_model_config
+    mcfg = read_model_config(args.config_name, args.synthetic)
+    p_h = mcfg.get("hidden_dropout_prob", 0.1) if args.hidden_dropout_prob is None else args.hidden_dropout_prob
+    p_a = mcfg.get("attention_probs_dropout_prob", 0.1) if args.attention_probs_dropout_prob is None else args.attention_probs_dropout_prob
+    if args.mode == "train":
+        eng.set_dropout(p_h, p_a, seed=args.seed * 1000003 + rank)       # every rank draws its own masks, like per-process torch RNGs
+        logging.info("[%d] train-mode dropout: hidden %.3g, attention probabilities %.3g", rank, p_h, p_a)
     if args.synthetic:
         eng.load_state_dict({k: torch.from_numpy(hashinit.init_tensor(1234, k, tuple(s))) for k, s in eng.shapes.items()})
     else:

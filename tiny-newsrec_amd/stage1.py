@@ -16,8 +16,9 @@ tnr_score_bwd already use in stage 2 with the body vector in the "user" slot.
 
 Trainable set = the notebook's (cell 17): heads + transform matrices + encoder layers 2 and 3 of the frozen UniLM
 (`trainable_layers`); optimiser = its plain Adam with two rates (cell 18: 1e-6 for bert_model, 1e-5 for the rest) via
-step(lr, lr_bert, amsgrad=False).  Not covered: the notebook runs the encoder in train() mode, i.e. with the
-UniLM config's dropout (0.1) active; this path has no dropout.
+step(lr, lr_bert, amsgrad=False).  The notebook trains under .train() (cell 19:6), i.e. with the UniLM config's dropout
+(hidden 0.1, attention probabilities 0.1) live in the encoder: set_dropout() turns the same four sites on (counter-based masks,
+csrc/dropout.h; the title and the body pass draw independent masks, as two passes through nn.Dropout do).
 """
 import torch
 
@@ -37,6 +38,11 @@ class Stage1Engine:
         self.title = Engine(self.cfg_t, device, max_batch=batch, dtype=dtype)
         self.body = Engine(self.cfg_b, device, max_batch=batch, dtype=dtype, share=self.title)
         self.dev = self.title.dev
+
+    def set_dropout(self, p_hidden, p_attn, seed):
+        """Train-mode dropout of both encoder passes (tnlrv3/config/*.json:2,4 under Post-train_KD.ipynb cell 19:6)."""
+        self.title.set_dropout(p_hidden, p_attn, seed, pass_id=0)
+        self.body.set_dropout(p_hidden, p_attn, seed, pass_id=1)
 
     # parameters / optimiser state are the title engine's
     def load_state_dict(self, sd):

@@ -15,6 +15,22 @@ EPI_BIAS, EPI_GELU, EPI_TANH, EPI_RES, EPI_MULDGELU, EPI_OUTF32, EPI_AUXOUT, EPI
 _c = ctypes
 _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 
+DROP_EMB, DROP_PROB, DROP_ATTN_OUT, DROP_FFN_OUT = 0, 1, 2, 3
+
+
+class Dropout(_c.Structure):
+    """tnr_dropout_t (include/tnr_hip.h): one dropout site of one forward pass; pass None for "no dropout"."""
+    _fields_ = [("seed", _c.c_uint64), ("site", _c.c_uint32), ("call", _c.c_uint32), ("p", _c.c_double)]
+
+    @classmethod
+    def site_of(cls, p, seed, kind, layer, call):
+        if p is None or p <= 0.0:
+            return None
+        return cls(int(seed) & 0xFFFFFFFFFFFFFFFF, int(kind) | (int(layer) << 8), int(call) & 0xFFFFFFFF, float(p))
+
+
+_D = _c.POINTER(Dropout)
+
 # name -> argument types (return type int unless listed in _RET)
 _SIG = {
     "tnr_version": [],
@@ -60,6 +76,8 @@ _SIG = {
     "tnr_kd_embed_loss": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "tnr_reduce_rows": [_P, _L, _L, _L, _P, _I, _P],
     "tnr_reduce_multi": [_P, _I, _P],
+    "tnr_dropout_mask": [_D, _L, _L, _P, _P],
+    "tnr_dropout_mask_probs": [_D, _L, _I, _I, _P, _P],
     "tnr_scale_inplace": [_P, _L, _F, _P],
     "tnr_amsgrad_step": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "tnr_refresh_shadows": [_P, _I, _L, _P, _P],
@@ -71,6 +89,13 @@ TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gem
          "tnr_gemm_tn_wgrad", "tnr_gemm_tn_wgrad_ex", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd",
          "tnr_colsum", "tnr_colsum_batched", "tnr_attpool_fwd", "tnr_attpool_bwd", "tnr_refresh_shadows",
          "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32", "tnr_pool_fwd", "tnr_pool_bwd"]
+# *_do: the same with a tnr_dropout_t* in front of the stream (tnr_ln_bwd_do: the masked second output first)
+for _n in ("tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd"):
+    _SIG[_n + "_do"] = _SIG[_n][:-1] + [_D, _P]
+    TYPED.append(_n + "_do")
+_SIG["tnr_gemm_nt_do"] = _SIG["tnr_gemm_nt_ex"][:-1] + [_D, _P]
+_SIG["tnr_ln_bwd_do"] = _SIG["tnr_ln_bwd"][:-1] + [_P, _D, _P]
+TYPED += ["tnr_gemm_nt_do", "tnr_ln_bwd_do"]
 for _n in TYPED:
     _SIG[_n + "_f16"] = _SIG[_n]
 _RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_gemm_tn_ws_elems_f16": _L, "tnr_gemm_colsum_rows_f16": _L, "tnr_gemm_colsum_rows": _L, "tnr_ln_bwd_part_elems": _L, "tnr_ln_bwd_blocks": _L, "tnr_colsum_part_elems": _L,
@@ -108,6 +133,12 @@ def _ptr(t):
     return t.data_ptr()
 
 
+def _conv(a):
+    if isinstance(a, Dropout):
+        return ctypes.byref(a)
+    return _ptr(a) if (isinstance(a, torch.Tensor) or a is None) else a
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -118,7 +149,7 @@ TIMED = {}
 
 
 def _work(name, conv):
-    if name in ("tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_nt_f16", "tnr_gemm_nt_ex_f16"):
+    if name.startswith("tnr_gemm_nt"):
         return 2.0 * conv[6] * conv[7] * conv[8]
     if name.startswith("tnr_gemm_tn_wgrad"):
         return 2.0 * conv[6] * conv[7] * conv[8]
@@ -128,7 +159,7 @@ def _work(name, conv):
 def call(name, *args):
     """Invoke an int-status entry point on torch's current stream (appended automatically)."""
     L = lib()
-    conv = [_ptr(a) if (isinstance(a, torch.Tensor) or a is None) else a for a in args]
+    conv = [_conv(a) for a in args]
     rec = TIMED.get(name)
     if rec is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
