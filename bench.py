@@ -194,8 +194,7 @@ def main():
         eng.forward_indexed(comb, hidx[s], mask[s], cidx[s], label[s], tables if a.teachers else None,
                             plans[i] if use_plan else None)
         eng.backward(after_bucket=gs.launch if use_dp else None)
-        gs.wait()
-        eng.step(lr=1e-4, grad_scale=gs.scale)
+        eng.step(lr=1e-4, grad_scale=gs.scale, sync=gs)      # per bucket: wait for its all-reduce, then its AMSGrad slice
 
     def timed_loop(eng, gs, use_plan, time_kernels=None):
         """W untimed warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks (seconds)."""
@@ -274,8 +273,8 @@ def main():
                 pm = json.load(open(pj))
                 if pm.get("lib_sha16") == lib_sha16() and pm.get("dtype") == a.dtype:
                     traffic = pm.get("hbm_bytes_per_launch")
-            names = {128: "gemm_nt_kernel(128x128)", 2128: "gemm_nt256_kernel(256x128)", 256: "gemm_nt256x256_kernel<8>",
-                     224: "gemm_nt256x256_kernel<7>(224 rows)"}
+            names = {128: "gemm_nt_kernel(128x128)", 2128: "gemm_nt256_kernel(256x128)", 256: "gemm_nt_pp_kernel<8,*>(256-row tiles)",
+                     224: "gemm_nt_pp_kernel<7,*>(224-row tiles)"}
             out["roofline"] = {"bound": "mfma",
                                "kernel": "NT GEMM family (%s MFMA 16x16x32, every forward / dgrad Linear incl. fused epilogues): %s"
                                          % (a.dtype, ", ".join(sorted({names.get(r, str(r)) for r in routes.values()}))),

@@ -179,7 +179,9 @@ int tnr_pool_bwd(const float* dnv, void* dy, int64_t n_seq, int L, int H, int me
 /* small fp32 GEMM on the f32 MFMA (exact fp32):  for z in [0,batch):
  *   C_z[m,n] = alpha * sum_k A_z(m,k) B_z(n,k) + bias_z[n] + beta * C_z[m,n]
  * A_z(m,k) = A[z*sA + m*a_rs + k*a_cs] (a_idx must be NULL), likewise B.  ksplit > 1 splits K over workgroups
- * into part (ksplit, batch, M, N) fp32 and sums them in fixed order (needs dense C, no bias/alpha; beta 0 or 1). */
+ * into part (ksplit, batch, M, N) fp32 (caller's workspace) and a second kernel sums the slices in fixed order and
+ * applies alpha / bias / beta: the fp32 MFMA issues one 32x32x2 block per 64 cycles, so a workgroup's time is
+ * K * 32 cycles whatever the tile count -- few-tile GEMMs with a long K are latency-sized unless K is split. */
 int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA, const int32_t* a_idx,
               const float* B, int64_t b_rs, int64_t b_cs, int64_t sB,
               float* C, int64_t ldc, int64_t sC, const float* bias, int64_t sBias,

@@ -136,7 +136,14 @@ def _sync_worker(rank, world, port, q):
     gs = dist.GradSync(flat, ranges, w)
     for b in range(3):
         gs.launch(b)
+    # per-bucket completion (Engine.step runs each bucket's optimiser slice behind its own all-reduce only): bucket 0 is
+    # final after wait_bucket(0) whatever the later ones are doing; waiting twice / for an unlaunched bucket is a no-op
+    assert sorted(gs.pending) == [0, 1, 2]
+    gs.wait_bucket(0)
+    assert torch.equal(flat[600:1000], torch.arange(600, 1000, dtype=torch.float32) * 3) and sorted(gs.pending) == [1, 2]
+    gs.wait_bucket(0)
     gs.wait()
+    assert not gs.pending
     p = torch.full((10,), float(r))
     dist.broadcast_flat([p])
     dist.barrier()

@@ -115,8 +115,12 @@ struct SgemmArgs {
     int ksplit, kchunk, batch;      // ksplit > 1: C = partials (ksplit, batch, M, N), no bias / beta
 };
 
+// One K step is 64 deep: 16 + 16 scalar loads per thread issued together (the next step's fly under this step's 32 MFMAs), so
+// a step costs about one memory latency OR its MFMA time (32 x 64 cycles), whichever is longer -- with 16-deep steps every
+// step paid a full latency for 8 MFMAs (44 us for the 1760 x 256 x 768 dense layer, 13 us for an M = 1 call).
+constexpr int SG_BK = 64;
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
-    __shared__ float As[64][17], Bs[64][17];
+    __shared__ float As[64][SG_BK + 1], Bs[64][SG_BK + 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     const int zb = blockIdx.z / g.ksplit, zk = blockIdx.z - zb * g.ksplit;
     const float* A = g.A + zb * g.sA;
@@ -130,32 +134,33 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool a_kfast = g.a_cs == 1, b_kfast = g.b_cs == 1;
-    int ra[4], ka[4], rb[4], kb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int idx = tid + 256 * q;
-        ra[q] = a_kfast ? idx >> 4 : idx & 63; ka[q] = a_kfast ? idx & 15 : idx >> 6;
-        rb[q] = b_kfast ? idx >> 4 : idx & 63; kb[q] = b_kfast ? idx & 15 : idx >> 6;
-    }
-    float av[4], bv[4];
+    constexpr int NQ = 64 * SG_BK / 256;         // elements per thread, operand and step
+    // k-fast operands: 64 consecutive threads read one row's 64 k values; otherwise 64 consecutive threads read 64 rows of one k
+    const int ra0 = a_kfast ? tid >> 6 : tid & 63, ka0 = a_kfast ? tid & 63 : tid >> 6;
+    const int rb0 = b_kfast ? tid >> 6 : tid & 63, kb0 = b_kfast ? tid & 63 : tid >> 6;
+    float av[NQ], bv[NQ];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            av[q] = (m0 + ra[q] < g.M && k0 + ka[q] < kend) ? A[(int64_t)(m0 + ra[q]) * g.a_rs + (int64_t)(k0 + ka[q]) * g.a_cs] : 0.f;
-            bv[q] = (n0 + rb[q] < g.N && k0 + kb[q] < kend) ? B[(int64_t)(n0 + rb[q]) * g.b_rs + (int64_t)(k0 + kb[q]) * g.b_cs] : 0.f;
+        for (int q = 0; q < NQ; ++q) {
+            const int ra = a_kfast ? ra0 + 4 * q : ra0, ka = a_kfast ? ka0 : ka0 + 4 * q;
+            const int rb = b_kfast ? rb0 + 4 * q : rb0, kb = b_kfast ? kb0 : kb0 + 4 * q;
+            av[q] = (m0 + ra < g.M && k0 + ka < kend) ? A[(int64_t)(m0 + ra) * g.a_rs + (int64_t)(k0 + ka) * g.a_cs] : 0.f;
+            bv[q] = (n0 + rb < g.N && k0 + kb < kend) ? B[(int64_t)(n0 + rb) * g.b_rs + (int64_t)(k0 + kb) * g.b_cs] : 0.f;
         }
     };
     fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    for (int k0 = kbeg; k0 < kend; k0 += SG_BK) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            As[ra[q]][ka[q]] = av[q];
-            Bs[rb[q]][kb[q]] = bv[q];
+        for (int q = 0; q < NQ; ++q) {
+            const int ra = a_kfast ? ra0 + 4 * q : ra0, ka = a_kfast ? ka0 : ka0 + 4 * q;
+            const int rb = b_kfast ? rb0 + 4 * q : rb0, kb = b_kfast ? kb0 : kb0 + 4 * q;
+            As[ra][ka] = av[q];
+            Bs[rb][kb] = bv[q];
         }
         __syncthreads();
-        if (k0 + 16 < kend) fetch(k0 + 16);          // next tile's global loads fly under the MFMAs
-#pragma unroll
-        for (int kk = 0; kk < 16; kk += 2) {
+        if (k0 + SG_BK < kend) fetch(k0 + SG_BK);    // next step's global loads fly under the MFMAs
+        const int kk_end = kend - k0 < SG_BK ? kend - k0 : SG_BK;
+        for (int kk = 0; kk < kk_end; kk += 2) {      // fixed order: an fp32 fma chain over k (zero padding beyond kend)
             float a = As[wm * 32 + (lane & 31)][kk + (lane >> 5)];
             float b = Bs[wn * 32 + (lane & 31)][kk + (lane >> 5)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -179,6 +184,24 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
             }
         }
     }
+}
+
+// split-K epilogue: C_z[m,n] = alpha * sum_s part[s][z][m][n] + bias_z[n] + beta * C_z[m,n], slices summed in order
+__global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ part, int ksplit, int batch, int M, int N,
+                                                           float* __restrict__ C, int64_t ldc, int64_t sC,
+                                                           const float* __restrict__ bias, int64_t sBias, float alpha, float beta) {
+    const int64_t per = (int64_t)M * N, total = per * batch;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float t = part[i];
+    for (int s = 1; s < ksplit; ++s) t += part[(int64_t)s * total + i];
+    const int z = (int)(i / per);
+    const int64_t r = i - (int64_t)z * per;
+    const int m = (int)(r / N), n = (int)(r - (int64_t)m * N);
+    float* c = C + (int64_t)z * sC + (int64_t)m * ldc + n;
+    float v = alpha * t + (bias ? bias[(int64_t)z * sBias + n] : 0.f);
+    if (beta != 0.f) v += beta * *c;
+    *c = v;
 }
 
 // rows of per-model tables gathered into a dense (n_model, n_idx, D) array
@@ -803,10 +826,8 @@ extern "C" int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA,
     if (ksplit < 1) ksplit = 1;
     int kchunk = (int)K;
     if (ksplit > 1) {
-        TNR_CHECK_ARG(part && bias == nullptr && alpha == 1.0f && (beta == 0.0f || beta == 1.0f) && ldc == N &&
-                          (batch == 1 || sC == M * N),
-                      "tnr_sgemm: split-K needs a partial buffer, dense C, no bias/alpha, beta 0 or 1");
-        kchunk = (int)(((K + ksplit - 1) / ksplit + 15) / 16 * 16);
+        TNR_CHECK_ARG(part != nullptr, "tnr_sgemm: split-K needs the partial buffer (ksplit * batch * M * N floats)");
+        kchunk = (int)(((K + ksplit - 1) / ksplit + 15) / 16 * 16);      // any multiple of 2 keeps the k pairs of the MFMA aligned
         ksplit = (int)((K + kchunk - 1) / kchunk);
     }
     SgemmArgs g{A, a_rs, a_cs, sA, B, b_rs, b_cs, sB, ksplit > 1 ? part : C, ldc, sC, bias, sBias, (int)M, (int)N, (int)K,
@@ -814,8 +835,12 @@ extern "C" int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA,
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(batch * ksplit));
     hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     TNR_CHECK_LAUNCH("tnr_sgemm");
-    if (ksplit > 1)
-        return tnr_reduce_rows(part, ksplit, (int64_t)batch * M * N, (int64_t)batch * M * N, C, beta == 1.0f, stream);
+    if (ksplit > 1) {
+        const int64_t total = (int64_t)batch * M * N;
+        hipLaunchKernelGGL(sgemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                           ksplit, batch, (int)M, (int)N, C, ldc, sC, bias, sBias, alpha, beta);
+        TNR_CHECK_LAUNCH("tnr_sgemm/reduce");
+    }
     return TNR_OK;
 }
 

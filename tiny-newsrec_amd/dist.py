@@ -3,7 +3,9 @@ replacing horovod (run.py:141-149, utils.py:43-60): flat parameter broadcast fro
 gradient AVERAGE (hvd.Average, Compression.none, fp32) done as a few large contiguous all-reduces
 (one per gradient bucket: heads first, then per trainable layer from the top its FFN block and its
 attention block, Engine.bucket_ranges) launched as soon as backward has produced the bucket, so they
-overlap the remaining backward GEMMs; the 1/world scale is folded into the AMSGrad kernel.  xGMI is point-to-point, so few large messages beat many small ones."""
+overlap the remaining backward GEMMs; the 1/world scale is folded into the AMSGrad kernel, which Engine.step runs bucket by
+bucket in the same order, each behind its own all-reduce only (wait_bucket), so the optimiser work of the early buckets hides
+under the last, exposed all-reduce.  xGMI is point-to-point, so few large messages beat many small ones."""
 import os
 
 import torch
@@ -33,7 +35,7 @@ class GradSync:
     def __init__(self, flat_g, ranges, world, force=False):
         self.flat_g, self.ranges, self.world = flat_g, list(ranges), world
         self.force = force and dist.is_initialized()      # exercise the collective path even with one rank
-        self.pending = []
+        self.pending = {}                                 # bucket -> outstanding work handle
         self.host_staged = dist.is_initialized() and dist.get_backend() == "gloo" and flat_g.is_cuda
 
     def launch(self, bucket):
@@ -45,12 +47,17 @@ class GradSync:
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
             self.flat_g[s:e].copy_(h)
             return
-        self.pending.append(dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        self.pending[bucket] = dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True)
+
+    def wait_bucket(self, bucket):
+        """Make the current stream wait for bucket's all-reduce (no-op when it was not launched asynchronously)."""
+        w = self.pending.pop(bucket, None)
+        if w is not None:
+            w.wait()
 
     def wait(self):
-        for w in self.pending:
-            w.wait()
-        self.pending = []
+        for b in list(self.pending):
+            self.wait_bucket(b)
 
     @property
     def scale(self):

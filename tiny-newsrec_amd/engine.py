@@ -489,7 +489,7 @@ class Engine:
         self.epad_buf = {1: f(1, cfg.Qu), T_: f(T_, cfg.Qu)}      # student / teachers (these run on different streams)
         self.epre_t = f(T_, B * cfg.U, cfg.Qu)
         self.KS = 8                                                        # split-K of the long-K small GEMMs
-        self.sg_part = f(self.KS * max(T_ * D * D, D * H, 3 * D * D))
+        self.sg_part = f(self.KS * max(T_ * D * D, D * H, 3 * D * D, T_ * Rt * D, N * max(H, D), T_ * B * cfg.U * max(cfg.Qu, 3 * D)))
         self.ws = f(max(self._wgrad_splits(n_, k_)[1] for n_, k_ in ((3 * H, H), (H, H), (I, H), (H, I), (QPAD, H))))
         self._rel_stale = True       # filled by the first encode() (no kernel launch at construction time)
 
@@ -519,8 +519,14 @@ class Engine:
     def _colsum(self, x, out, M, dtype=T.BF16):   # dtype BF16 = "the 16-bit type of the build"
         self._c("tnr_colsum", x, x.stride(0), dtype, M, x.shape[1], out, self.cs_part, 0)
 
-    def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, ksplit=1, alpha=1.0,
+    def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, ksplit=None, alpha=1.0,
                beta=0.0):
+        """ksplit None: K is split into slices of >= 128 (a workgroup's time on the fp32 MFMA is ~K * 32 cycles whatever the
+        tile count, and these GEMMs have few tiles).  The split depends on K ALONE, never on the row count: a news vector must
+        come out with the same bits whatever batch it is encoded in (in-batch de-duplication, frozen-layer cache)."""
+        if ksplit is None:
+            ksplit = max(1, min(K // 128, 8))
+            assert ksplit * batch * M * N <= self.sg_part.numel(), "fp32 GEMM workspace too small for its K split"
         T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, alpha, beta,
                ksplit, self.sg_part if ksplit > 1 else None)
 
@@ -976,11 +982,13 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ optimiser
-    def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, lr_bert=None, amsgrad=True, lr_news_head=None):
+    def step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, lr_bert=None, amsgrad=True, lr_news_head=None, sync=None):
         """torch.optim.Adam(amsgrad=True).step() (run.py:134,195) + refresh of the 16-bit weight copies.
         lr_bert / lr_news_head: learning rates of the encoder layers / of the news encoder's pooling + dense when they
         differ (PLM-NR/run.py:104-106: {'params': pretrained, 'lr': pretrain_lr}, {'params': rest, 'lr': lr}; the notebooks
-        use 1e-6 for bert_model and 1e-5 for the rest).  amsgrad=False: plain Adam (Post-train_KD.ipynb cell 18)."""
+        use 1e-6 for bert_model and 1e-5 for the rest).  amsgrad=False: plain Adam (Post-train_KD.ipynb cell 18).
+        sync: a dist.GradSync with all-reduces in flight -- the update then runs bucket by bucket in completion order, each
+        slice behind its own collective only (elementwise optimiser: the same bits as one launch over everything)."""
         self.step_count += 1
         head0 = self.off(PFX + ("attn.att_fc1.weight" if self.cfg.pooling == "att" else "dense.weight"))   # end of the BERT layers
         e = self.off(PFX + "dense.bias") + self.slot[PFX + "dense.bias"][2]
@@ -988,10 +996,27 @@ class Engine:
         lb = lr if lr_bert is None else lr_bert
         lh = lr if lr_news_head is None else lr_news_head
         ranges = [(0, self.n_train, lr)] if (lb == lr and lh == lr) else [(0, head0, lb), (head0, rest0, lh), (rest0, self.n_train, lr)]
-        for lo_, hi_, rate in ranges:
-            sc = grad_scale
+        def launch(lo_, hi_, rate):
             if hi_ > lo_:
                 T.call("tnr_amsgrad_step", self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_],
                        self.adam_v[lo_:hi_], self.adam_vmax[lo_:hi_] if amsgrad else None, hi_ - lo_, self.step_count, rate,
-                       beta1, beta2, eps, sc)
+                       beta1, beta2, eps, grad_scale)
+
+        if sync is not None and sync.pending:
+            done = []
+            for b, (s_, e_) in enumerate(sync.ranges):       # completion order of backward = launch order of the all-reduces
+                sync.wait_bucket(b)
+                for lo_, hi_, rate in ranges:
+                    launch(max(lo_, s_), min(hi_, e_), rate)
+                done.append((s_, e_))
+            pos = 0                                          # anything outside the buckets (alignment gaps: zero gradients)
+            for s_, e_ in sorted(done) + [(self.n_train, self.n_train)]:
+                for lo_, hi_, rate in ranges:
+                    launch(max(lo_, pos), min(hi_, s_), rate)
+                pos = max(pos, e_)
+        else:
+            if sync is not None:
+                sync.wait()
+            for lo_, hi_, rate in ranges:
+                launch(lo_, hi_, rate)
         self.refresh_shadows(all_layers=False)

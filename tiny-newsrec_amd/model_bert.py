@@ -252,9 +252,7 @@ class TnrAdam:
         pass                      # every backward overwrites the whole flat gradient buffer
 
     def step(self):
-        scale = 1.0
-        if self.grad_sync is not None:
-            self.grad_sync.wait()
-            scale = self.grad_sync.scale
+        scale = self.grad_sync.scale if self.grad_sync is not None else 1.0
+        # the engine waits for the gradient all-reduces bucket by bucket and updates each slice behind its own collective
         self.model.engine.step(self.lr, grad_scale=scale, lr_bert=self.pretrain_lr,
-                               lr_news_head=self.pretrain_lr if self.pretrained_heads else None)
+                               lr_news_head=self.pretrain_lr if self.pretrained_heads else None, sync=self.grad_sync)

@@ -221,11 +221,7 @@ def train(args):
             sums[3] += losses[2]
             sums[4] += utils.acc(label, score)
             eng.backward(after_bucket=sync.launch if sync else None)
-            scale = 1.0
-            if sync:
-                sync.wait()
-                scale = sync.scale
-            eng.step(args.lr, grad_scale=scale, lr_bert=args.pretrain_lr, amsgrad=False)
+            eng.step(args.lr, grad_scale=sync.scale if sync else 1.0, lr_bert=args.pretrain_lr, amsgrad=False, sync=sync)
             if args.stage == 0 and rank == 0 and cnt % args.save_steps == 0:          # cell 16: DP_12_layer_{cnt}.pt
                 os.makedirs(args.save_dir, exist_ok=True)
                 torch.save({"model_state_dict": _ckpt_state(eng, 0)},
