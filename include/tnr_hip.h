@@ -58,6 +58,11 @@ typedef struct tnr_dropout {
 int tnr_version(void);
 const char* tnr_last_error(void);
 
+/* Collectives are NOT part of this ABI: the gradient average of the reference (hvd.DistributedOptimizer / hvd.allreduce,
+ * Tiny-NewsRec/run.py:141-149, utils.py:43-60) is done by the caller with torch.distributed (backend "nccl" = RCCL) on the
+ * flat gradient buffer (tiny-newsrec_amd/dist.py); every entry point here is a single-device operation on the stream passed
+ * last and the library holds no communicator, device or stream state of its own. */
+
 /* ---- encoder --------------------------------------------------------------------------------- */
 
 /* relative_position_bucket + one_hot + Linear(32->A) hoisted to one (A,32,32) fp32 table

@@ -13,6 +13,15 @@
 namespace {
 
 constexpr float NEG_BIG = -3.0e38f;
+// LDS tiles are [32 rows][64 x 16-bit] with a row pitch of TS bytes and TB bytes per tile.  TS = 128 (dense rows) puts rows r
+// and r + 2 on the same banks: the 16-byte staging stores of 8 consecutive rows are 4-way conflicted and the two lane halves
+// of an accumulator dump (rows r, r + 4) collide; 144 = 36 dwords walks the 64 banks in steps of 4 dwords (attention
+// backward counted 15 M conflict cycles per launch, about as many as its busy cycles, with dense rows).
+#ifndef TNR_ATTN_TS
+#define TNR_ATTN_TS 144
+#endif
+constexpr int TS = TNR_ATTN_TS;
+constexpr int TB = 32 * TS;
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -28,8 +37,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int s, int ct, int l
     const int g16 = lane >> 4, hh = g16 >> 1, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     const int row = 16 * s + 4 * hh + q;
     const int col = ct * 32 + 16 * (g16 & 1) + 4 * p;
-    bf16x4 v0 = ds_read_tr16(tile + row * 128 + col * 2);
-    bf16x4 v1 = ds_read_tr16(tile + (row + 8) * 128 + col * 2);
+    bf16x4 v0 = ds_read_tr16(tile + row * TS + col * 2);
+    bf16x4 v1 = ds_read_tr16(tile + (row + 8) * TS + col * 2);
     return cat4(v0, v1);
 }
 
@@ -47,14 +56,14 @@ __device__ __forceinline__ void acc_to_lds(char* tile, const f32x16& x, int ct, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        *(bf16*)(tile + row * 128 + c * 2) = (bf16)(x[r] * scale);
+        *(bf16*)(tile + row * TS + c * 2) = (bf16)(x[r] * scale);
     }
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                        const float* __restrict__ rel, bf16* __restrict__ ctx,
                                                        int64_t n_pairs, int L, int A, TnrDrop drop) {
-    __shared__ __attribute__((aligned(16))) char lds[4][4096];
+    __shared__ __attribute__((aligned(16))) char lds[4][TB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t pair = (int64_t)blockIdx.x * 4 + w;
     const bool valid = pair < n_pairs;
@@ -66,31 +75,58 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const int row = lane & 31, h = lane >> 5;
     const int rowc = row < L ? row : L - 1;
     char* my = lds[w];
+#ifdef TNR_ATTN_STAMPS
+    unsigned long long tst[6];
+    tst[0] = __builtin_amdgcn_s_memtime();
+#define TNR_STAMP(i, dep) { asm volatile("" ::"v"(dep)); tst[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define TNR_STAMP(i, dep)
+#endif
 
+    // additive mask + rel-pos rows of this lane's query FIRST: they are needed right after the score MFMAs, and a load issued
+    // there is a second full trip through a saturated memory pipeline (stamps: 7.7 k of a wave's 45 k cycles, tools/attn_stamps.py)
+    f32x4 mkv[4], rlv[4];
+    {
+        const float* relp0 = rel + a * 1024 + row * 32;
+        const float* mp0 = mask_add + n * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mkv[g] = *(const f32x4*)(mp0 + 8 * g + 4 * h);
+            rlv[g] = *(const f32x4*)(relp0 + 8 * g + 4 * h);
+        }
+    }
     const bf16* qp = qkv + (n * L + rowc) * ldq + a * 64 + 8 * h;
     bf16x8 qf[4], kf[4];
+#ifdef TNR_ATTN_PROBE      // timing probe only (wrong results): Q / K loaded in full 128-byte lines, 8 rows per instruction
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        int idx = s * 64 + lane, r = idx >> 3, c = idx & 7;
+        int rc = r < L ? r : L - 1;
+        qf[s] = *(const bf16x8*)(qkv + (n * L + rc) * ldq + a * 64 + c * 8);
+        kf[s] = *(const bf16x8*)(qkv + (n * L + rc) * ldq + HD + a * 64 + c * 8);
+    }
+#else
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         qf[s] = *(const bf16x8*)(qp + 16 * s);
         kf[s] = *(const bf16x8*)(qp + HD + 16 * s);
     }
+#endif
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
         int rc = r < L ? r : L - 1;
-        *(bf16x8*)(my + r * 128 + c * 16) = *(const bf16x8*)(qkv + (n * L + rc) * ldq + 2 * HD + a * 64 + c * 8);
+        *(bf16x8*)(my + r * TS + c * 16) = *(const bf16x8*)(qkv + (n * L + rc) * ldq + 2 * HD + a * 64 + c * 8);
     }
     f32x16 st = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) st = TNR_MFMA_32x32x16(kf[s], qf[s], st, 0, 0, 0);
+    TNR_STAMP(1, st[0])
 
-    const float* relp = rel + a * 1024 + row * 32;
-    const float* mp = mask_add + n * 32;
     float mx = NEG_BIG;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        f32x4 mk = *(const f32x4*)(mp + 8 * g + 4 * h);
-        f32x4 rl = *(const f32x4*)(relp + 8 * g + 4 * h);
+        const f32x4 mk = mkv[g], rl = rlv[g];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = st[4 * g + e] * 0.125f + mk[e] + rl[e];
@@ -120,6 +156,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     }
     bf16x8 pf[2];
     acc_to_frags(st, pf);
+    TNR_STAMP(2, pf[0][0])
 
     f32x16 o[2];
 #pragma unroll
@@ -129,13 +166,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         for (int s = 0; s < 2; ++s)
             o[ct] = TNR_MFMA_32x32x16(pf[s], tr_frag(my, s, ct, lane), o[ct], 0, 0, 0);
     }
+    TNR_STAMP(3, o[1][0])
     acc_to_lds(my, o[0], 0, lane, 1.0f);
     acc_to_lds(my, o[1], 1, lane, 1.0f);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
-        if (valid && r < L) *(bf16x8*)(ctx + (n * L + r) * HD + a * 64 + c * 8) = *(const bf16x8*)(my + r * 128 + c * 16);
+        if (valid && r < L) *(bf16x8*)(ctx + (n * L + r) * HD + a * 64 + c * 8) = *(const bf16x8*)(my + r * TS + c * 16);
     }
+#ifdef TNR_ATTN_STAMPS
+    tst[4] = __builtin_amdgcn_s_memtime();
+    // stamps of one wave per block for the first 4096 blocks, written over the (probe-only) tail of rel: never read by anyone
+    if (lane == 0 && w == 0 && blockIdx.x < 4096) {
+        unsigned long long* o64 = (unsigned long long*)(rel + 12 * 1024) + blockIdx.x * 8;
+        for (int i = 0; i < 5; ++i) o64[i] = tst[i];
+    }
+#endif
 }
 
 // Backward: recompute P in both orientations, then dV = P^T dO, dS = P*(dP - rowsum(dP*P)),
@@ -145,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
                                                        bf16* __restrict__ dqkv, float* __restrict__ bias_part,
                                                        int64_t n_pairs, int L, int A, TnrDrop drop) {
     // per wave: K tile, dO tile, Q tile (each 4 KB, row-major [32][64]) + 256 B of row statistics
-    __shared__ __attribute__((aligned(16))) char lds[4][3 * 4096 + 256];
+    __shared__ __attribute__((aligned(16))) char lds[4][3 * TB + 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t pair = (int64_t)blockIdx.x * 4 + w;
     const bool valid = pair < n_pairs;
@@ -157,10 +203,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     const int row = lane & 31, h = lane >> 5;
     const int rowc = row < L ? row : L - 1;
     char* tK = lds[w];
-    char* tO = tK + 4096;
-    char* tQ = tK + 8192;
-    float* stat = (float*)(tK + 12288);          // [0..31] = max + log(sum) per query, [32..63] = D per query
+    char* tO = tK + TB;
+    char* tQ = tK + 2 * TB;
+    float* stat = (float*)(tK + 3 * TB);          // [0..31] = max + log(sum) per query, [32..63] = D per query
 
+    // mask / rel-pos values of both orientations first (see the forward kernel): the query-row view (lane = query) and the
+    // key-column view (lane = key; 16 strided rel values) are consumed right after the two MFMA groups below
+    f32x4 mkv[4], rlv[4];
+    float relcol[16];
+    const float* mp = mask_add + n * 32;
+    const float mkcol = mp[row];                   // this lane's key (natural orientation)
+    {
+        const float* relp0 = rel + a * 1024 + row * 32;
+        const float* relc0 = rel + a * 1024 + row;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mkv[g] = *(const f32x4*)(mp + 8 * g + 4 * h);
+            rlv[g] = *(const f32x4*)(relp0 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) relcol[4 * g + e] = relc0[(8 * g + 4 * h + e) * 32];
+        }
+    }
     const bf16* qp = qkv + (n * L + rowc) * ldq + a * 64 + 8 * h;
     const bf16* dop = dctx + (n * L + rowc) * HD + a * 64 + 8 * h;
     bf16x8 qf[4], kf[4], vf[4], df[4];
@@ -174,12 +237,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 8; ++e) df[s][e] = (bf16)0.f;
         }
-        int off = row * 128 + (16 * s + 8 * h) * 2;
+        int off = row * TS + (16 * s + 8 * h) * 2;
         *(bf16x8*)(tK + off) = kf[s];
         *(bf16x8*)(tO + off) = df[s];
         *(bf16x8*)(tQ + off) = qf[s];
     }
-    const float* mp = mask_add + n * 32;
 
     // ---- transposed orientation: lanes = queries, regs = keys
     f32x16 st = zero16(), dpt = zero16();
@@ -189,12 +251,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         dpt = TNR_MFMA_32x32x16(vf[s], df[s], dpt, 0, 0, 0);
     }
     {
-        const float* relp = rel + a * 1024 + row * 32;
         float mx = NEG_BIG;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 mk = *(const f32x4*)(mp + 8 * g + 4 * h);
-            f32x4 rl = *(const f32x4*)(relp + 8 * g + 4 * h);
+            const f32x4 mk = mkv[g], rl = rlv[g];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = st[4 * g + e] * 0.125f + mk[e] + rl[e];
@@ -253,8 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         dpn = TNR_MFMA_32x32x16(df[s], vf[s], dpn, 0, 0, 0);
     }
     {
-        const float mk = mp[row];                  // this lane's key
-        const float* relc = rel + a * 1024 + row;
+        const float mk = mkcol;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 lse = *(const f32x4*)(stat + 8 * g + 4 * h);
@@ -263,8 +322,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
             if (drop.thresh) tnr_drop_prob_col(drop, (uint64_t)pair, 8, 8 * g + 4 * h, row, dm);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int qi = 8 * g + 4 * h + e;
-                float p = __expf(sn[4 * g + e] * 0.125f + mk + relc[qi * 32] - lse[e]);
+                float p = __expf(sn[4 * g + e] * 0.125f + mk + relcol[4 * g + e] - lse[e]);
                 sn[4 * g + e] = p * dm[e];                                // what multiplied V in the forward pass
                 dpn[4 * g + e] = p * (dpn[4 * g + e] * dm[e] - dd[e]);    // dS
             }
@@ -319,9 +377,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
         if (valid && r < L) {
             bf16* dst = dqkv + (n * L + r) * ldq + a * 64 + c * 8;
-            *(bf16x8*)(dst) = *(const bf16x8*)(tK + r * 128 + c * 16);
-            *(bf16x8*)(dst + HD) = *(const bf16x8*)(tO + r * 128 + c * 16);
-            *(bf16x8*)(dst + 2 * HD) = *(const bf16x8*)(tQ + r * 128 + c * 16);
+            *(bf16x8*)(dst) = *(const bf16x8*)(tK + r * TS + c * 16);
+            *(bf16x8*)(dst + HD) = *(const bf16x8*)(tO + r * TS + c * 16);
+            *(bf16x8*)(dst + 2 * HD) = *(const bf16x8*)(tQ + r * TS + c * 16);
         }
     }
 }
@@ -340,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restri
                                                             const float* __restrict__ rel, bf16* __restrict__ ctx,
                                                             float* __restrict__ lse, int64_t n_items, int L, int Lr, int A,
                                                             TnrDrop drop) {
-    __shared__ __attribute__((aligned(16))) char lds[4][4096];
+    __shared__ __attribute__((aligned(16))) char lds[4][TB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t item = (int64_t)blockIdx.x * 4 + w;
     const bool valid = item < n_items;
@@ -375,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restri
             int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
             int rc = kt * 32 + r;
             rc = rc < L ? rc : L - 1;
-            *(bf16x8*)(my + r * 128 + c * 16) = *(const bf16x8*)(qbase + 2 * HD + (int64_t)rc * ldq + c * 8);
+            *(bf16x8*)(my + r * TS + c * 16) = *(const bf16x8*)(qbase + 2 * HD + (int64_t)rc * ldq + c * 8);
         }
         f32x16 st = zero16();
 #pragma unroll
@@ -431,13 +489,13 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int dd = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            *(bf16*)(my + row * 128 + dd * 2) = (bf16)(o[ct][r] * inv);
+            *(bf16*)(my + row * TS + dd * 2) = (bf16)(o[ct][r] * inv);
         }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
         int q = qt * 32 + r;
-        if (valid && q < L) *(bf16x8*)(ctx + (n * L + q) * HD + a * 64 + c * 8) = *(const bf16x8*)(my + r * 128 + c * 16);
+        if (valid && q < L) *(bf16x8*)(ctx + (n * L + q) * HD + a * 64 + c * 8) = *(const bf16x8*)(my + r * TS + c * 16);
     }
 }
 
@@ -447,7 +505,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
                                                                const bf16* __restrict__ dctx, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                                int64_t n_items, int L, int Lr, int A, TnrDrop drop) {
-    __shared__ __attribute__((aligned(16))) char lds[4][4096];
+    __shared__ __attribute__((aligned(16))) char lds[4][TB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t item = (int64_t)blockIdx.x * 4 + w;
     const bool valid = item < n_items;
@@ -495,7 +553,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
         for (int s = 0; s < 4; ++s) {
             kf[s] = ld_frag(qbase + HD, ldq, kjc, h, s);
             vf[s] = ld_frag(qbase + 2 * HD, ldq, kjc, h, s);
-            *(bf16x8*)(my + row * 128 + (16 * s + 8 * h) * 2) = kf[s];       // K tile for the dQ product
+            *(bf16x8*)(my + row * TS + (16 * s + 8 * h) * 2) = kf[s];       // K tile for the dQ product
         }
         f32x16 st = zero16(), dpt = zero16();
 #pragma unroll
@@ -528,7 +586,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
     for (int p = 0; p < 4; ++p) {
         int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
         int q = qt * 32 + r;
-        if (valid && q < L) *(bf16x8*)(dqkv + (n * L + q) * ldq + a * 64 + c * 8) = *(const bf16x8*)(my + r * 128 + c * 16);
+        if (valid && q < L) *(bf16x8*)(dqkv + (n * L + q) * ldq + a * 64 + c * 8) = *(const bf16x8*)(my + r * TS + c * 16);
     }
 }
 
@@ -538,7 +596,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const bf16* __re
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 bf16* __restrict__ dqkv, int64_t n_items, int L, int Lr, int A,
                                                                 TnrDrop drop) {
-    __shared__ __attribute__((aligned(16))) char lds[4][2 * 4096];
+    __shared__ __attribute__((aligned(16))) char lds[4][2 * TB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int64_t item = (int64_t)blockIdx.x * 4 + w;
     const bool valid = item < n_items;
@@ -552,7 +610,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const bf16* __re
     const int64_t ldq = 3 * HD;
     const int row = lane & 31, h = lane >> 5;
     char* tO = lds[w];
-    char* tQ = tO + 4096;
+    char* tQ = tO + TB;
     const int kj = kt * 32 + row;                          // this lane's key
     const int kjc = kj < L ? kj : L - 1;
     const bf16* qbase = qkv + (n * L) * ldq + a * 64;
@@ -580,7 +638,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const bf16* __re
 #pragma unroll
                 for (int e = 0; e < 8; ++e) df[s][e] = (bf16)0.f;
             }
-            int off = row * 128 + (16 * s + 8 * h) * 2;
+            int off = row * TS + (16 * s + 8 * h) * 2;
             *(bf16x8*)(tO + off) = df[s];
             *(bf16x8*)(tQ + off) = qf[s];
         }
@@ -625,8 +683,8 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const bf16* __re
         int j = kt * 32 + r;
         if (valid && j < L) {
             bf16* dst = dqkv + (n * L + j) * ldq + a * 64 + c * 8;
-            *(bf16x8*)(dst + HD) = *(const bf16x8*)(tO + r * 128 + c * 16);
-            *(bf16x8*)(dst + 2 * HD) = *(const bf16x8*)(tQ + r * 128 + c * 16);
+            *(bf16x8*)(dst + HD) = *(const bf16x8*)(tO + r * TS + c * 16);
+            *(bf16x8*)(dst + 2 * HD) = *(const bf16x8*)(tQ + r * TS + c * 16);
         }
     }
 }
