@@ -276,14 +276,17 @@ int tnr_reduce_multi(const int64_t* desc, int n_blocks, void* stream);
 /* x[i] *= s , i < n (fp32) */
 int tnr_scale_inplace(float* x, int64_t n, float s, void* stream);
 
-/* ---- dropout (train-mode) variants: the same operations with a dropout site, see tnr_dropout_t ------------------ */
+/* ---- dropout (train-mode) variants: the same operations with a dropout site, see tnr_dropout_t ------------------
+ * The two embedding variants (mask after the LayerNorm, tnlrv3/modeling.py:177) also take pos_ids: NULL = position i of token i
+ * (BERT / UniLM), else an int32 table laid out like the token table (n_seq or n+1 rows x L) naming each token's position row --
+ * RoBERTa's cumulative non-pad count + padding_idx (PLM-NR --model_type roberta, PLM-NR/utils.py:17-21). */
 int tnr_embed_ln_fwd_do(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
                         const float* type0, const float* gamma, const float* beta, float eps, void* out, float* mask_add,
-                        const tnr_dropout_t* drop, void* stream);                       /* mask after the LayerNorm, :177 */
+                        const tnr_dropout_t* drop, const int32_t* pos_ids, void* stream);
 int tnr_embed_ln_fwd_indexed_do(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
                                 const float* word, const float* pos, const float* type0, const float* gamma,
                                 const float* beta, float eps, void* out, float* mask_add, const tnr_dropout_t* drop,
-                                void* stream);
+                                const int32_t* pos_ids, void* stream);
 /* C = epilogue(A . B^T) with the site's mask on (acc + bias [-> activation]) BEFORE the residual add:
  * BertSelfOutput / BertOutput = dense -> dropout -> LayerNorm(x + residual).  Mask element index = m * N + n. */
 int tnr_gemm_nt_do(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
@@ -381,11 +384,11 @@ int tnr_cast_bf16_to_f32_f16(const void* src, float* dst, int64_t n, void* strea
 
 int tnr_embed_ln_fwd_do_f16(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
                         const float* type0, const float* gamma, const float* beta, float eps, void* out, float* mask_add,
-                        const tnr_dropout_t* drop, void* stream);
+                        const tnr_dropout_t* drop, const int32_t* pos_ids, void* stream);
 int tnr_embed_ln_fwd_indexed_do_f16(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
                                 const float* word, const float* pos, const float* type0, const float* gamma,
                                 const float* beta, float eps, void* out, float* mask_add, const tnr_dropout_t* drop,
-                                void* stream);
+                                const int32_t* pos_ids, void* stream);
 int tnr_gemm_nt_do_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                    void* aux, int64_t ldaux, int flags, float* colsum_part, const tnr_dropout_t* drop, void* stream);

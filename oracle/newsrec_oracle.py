@@ -110,12 +110,17 @@ def linear(x, w, b=None):
 # --------------------------------------------------------------------------- #
 # encoder  (tnlrv3/modeling.py:133-178, 181-342, 421-476)
 # --------------------------------------------------------------------------- #
-def embeddings_fwd(P, ids, eps=1e-12, drop=None):
+def embeddings_fwd(P, ids, eps=1e-12, drop=None, pos_pad=None):
     """BertEmbeddings.forward tnlrv3/modeling.py:153-178: word + pos[arange] + type[0] -> LN [-> dropout, train mode, :177].
     drop: oracle/dropout_oracle.Dropout (the masks of this forward call) or None."""
     L = ids.shape[1]
+    if pos_pad is None:
+        pe = P[BERT + "embeddings.position_embeddings.weight"][:L][None]
+    else:       # RoBERTa (PLM-NR --model_type roberta): transformers create_position_ids_from_input_ids
+        ne = (ids != pos_pad).astype(np.int64)
+        pe = P[BERT + "embeddings.position_embeddings.weight"][np.cumsum(ne, 1) * ne + pos_pad]
     e = (P[BERT + "embeddings.word_embeddings.weight"][ids]
-         + P[BERT + "embeddings.position_embeddings.weight"][:L][None]
+         + pe
          + P[BERT + "embeddings.token_type_embeddings.weight"][0][None, None])
     y, _ = layer_norm_fwd(e.astype(F32), P[BERT + "embeddings.LayerNorm.weight"],
                           P[BERT + "embeddings.LayerNorm.bias"], eps)
@@ -265,28 +270,28 @@ def split_tokens(x2l):
     return x2l[:, :L], x2l[:, L:]
 
 
-def encoder_fwd(P, ids, mask, n_layers, A, keep_from=None, drop=None):
+def encoder_fwd(P, ids, mask, n_layers, A, keep_from=None, drop=None, eps=1e-12, pos_pad=None):
     """TuringNLRv3Model.forward tnlrv3/modeling.py:421-476 -> last hidden state.
 
     keep_from: first layer whose cache is kept for backward (None = keep none)."""
     mask_add = ((1.0 - mask.astype(F32)) * F32(-10000.0)).astype(F32)
-    x = embeddings_fwd(P, ids, drop=drop)
+    x = embeddings_fwd(P, ids, eps=eps, drop=drop, pos_pad=pos_pad)
     rel = relpos_bias_table(P[BERT + "rel_pos_bias.weight"], ids.shape[1])
     caches = {}
     hidden = [x]
     for l in range(n_layers):
-        x, c = bert_layer_fwd(P, l, x, mask_add, rel, A, drop=drop)
+        x, c = bert_layer_fwd(P, l, x, mask_add, rel, A, eps=eps, drop=drop)
         hidden.append(x)
         if keep_from is not None and l >= keep_from:
             caches[l] = c
     return x, caches, hidden
 
 
-def news_encoder_fwd(P, x2l, n_layers, A, keep_from=None, pooling="att", drop=None):
+def news_encoder_fwd(P, x2l, n_layers, A, keep_from=None, pooling="att", drop=None, eps=1e-12, pos_pad=None):
     """NewsEncoder.forward model_bert.py:119-137: pooling 'att' (additive attention, no mask) | 'cls' (token 0) |
     anything else = mean over ALL L positions (padding included, :135), then dense."""
     ids, mask = split_tokens(x2l)
-    h, caches, hidden = encoder_fwd(P, ids, mask, n_layers, A, keep_from, drop=drop)
+    h, caches, hidden = encoder_fwd(P, ids, mask, n_layers, A, keep_from, drop=drop, eps=eps, pos_pad=pos_pad)
     pc = None
     if pooling == "att":
         nv, pc = att_pool_fwd(h, P[PFX + "attn.att_fc1.weight"], P[PFX + "attn.att_fc1.bias"],
@@ -434,7 +439,8 @@ def model_fwd(P, cfg, history, history_mask, candidate, label, teacher_hist, tea
     # ModelBert.forward :187-205 -- candidates and history share the encoder; rows are independent,
     # so one pass over the concatenation equals the reference's two calls.
     allx = np.concatenate([history.reshape(B * U, W2), candidate.reshape(B * C, W2)], 0)
-    vec, nc = news_encoder_fwd(P, allx, nl, A, keep_from, cfg.get("pooling", "att"))
+    vec, nc = news_encoder_fwd(P, allx, nl, A, keep_from, cfg.get("pooling", "att"), eps=cfg.get("ln_eps", 1e-12),
+                               pos_pad=cfg.get("pos_pad"))
     nrms = int(cfg.get("nrms_heads", 0))
     D = vec.shape[1]
     hist = vec[:B * U].reshape(B, U, D)

@@ -501,6 +501,71 @@ def golden_plmnr(out_name="plmnr_full_0.npz", seed=41, nl=2, trainable=(0, 1)):
     print(out_name, rec["loss0"], rec["loss1"])
 
 
+def golden_plmnr_hf(model_type, seed):
+    """PLM-NR's ModelBert with --model_type bert / roberta (PLM-NR/utils.py:17-21: transformers BertModel / RobertaModel as the
+    news encoder, PLM-NR/model_bert.py:109-118, hidden state of the last layer): 2 layers, both trainable (PLM-NR/run.py:119-124
+    unfreezes bert_model.encoder.layer[i]), one forward / backward.  Weights under the reference's own key names
+    ("student." + key for the shared hash generator); RoBERTa inputs use its padding id 1 and its config (type_vocab 1,
+    514 positions, layer_norm_eps 1e-5)."""
+    import transformers
+    R = ref_shim.load_reference("PLM-NR")
+    cls = {"bert": transformers.BertModel, "roberta": transformers.RobertaModel}[model_type]
+    keep = cls.__dict__.get("from_pretrained")
+    cls.from_pretrained = classmethod(lambda c, path, config=None, **kw: c(config).eval())
+    try:
+        nl, B = 2, 2
+        cfg_json = dict(ref_shim.BASE_CFG, num_hidden_layers=nl)
+        cfg_json.pop("rel_pos_bins"), cfg_json.pop("max_rel_pos")
+        if model_type == "roberta":
+            cfg_json.update(pad_token_id=1, type_vocab_size=1, max_position_embeddings=514, layer_norm_eps=1e-5, vocab_size=50265)
+        cfg_json["_attn_implementation"] = "eager"
+        a = ref_shim.make_args(config_name=ref_shim.write_config(cfg_json), num_hidden_layers=nl, batch_size=B, model_type=model_type)
+        model = R.model_bert.ModelBert(a)
+        sd = model.state_dict()
+        with torch.no_grad():
+            for k, v in sd.items():
+                v.copy_(torch.from_numpy(hashinit.init_tensor(seed, "student." + k, tuple(v.shape))))
+        for p_ in model.news_encoder.bert_model.parameters():
+            p_.requires_grad = False
+        for layer in model.news_encoder.bert_model.encoder.layer:
+            for p_ in layer.parameters():
+                p_.requires_grad = True
+        inp = make_inputs(seed, B, a.user_log_length, a.npratio + 1, a.num_words_title, 30522, 0, a.news_dim)
+        hist, mask, cand, label = [np.array(x) for x in inp[:4]]
+        if model_type == "roberta":          # its tokenizer pads with id 1 and never emits 0 / 1 inside a text
+            L = a.num_words_title
+            for x in (hist, cand):
+                ids, m = x[..., :L], x[..., L:]
+                x[..., :L] = np.where(m > 0, np.maximum(ids, 2), 1)
+        tt = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+        loss, score = model(tt(hist), tt(mask), tt(cand), tt(label))
+        loss.backward()
+        assert torch.isfinite(loss) and torch.isfinite(score).all()
+        rec = dict(in_hist=hist, in_mask=mask, in_cand=cand, in_label=label, loss0=loss.item(), score0=score.detach().numpy(),
+                   meta=np.array([seed, B, 0, a.user_log_length, a.npratio + 1, a.num_words_title, a.news_dim,
+                                  cfg_json["num_attention_heads"], nl]), trainable=np.array([0, 1]),
+                   keys=np.array(sorted(k for k in sd if not k.endswith("position_ids"))),
+                   dims=np.array([cfg_json["vocab_size"], cfg_json["max_position_embeddings"], cfg_json["type_vocab_size"]]),
+                   ln_eps=np.float64(cfg_json.get("layer_norm_eps", 1e-12)))
+        names = []
+        for n, p_ in model.named_parameters():
+            if p_.grad is None:
+                continue
+            g = p_.grad.numpy()
+            names.append(n)
+            rec["gnorm." + n] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            idx, val = grad_samples(seed, n, g)
+            rec["gidx." + n], rec["gval." + n] = idx, val
+        rec["grad_names"] = np.array(names)
+        np.savez_compressed(os.path.join(HERE, "plmnr_%s.npz" % model_type), **rec)
+        print("plmnr_%s.npz" % model_type, rec["loss0"], len(names), "gradients")
+    finally:
+        if keep is None:
+            del cls.from_pretrained
+        else:
+            cls.from_pretrained = keep
+
+
 def golden_stage0(R):
     """Domian-specific_Post-train.ipynb (stage 0: contrastive title/body matching of the teacher): its
     TitleBodySimModel (cells 10-11) executed as published -- CE over 1+K title scores per body, no teachers."""
@@ -590,6 +655,9 @@ def golden_interface():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "configs":       # only the round-2 additions (the other fixtures are unchanged)
         golden_configs(ref_shim.load_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == "hf":
+        golden_plmnr_hf("bert", 51)
+        golden_plmnr_hf("roberta", 52)
     elif len(sys.argv) > 1 and sys.argv[1] == "dropout":
         golden_stage1_dropout(ref_shim.load_reference())
     else:

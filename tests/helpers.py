@@ -71,6 +71,30 @@ def load_plmnr_case(name="plmnr_full_0.npz"):
     return z, P, cfg, (z["in_hist"], z["in_mask"], z["in_cand"], z["in_label"])
 
 
+def load_plmnr_hf_case(model_type):
+    """PLM-NR ModelBert with --model_type bert / roberta (transformers BertModel / RobertaModel as the encoder) ->
+    (z, P under the engine's / oracle's internal key names, cfg, inputs).  The reference's keys sit directly under bert_model.*;
+    internally the encoder keeps the UniLM layout with the rel-pos bias (and the unused classification head) at zero."""
+    z = np.load(os.path.join(GOLDEN, "plmnr_%s.npz" % model_type))
+    seed, B, T, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
+    vocab, max_pos, type_vocab = [int(x) for x in z["dims"]]
+    shapes = state_shapes(dict(FULL, vocab=vocab, max_pos=max_pos), nl, D, 0)
+    shapes["student.news_encoder.bert_model.bert.embeddings.token_type_embeddings.weight"] = (type_vocab, FULL["H"])
+    P = {}
+    for k, shp in shapes.items():
+        if k.endswith("rel_pos_bias.weight") or ".bert_model.classifier." in k:
+            P[k] = np.zeros(shp, np.float32)
+        else:
+            P[k] = hashinit.init_tensor(seed, k.replace(".bert_model.bert.", ".bert_model."), tuple(shp))
+    ref_keys = {"student." + str(k) for k in z["keys"]}
+    mine = {k.replace(".bert_model.bert.", ".bert_model.") for k in shapes if not (k.endswith("rel_pos_bias.weight") or ".bert_model.classifier." in k)}
+    assert ref_keys == mine, ref_keys ^ mine
+    cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]], user_log_mask=False, temperature=1.0, coef=1.0,
+               ln_eps=float(z["ln_eps"]), pos_pad=1 if model_type == "roberta" else None,
+               vocab=vocab, max_pos=max_pos, type_vocab=type_vocab)
+    return z, P, cfg, (z["in_hist"], z["in_mask"], z["in_cand"], z["in_label"])
+
+
 def load_stage0_case(name="stage0_full.npz"):
     """Stage-0 golden (Domian-specific_Post-train.ipynb TitleBodySimModel, 12 layers, CE only) -> (z, P, cfg, inputs)."""
     z = np.load(os.path.join(GOLDEN, name))

@@ -171,6 +171,63 @@ def test_plmnr_modelbert_surface():
     assert w["news_encoder.dense.weight"].grad is not None and w["news_encoder.bert_model.bert.embeddings.word_embeddings.weight"].grad is None
 
 
+@pytest.mark.parametrize("model_type", ["bert", "roberta"])
+def test_plmnr_modelbert_bert_and_roberta_model_types(model_type, tmp_path):
+    """PLM-NR --model_type bert / roberta (PLM-NR/utils.py:17-21): ModelBert with transformers BertModel / RobertaModel as the
+    encoder -- the module tree and state_dict keys of the reference (parameters directly under bert_model.*, no rel-pos bias, no
+    classification head), loss / scores of the reference's own run (fp16 bound), the freeze pattern of PLM-NR/run.py:119-124, and
+    the pretrained-checkpoint import of BertModel.from_pretrained (prefixed keys, old LayerNorm names)."""
+    import model_bert
+    from helpers import load_plmnr_hf_case
+    z, P, cfg, inp = load_plmnr_hf_case(model_type)
+    seed, B, _, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
+    cj = dict(hidden_size=768, num_attention_heads=A, intermediate_size=3072, vocab_size=cfg["vocab"], max_position_embeddings=cfg["max_pos"],
+              type_vocab_size=cfg["type_vocab"], layer_norm_eps=cfg["ln_eps"], pad_token_id=1 if model_type == "roberta" else 0)
+    (tmp_path / "config.json").write_text(json.dumps(cj))
+    args = types.SimpleNamespace(
+        config_name=str(tmp_path / "config.json"), model_name=None, model_type=model_type, pooling="att", model="NAML", num_hidden_layers=nl,
+        num_teacher_layers=12, num_student_layers=4, bert_trainable_layer=[0, 1], news_dim=D, news_query_vector_dim=200,
+        user_query_vector_dim=200, num_teachers=4, user_log_length=U, npratio=C - 1, num_words_title=L, user_log_mask=False,
+        temperature=1.0, coef=0.2, batch_size=B, num_attention_heads=16)
+    torch.cuda.set_device(0)
+    model = model_bert.ModelBert(args)
+    sd = model.state_dict()
+    assert sorted(sd) == sorted(str(k) for k in z["keys"])                 # the reference's keys, nothing else
+    assert float(model.engine.rel.abs().max()) == 0.0                       # no relative-position bias in these encoders
+    ref_sd = {k[len("student."):].replace(".bert_model.bert.", ".bert_model."): torch.from_numpy(v) for k, v in P.items()
+              if not (k.endswith("rel_pos_bias.weight") or ".bert_model.classifier." in k)}
+    ref_sd["news_encoder.bert_model.embeddings.position_ids"] = torch.arange(cfg["max_pos"]).unsqueeze(0)     # transformers 3.0.2 buffer
+    model.load_state_dict(ref_sd)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    loss, score = model(t(inp[0]), t(inp[1]), t(inp[2]), t(inp[3]))
+    serr = np.abs(score.detach().cpu().numpy() - z["score0"]).max()
+    print("\n[plmnr %s] loss %.6f ref %.6f ; score max|err| %.2e (|ref| max %.2f)" % (model_type, loss.item(), float(z["loss0"]), serr, np.abs(z["score0"]).max()))
+    assert abs(loss.item() - float(z["loss0"])) <= 1e-3 * max(1.0, float(z["loss0"]))
+    assert serr <= 1e-3 * max(1.0, np.abs(z["score0"]).max())
+    loss.backward()
+    w = dict(model.named_parameters())
+    assert w["news_encoder.bert_model.embeddings.word_embeddings.weight"].grad is None          # frozen, PLM-NR/run.py:119-121
+    for n in [str(x) for x in z["grad_names"]]:
+        if n.endswith("self.key.bias") or n.endswith("att_fc2.bias"):
+            continue
+        g, gn = w[n].grad.cpu().numpy(), float(z["gnorm." + n])
+        assert abs(np.sqrt((g.astype(np.float64) ** 2).sum()) - gn) <= 1.5e-2 * gn + 1e-7, n
+        ref = z["gval." + n]
+        assert np.abs(g.reshape(-1)[z["gidx." + n]] - ref).max() <= 2e-2 * np.abs(ref).max() + 1e-7, n
+    # BertModel.from_pretrained: a checkpoint with the "bert." / "roberta." prefix and pre-1.0 LayerNorm names
+    ck = {}
+    for k, v in ref_sd.items():
+        if ".bert_model." in k and "position_ids" not in k:
+            kk = model_type + "." + k.split(".bert_model.")[1]
+            ck[kk.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")] = v + 1.0
+    ck["cls.predictions.bias"] = torch.zeros(4)
+    torch.save(ck, tmp_path / "pytorch_model.bin")
+    missing, unexpected = model.load_pretrained(str(tmp_path / "pytorch_model.bin"))
+    assert missing == [] and unexpected == ["cls.predictions.bias"]
+    k0 = "news_encoder.bert_model.encoder.layer.1.output.LayerNorm.weight"
+    assert torch.equal(model.state_dict()[k0].cpu(), ref_sd[k0] + 1.0)
+
+
 def test_run_py_train_from_mind_format_files(tmp_path):
     """`python run.py --mode train` on real-format inputs (news.tsv through the BERT wordpiece tokenizer, behaviors_np4_*.tsv
     shards through the TF-free streamer, teacher-embedding pickles, PLM-NR teacher checkpoints): the demo.sh train flow

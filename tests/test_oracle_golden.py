@@ -207,6 +207,28 @@ def test_philox_known_answers_and_mask_statistics():
         assert 0.15 < ((m == 0) != (other == 0)).mean() < 0.21          # 2 p (1 - p) = 0.18 for independent masks
 
 
+@pytest.mark.parametrize("model_type", ["bert", "roberta"])
+def test_plmnr_bert_and_roberta_encoders(model_type):
+    """PLM-NR --model_type bert / roberta (PLM-NR/utils.py:17-21, model_bert.py:109-118): transformers BertModel / RobertaModel
+    as the news encoder = the oracle's encoder with a zero rel-pos table, RoBERTa with its position rule (cumulative non-pad
+    count + padding_idx), one token type and layer_norm_eps 1e-5; loss, scores and every encoder-layer / head gradient."""
+    from helpers import load_plmnr_hf_case
+    z, P, cfg, inp = load_plmnr_hf_case(model_type)
+    loss, score, out = O.plmnr_fwd(P, cfg, *inp, keep=True)
+    np.testing.assert_allclose(float(loss), float(z["loss0"]), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(score, z["score0"], rtol=1e-3, atol=ATOL)
+    G = O.plmnr_bwd(P, cfg, out)
+    for n in [str(x) for x in z["grad_names"]]:
+        g = G["student." + n.replace(".bert_model.", ".bert_model.bert.")]
+        ref_norm = float(z["gnorm." + n])
+        if n.endswith("self.key.bias") or n.endswith("att_fc2.bias"):
+            assert np.sqrt((g.astype(np.float64) ** 2).sum()) < 1e-4 and ref_norm < 1e-4
+            continue
+        np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), ref_norm, rtol=1e-3, atol=1e-9, err_msg=n)
+        ref = z["gval." + n]
+        np.testing.assert_allclose(g.reshape(-1)[z["gidx." + n]], ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-10, err_msg=n)
+
+
 def test_nrms_self_attention_backward_matches_finite_differences():
     """The NRMS goldens carry little gradient through the user encoder (see the noise-floor note above), so the
     hand-derived backward of model_bert.py:37-100 is also checked against central differences of its own forward."""

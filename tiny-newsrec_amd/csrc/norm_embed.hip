@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const TokT* __restrict__ 
                                                        const float* __restrict__ word, const float* __restrict__ pos,
                                                        const float* __restrict__ type0, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, bf16* __restrict__ out,
-                                                       float* __restrict__ mask_add, TnrDrop drop) {
+                                                       float* __restrict__ mask_add, TnrDrop drop,
+                                                       const int32_t* __restrict__ pos_ids) {
     const int H = 256 * V;
     const int lane = threadIdx.x & 63;
     int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -48,12 +49,15 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const TokT* __restrict__ 
         if (i == 0)
             for (int j = L; j < Lr; ++j) mask_add[n * Lr + j] = -1e30f;
     }
+    // position row: the token's index (BERT / UniLM, tnlrv3/modeling.py:164-167), or a per-token id table laid out like the
+    // token table (RoBERTa: cumulative count of non-pad tokens + padding_idx, PLM-NR's --model_type roberta)
+    const int pi = pos_ids ? pos_ids[trow * L + i] : i;
     float x[V][4];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         int c = v * 256 + lane * 4;
         f32x4 a = *(const f32x4*)(word + id * H + c);
-        f32x4 b = *(const f32x4*)(pos + (int64_t)i * H + c);
+        f32x4 b = *(const f32x4*)(pos + (int64_t)pi * H + c);
         f32x4 d = *(const f32x4*)(type0 + c);
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[v][r] = a[r] + b[r] + d[r];
@@ -394,7 +398,7 @@ extern "C" int tnr_relpos_table(const float* weight, int A, int L, float* table,
 
 extern "C" int TNR_NAME(tnr_embed_ln_fwd_do)(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
                                    const float* type0, const float* gamma, const float* beta, float eps, void* out,
-                                   float* mask_add, const tnr_dropout_t* drop, void* stream) {
+                                   float* mask_add, const tnr_dropout_t* drop, const int32_t* pos_ids, void* stream) {
     TnrDrop dd;
     if (int rc = tnr_make_drop(drop, &dd, "tnr_embed_ln_fwd")) return rc;
     TNR_CHECK_ARG(tok && word && pos && type0 && gamma && beta && out && mask_add, "tnr_embed_ln_fwd: null pointer");
@@ -403,7 +407,7 @@ extern "C" int TNR_NAME(tnr_embed_ln_fwd_do)(const int64_t* tok, int64_t n_seq, 
     int64_t n_tok = n_seq * L;
     dim3 grid((unsigned)((n_tok + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int64_t>), grid, blk, 0, st, tok, (const int32_t*)nullptr, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add, dd)
+#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int64_t>), grid, blk, 0, st, tok, (const int32_t*)nullptr, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add, dd, pos_ids)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     TNR_CHECK_LAUNCH("tnr_embed_ln_fwd");
@@ -412,13 +416,13 @@ extern "C" int TNR_NAME(tnr_embed_ln_fwd_do)(const int64_t* tok, int64_t n_seq, 
 extern "C" int TNR_NAME(tnr_embed_ln_fwd)(const int64_t* tok, int64_t n_seq, int L, int H, const float* word, const float* pos,
                                 const float* type0, const float* gamma, const float* beta, float eps, void* out,
                                 float* mask_add, void* stream) {
-    return TNR_NAME(tnr_embed_ln_fwd_do)(tok, n_seq, L, H, word, pos, type0, gamma, beta, eps, out, mask_add, nullptr, stream);
+    return TNR_NAME(tnr_embed_ln_fwd_do)(tok, n_seq, L, H, word, pos, type0, gamma, beta, eps, out, mask_add, nullptr, nullptr, stream);
 }
 
 extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed_do)(const int32_t* news_combined, const int32_t* nidx, int64_t n_seq, int L, int H,
                                            const float* word, const float* pos, const float* type0, const float* gamma,
                                            const float* beta, float eps, void* out, float* mask_add,
-                                           const tnr_dropout_t* drop, void* stream) {
+                                           const tnr_dropout_t* drop, const int32_t* pos_ids, void* stream) {
     TnrDrop dd;
     if (int rc = tnr_make_drop(drop, &dd, "tnr_embed_ln_fwd_indexed")) return rc;
     TNR_CHECK_ARG(news_combined && nidx && word && pos && type0 && gamma && beta && out && mask_add,
@@ -428,7 +432,7 @@ extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed_do)(const int32_t* news_combine
     int64_t n_tok = n_seq * L;
     dim3 grid((unsigned)((n_tok + 3) / 4)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int32_t>), grid, blk, 0, st, news_combined, nidx, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add, dd)
+#define LAUNCH(V) hipLaunchKernelGGL((embed_ln_kernel<V, int32_t>), grid, blk, 0, st, news_combined, nidx, n_tok, L, word, pos, type0, gamma, beta, eps, (bf16*)out, mask_add, dd, pos_ids)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     TNR_CHECK_LAUNCH("tnr_embed_ln_fwd_indexed");
@@ -438,7 +442,7 @@ extern "C" int TNR_NAME(tnr_embed_ln_fwd_indexed)(const int32_t* news_combined, 
                                         const float* word, const float* pos, const float* type0, const float* gamma,
                                         const float* beta, float eps, void* out, float* mask_add, void* stream) {
     return TNR_NAME(tnr_embed_ln_fwd_indexed_do)(news_combined, nidx, n_seq, L, H, word, pos, type0, gamma, beta, eps, out, mask_add,
-                                                 nullptr, stream);
+                                                 nullptr, nullptr, stream);
 }
 
 extern "C" int TNR_NAME(tnr_pool_fwd)(const void* y, float* nv, int64_t n_seq, int L, int H, int mean, void* stream) {

@@ -30,10 +30,14 @@ class EngineConfig:
     def __init__(self, n_layers=4, trainable_layers=(2, 3), hidden=768, heads=12, inter=3072, news_dim=256,
                  news_query=200, user_query=200, num_teachers=4, user_log_length=50, npratio=4, num_words=30,
                  user_log_mask=False, temperature=1.0, coef=0.2, vocab=30522, max_pos=512, type_vocab=2,
-                 ln_eps=1e-12, stage1=False, pooling="att", nrms_heads=0):
+                 ln_eps=1e-12, stage1=False, pooling="att", nrms_heads=0, pos_pad_id=None):
         """stage1=True: the DistillModel of Post-train_KD.ipynb (no user encoders: parameters are
         student.news_encoder.* and transform_matrix.* only; user_log_length is 0, npratio+1 titles per body)."""
         self.stage1 = stage1
+        # PLM-NR --model_type (PLM-NR/utils.py:17-21): 'bert' is this encoder with a zero rel-pos table (rel_pos_bias.weight = 0);
+        # 'roberta' additionally takes its position rows from the token ids -- cumulative count of non-pad tokens + padding_idx
+        # (transformers create_position_ids_from_input_ids) -- with type_vocab 1, max_pos 514 and ln_eps 1e-5 from its config
+        self.pos_pad_id = pos_pad_id
         # args.pooling (model_bert.py:130-135): 'att' | 'cls' | anything else = mean ; args.model == 'NRMS' puts a
         # nrms_heads x 16 self-attention in front of every user encoder's pooling (model_bert.py:145-148)
         self.pooling = pooling if pooling in ("att", "cls") else "mean"
@@ -553,6 +557,20 @@ class Engine:
         self.fcache = (fx.view(torch.float32), fm, news_combined.data_ptr(), n)
         return True
 
+    def _pos_ids(self, tok):
+        """RoBERTa position ids of a token table (rows [ids | mask], any integer dtype) -> (rows, L) int32; the resident table's
+        are computed once (cached by its address).  Integer index preparation, like the torch.cat of the news indices."""
+        key = (tok.data_ptr(), tuple(tok.shape))
+        c = getattr(self, "_pos_cache", None)
+        if c is not None and c[0] == key:
+            return c[1]
+        L, pad = self.cfg.L, self.cfg.pos_pad_id
+        ne = (tok[:, :L] != pad)
+        pid = (torch.cumsum(ne.to(torch.int32), 1) * ne + pad).to(torch.int32).contiguous()
+        if tok.shape[0] > 4 * self.N_alloc:          # a resident table, not a per-step batch
+            self._pos_cache = (key, pid)
+        return pid
+
     def encode(self, tok, n_seq, nidx=None, out=None, stop_at=None, train=True):
         """NewsEncoder.forward model_bert.py:119-137 -> news vectors S[:n_seq] (fp32).
         tok (n_seq, 2L) int64 on device, or (nidx given) tok = resident news_combined (n+1, 2L) int32 and
@@ -580,10 +598,12 @@ class Engine:
                    g(BERT + "embeddings.token_type_embeddings.weight"), g(BERT + "embeddings.LayerNorm.weight"),
                    g(BERT + "embeddings.LayerNorm.bias"), cfg.ln_eps, self.x0, self.mask_add)
             de = ds(T.DROP_EMB, 0)
+            pid = self._pos_ids(tok if nidx is not None else tok[:n_seq]) if cfg.pos_pad_id is not None else None
             if nidx is None:
-                self._c("tnr_embed_ln_fwd_do", tok, n_seq, L, H, *emb, de) if de else self._c("tnr_embed_ln_fwd", tok, n_seq, L, H, *emb)
+                self._c("tnr_embed_ln_fwd_do", tok, n_seq, L, H, *emb, de, pid) if (de or pid is not None) else \
+                    self._c("tnr_embed_ln_fwd", tok, n_seq, L, H, *emb)
             else:
-                self._c("tnr_embed_ln_fwd_indexed_do", tok, nidx, n_seq, L, H, *emb, de) if de else \
+                self._c("tnr_embed_ln_fwd_indexed_do", tok, nidx, n_seq, L, H, *emb, de, pid) if (de or pid is not None) else \
                     self._c("tnr_embed_ln_fwd_indexed", tok, nidx, n_seq, L, H, *emb)
         x = self.x0
         self.x_in = {}

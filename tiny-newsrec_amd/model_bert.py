@@ -46,6 +46,7 @@ def engine_config_from_args(args, num_teachers=None, is_teacher=False):
         user_log_mask=args.user_log_mask, temperature=args.temperature, coef=args.coef, vocab=cfg.get("vocab_size", 30522),
         max_pos=cfg.get("max_position_embeddings", 512), type_vocab=cfg.get("type_vocab_size", 2),
         ln_eps=cfg.get("layer_norm_eps", 1e-12), pooling=getattr(args, "pooling", "att"),
+        pos_pad_id=cfg.get("pad_token_id", 1) if getattr(args, "tnr_model_type", "tnlrv3") == "roberta" else None,
         nrms_heads=getattr(args, "num_attention_heads", 0) if getattr(args, "model", "NAML") == "NRMS" else 0)
 
 
@@ -108,6 +109,42 @@ def load_pretrained_into(engine, path, seed=0, allow_missing=False):
     return missing, unexpected
 
 
+def load_hf_bert_into(engine, path, allow_missing=False):
+    """BertModel.from_pretrained / RobertaModel.from_pretrained (PLM-NR/model_bert.py:114, model_type bert / roberta): a
+    transformers checkpoint (keys optionally prefixed "bert." / "roberta.", old LayerNorm.gamma / beta names) onto the
+    engine's encoder; only the first n_layers layers are taken, like num_hidden_layers in the config does.  -> (missing,
+    unexpected)."""
+    import os
+    if not path:
+        return None
+    if not os.path.exists(path):
+        if allow_missing:
+            logging.warning("pretrained encoder %s not found: keeping the construction-time initialisation", path)
+            return None
+        raise FileNotFoundError("--model_name %s does not exist (pass --allow_random_init True to train from the "
+                                "construction-time initialisation)" % path)
+    from tnlrv3 import convert_state_dict as C
+    sd = C.read_checkpoint(path)
+    sd = sd.get("model_state_dict", sd)
+    wanted = {k[len(E.BERT):]: k for k in engine.params if k.startswith(E.BERT) and not k.endswith("rel_pos_bias.weight")}
+    used, unexpected = set(), []
+    with torch.no_grad():
+        for k, v in sd.items():
+            name = k
+            for pre in ("bert.", "roberta."):
+                if name.startswith(pre):
+                    name = name[len(pre):]
+            name = name.replace("LayerNorm.gamma", "LayerNorm.weight").replace("LayerNorm.beta", "LayerNorm.bias")
+            tgt = wanted.get(name)
+            if tgt is None or tuple(engine.params[tgt].shape) != tuple(v.shape):
+                unexpected.append(k)
+                continue
+            engine.params[tgt].copy_(v)
+            used.add(name)
+    engine.refresh_shadows(all_layers=True)
+    return sorted(set(wanted) - used), unexpected
+
+
 class _Backward(torch.autograd.Function):
     """Bridges total_loss.backward() (run.py:194) to Engine.backward()."""
 
@@ -129,11 +166,15 @@ class _Backward(torch.autograd.Function):
 class _Shell(nn.Module):
     """nn.Module tree whose leaves are parameters aliased to engine storage; built from dotted key names."""
 
-    def _adopt(self, engine, prefix):
+    def _adopt(self, engine, prefix, rename=None):
+        """rename(key without prefix) -> module path, or None to keep the parameter out of the module tree."""
         for key, tensor in engine.params.items():
             if not key.startswith(prefix):
                 continue
-            parts = key[len(prefix):].split(".")
+            name = key[len(prefix):] if rename is None else rename(key[len(prefix):])
+            if name is None:
+                continue
+            parts = name.split(".")
             mod = self
             for p in parts[:-1]:
                 if p not in mod._modules:
@@ -150,6 +191,11 @@ class Model(_Shell):
         dev = device or ("cuda:%d" % torch.cuda.current_device())
         self.engine = E.Engine(engine_config_from_args(args), dev, max_batch=max_batch or args.batch_size,
                                dtype=getattr(args, "dtype", "fp16"))
+        if type(self) is Model and getattr(args, "model_type", "tnlrv3") != "tnlrv3":
+            # parameters.py defaults --model_type to "bert", demo.sh passes tnlrv3; the reference's Tiny-NewsRec tree cannot run
+            # anything else (run.py:113-116 dereferences bert_model.bert, which BertModel / RobertaModel do not have)
+            logging.warning("--model_type %s: Tiny-NewsRec's Model is the tnlrv3 (UniLM) encoder; bert / roberta exist on the "
+                            "PLM-NR path only (--num_teachers 0)", args.model_type)
         self._adopt(self.engine, "")
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self._after_bucket = None
@@ -212,20 +258,59 @@ class ModelBert(Model):
         ModelBert(args).forward(history, history_mask, candidate, label) -> (loss, score)
     and state_dict keys without the "student." prefix (news_encoder.*, user_encoder.*), so PLM-NR checkpoints load
     directly and what it saves is what Tiny-NewsRec's get_teacher_emb / teacher_ckpts read (run.py:61-70, 382-460).
-    args.num_hidden_layers sizes the encoder (PLM-NR/model_bert.py:109-111)."""
+    args.num_hidden_layers sizes the encoder (PLM-NR/model_bert.py:109-111).
+    args.model_type (PLM-NR/utils.py:17-21, model_bert.py:109): 'tnlrv3' (demo.sh), or 'bert' / 'roberta' = transformers
+    BertModel / RobertaModel as the encoder: the same layers without the rel-pos bias (its table is held at zero and, like the
+    sequence-classification head, is not part of the module tree), parameters directly under bert_model.* as BertModel names
+    them (PLM-NR/run.py:119-124 unfreezes bert_model.encoder.layer[i]), RoBERTa with its own position rule."""
 
     def __init__(self, args, device=None, max_batch=None):
         import types
         a = types.SimpleNamespace(**vars(args))
         a.num_student_layers = getattr(args, "num_hidden_layers", getattr(args, "num_student_layers", 12))
         a.num_teachers, a.temperature, a.coef = 0, 1.0, 1.0
+        mt = getattr(args, "model_type", "tnlrv3")
+        if mt not in ("tnlrv3", "bert", "roberta"):
+            raise KeyError("--model_type %s: MODEL_CLASSES has tnlrv3, bert, roberta (PLM-NR/utils.py:17-21)" % mt)
+        self.model_type = a.tnr_model_type = mt
         super().__init__(a, device, max_batch)
 
+    def _rename(self, name):
+        if self.model_type == "tnlrv3":
+            return name
+        if name.endswith("rel_pos_bias.weight") or ".bert_model.classifier." in name:
+            return None
+        return name.replace("news_encoder.bert_model.bert.", "news_encoder.bert_model.")
+
     def _adopt(self, engine, prefix):
-        super()._adopt(engine, "student.")           # module tree / parameter names drop the prefix
+        super()._adopt(engine, "student.", self._rename)      # module tree / parameter names drop the prefix
 
     def _engine_key(self, name):
+        if self.model_type != "tnlrv3":
+            name = name.replace("news_encoder.bert_model.", "news_encoder.bert_model.bert.")
         return "student." + name
+
+    def reset_parameters(self, seed=0):
+        super().reset_parameters(seed)
+        if self.model_type != "tnlrv3":                # no relative-position bias in BertModel / RobertaModel
+            self.engine.params[E.BERT + "rel_pos_bias.weight"].zero_()
+            self.engine.refresh_rel()
+
+    def load_state_dict(self, sd, strict=True):
+        if self.model_type != "tnlrv3":                # transformers 3.0.2 keeps position_ids as a persistent buffer
+            sd = {k: v for k, v in sd.items() if not k.endswith("embeddings.position_ids")}
+        return super().load_state_dict(sd, strict=strict)
+
+    def load_pretrained(self, path):
+        if self.model_type == "tnlrv3":
+            return super().load_pretrained(path)
+        a = self.args
+        allow = bool(getattr(a, "synthetic", False) or getattr(a, "allow_random_init", False))
+        rep = load_hf_bert_into(self.engine, path, allow_missing=allow)
+        if rep is not None:
+            logging.info("pretrained %s encoder %s: %d missing keys %s, %d unexpected keys %s", self.model_type, path, len(rep[0]),
+                         list(rep[0])[:8], len(rep[1]), list(rep[1])[:8])
+        return rep
 
     def forward(self, history, history_mask, candidate, label):
         losses, score = self.engine.forward(history, history_mask, candidate, label)

@@ -91,7 +91,7 @@ TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gem
          "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32", "tnr_pool_fwd", "tnr_pool_bwd"]
 # *_do: the same with a tnr_dropout_t* in front of the stream (tnr_ln_bwd_do: the masked second output first)
 for _n in ("tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd"):
-    _SIG[_n + "_do"] = _SIG[_n][:-1] + [_D, _P]
+    _SIG[_n + "_do"] = _SIG[_n][:-1] + [_D] + ([_P] if "embed" in _n else []) + [_P]      # embeddings: + pos_ids
     TYPED.append(_n + "_do")
 _SIG["tnr_gemm_nt_do"] = _SIG["tnr_gemm_nt_ex"][:-1] + [_D, _P]
 _SIG["tnr_ln_bwd_do"] = _SIG["tnr_ln_bwd"][:-1] + [_P, _D, _P]
