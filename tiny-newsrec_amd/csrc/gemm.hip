@@ -30,7 +30,8 @@ struct NTArgs {
     int tile0;                 // first logical tile of this launch (0: one launch per GEMM)
     TnrDrop drop;              // TNR_EPI_DROPOUT: the site whose mask multiplies (acc + bias [-> activation]) before the residual add
     int probe;                 // timing probes (tools only, TNR_PROBES builds): 1 no staging loads in the K loop, 2 no
-                               // fragment reads / MFMAs, 4 every row tile reads A rows 0-255 (A resident in L2), 8 no epilogue
+                               // fragment reads / MFMAs (512: no MFMAs only, 1024: no reads only), 4 every row tile reads A rows
+                               // 0-255 (A resident in L2), 8 no epilogue
 };
 
 constexpr int TILE_BYTES = 128 * 128;   // one operand tile: 128 rows x 64 bf16
@@ -1111,8 +1112,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     __builtin_amdgcn_sched_barrier(0)
 #if defined(TNR_PROBES) && TNR_PROBES >= 2
     const bool compute = !(g.probe & 2);
+    const bool reads_on = compute && !(g.probe & 1024), mfma_on = compute && !(g.probe & 512);   // 512: no MFMAs ; 1024: no fragment reads
 #else
-    constexpr bool compute = true;
+    constexpr bool reads_on = true, mfma_on = true;
 #endif
   while (true) {
     const int next = tile + per < c1 ? tile + per : -1;
@@ -1137,7 +1139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         const char* sb = smem + (kt & 1) * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
         const bool more = kt + 1 < nk;
         // ---- phase 0: A rows 0-63, B cols 0-31 ; quadrant (lo, lo)
-        if (compute)
+        if (reads_on)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -1147,7 +1149,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         }
         if (more) issue(1, kt + 1);
         TNR_PP_SEG_END();
-        if (compute)
+        if (mfma_on)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1156,14 +1158,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[i][j], 0, 0, 0);
         TNR_PP_MFMA_END();
         // ---- phase 1: B cols 32-63 ; quadrant (lo, hi)
-        if (compute)
+        if (reads_on)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 2; j < 4; ++j) bfr[j][s] = *(const bf16x8*)(sb + (32 + (j - 2) * 4) * 128 + boff[s]);
         if (more) issue(2, kt + 1);
         TNR_PP_SEG_END();
-        if (compute)
+        if (mfma_on)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1172,14 +1174,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
                 for (int j = 2; j < 4; ++j) acc[i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[i][j], 0, 0, 0);
         TNR_PP_MFMA_END();
         // ---- phase 2: A rows 64-127 ; quadrant (hi, hi)
-        if (compute)
+        if (reads_on)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < IHI; ++i) af[i][s] = *(const bf16x8*)(sa + (ILO + i) * 16 * 128 + foff[s]);
         if (more) issue(3, kt + 1);
         TNR_PP_SEG_END();
-        if (compute)
+        if (mfma_on)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
             TNR_WAIT_VMCNT(0);
         }
         TNR_PP_SEG_END();
-        if (compute)
+        if (mfma_on)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll

@@ -13,9 +13,10 @@ T.LIB_PATH = os.path.join(ROOT, "tools", "_probe", "libtnr_hip.so")
 dev, M = "cuda:0", int(os.environ.get("M", 52800))
 td, sfx = torch.float16, "_f16"
 opt = lambda k, v: T.lib().tnr_gemm_set_option(k.encode(), int(v))
-SHAPES = ((3072, 768, 0), (768, 3072, 0), (2304, 768, 1), (768, 768, 9))
-PROBES = [(0, "full"), (8, "no epilogue"), (16, "epilogue without stores"), (32, "stores stay in L2"), (1 | 8, "compute only"), (2 | 8, "loads only"),
-          (2 | 4 | 8, "loads only, A in L2")]
+SHAPES = ((3072, 768, 0), (768, 3072, 0))
+PROBES = [(0, "full"), (8, "no epilogue"), (1 | 8, "compute only"), (2 | 8, "loads only"),
+          (1 | 8 | 512, "fragment reads only (no DMA, no MFMA)"), (1 | 8 | 1024, "MFMA only (no DMA, no reads)"), (8 | 512, "DMA + reads, no MFMA"),
+          (8 | 1024, "DMA + MFMA, no reads"), (1 | 2 | 8, "barriers only")]
 for (N, K, fl) in SHAPES:
     a = (torch.randn((M, K), device=dev) * 0.5).to(td); b = (torch.randn((N, K), device=dev) * 0.05).to(td)
     c = torch.zeros((M, N), device=dev, dtype=td); bias = torch.randn(N, device=dev); r = torch.randn((M, N), device=dev).to(td)
