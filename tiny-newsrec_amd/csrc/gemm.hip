@@ -985,15 +985,17 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
 //      interval      0    1    2    3    4    5    6    7   | 8 ...
 //      group 0       L0   M0   L1   M1   L2   M2   L3   M3  | L0' ...
 //      group 1       -    L0   M0   L1   M1   L2   M2   L3  | M3  L0' ...
-// K tile = 4 phases: L0 reads A rows 0-63 + B cols 0-31, L1 B cols 32-63, L2 A rows 64-127, L3 nothing (B kept in registers);
+// K tile = 4 phases: L0 reads A rows 0-63, L1 B cols 32-63, L2 A rows 64-127, L3 B cols 0-31 OF THE NEXT K TILE (B is kept in
+// registers across the K tile; the two B register pairs swap roles every K tile, see TNR_PP_KTILE);
 // M0..M3 = quadrants (A lo, B lo), (A lo, B hi), (A hi, B hi), (A hi, B lo).
-// The LDS-DMA stream runs 5 half tiles (16 KB each: A0 = rows 0-127, A1 = rows 128-255, B0, B1) ahead of the phase
-// counter, in the order A0 A1 B0 B1 per K tile: phase p of tile t issues A1(t+1), B0(t+1), B1(t+1), A0(t+2).  Hazards:
+// The LDS-DMA stream (half tiles of 16 KB: A0 = rows 0-127, A1 = rows 128-255, B0, B1): phase p of K tile t issues
+// B0(t+1) + B1(t+1), A1(t+1), nothing, A0(t+2).  Hazards:
 //   WAR  a half tile is re-staged only after its last reader's lgkmcnt(0) AND a barrier both groups have passed
-//        (A0(t): group 0's L2 -> free from interval 8t+6 = this phase 3; A1(t): group 1's L2 -> free from 8t+7 < tile t+1's
-//        phase 0; B(t): L1 of both groups -> free from 8t+5);
-//   RAW  phase 3 waits vmcnt(2) (everything but the A0(t+2) pieces just issued; the streamed operand A gets 6 intervals,
-//        the L2-resident weights B 2) and both groups pass a barrier before tile t+1's first read.
+//        (A0(t): group 0's L2 -> free from interval 8t+6 = this phase 3; A1(t-1): group 1's L2 of tile t-1; B(t-1): L1 of tile
+//        t-1 and, for its columns 0-31, L3 of tile t-2);
+//   RAW  phase 2 waits vmcnt(2) (everything but the A1(t+1) pieces: B(t+1) has landed) and both groups pass a barrier before
+//        phase 3 reads B(t+1); phase 3 waits vmcnt(2) (everything but the A0(t+2) pieces) and both groups pass a barrier
+//        before tile t+1's first A read.  The streamed operand A gets 4+ intervals, the L2-resident weights B 4.
 // All waves execute the same number of barriers (group 1 one extra before the loop, group 0 one extra after it).
 // B rows are staged with their own swizzle (pp_bswz) and read in the permuted order of nt_epilogue_cols:
 //   fragment row of lane n' = lane & 15 in block j:  32 (j >> 1) + 8 (n' >> 2) + 4 (j & 1) + (n' & 3)
@@ -1134,78 +1136,76 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     first = false;
     __builtin_amdgcn_s_barrier();                        // K tile 0 is in LDS
     if (wm == 1) __builtin_amdgcn_s_barrier();           // the stagger: group 1 runs one interval behind
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* sa = smem + (kt & 1) * STAGE3 + wm * TILE_BYTES;
-        const char* sb = smem + (kt & 1) * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;
-        const bool more = kt + 1 < nk;
-        // ---- phase 0: A rows 0-63, B cols 0-31 ; quadrant (lo, lo)
-        if (reads_on)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j][s] = *(const bf16x8*)(sb + j * 4 * 128 + boff[s]);
-#pragma unroll
-            for (int i = 0; i < ILO; ++i) af[i][s] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]);
-        }
-        if (more) issue(1, kt + 1);
-        TNR_PP_SEG_END();
-        if (mfma_on)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < ILO; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[i][j], 0, 0, 0);
-        TNR_PP_MFMA_END();
-        // ---- phase 1: B cols 32-63 ; quadrant (lo, hi)
-        if (reads_on)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 2; j < 4; ++j) bfr[j][s] = *(const bf16x8*)(sb + (32 + (j - 2) * 4) * 128 + boff[s]);
-        if (more) issue(2, kt + 1);
-        TNR_PP_SEG_END();
-        if (mfma_on)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < ILO; ++i)
-#pragma unroll
-                for (int j = 2; j < 4; ++j) acc[i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[i][j], 0, 0, 0);
-        TNR_PP_MFMA_END();
-        // ---- phase 2: A rows 64-127 ; quadrant (hi, hi)
-        if (reads_on)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < IHI; ++i) af[i][s] = *(const bf16x8*)(sa + (ILO + i) * 16 * 128 + foff[s]);
-        if (more) issue(3, kt + 1);
-        TNR_PP_SEG_END();
-        if (mfma_on)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < IHI; ++i)
-#pragma unroll
-                for (int j = 2; j < 4; ++j) acc[ILO + i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[ILO + i][j], 0, 0, 0);
-        TNR_PP_MFMA_END();
-        // ---- phase 3: no reads ; quadrant (hi, lo) ; K tile kt+1 must have landed before the next phase 0
-        if (kt + 2 < nk) {
-            issue(0, kt + 2);
-            if (a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);
-        } else {
-            TNR_WAIT_VMCNT(0);
-        }
-        TNR_PP_SEG_END();
-        if (mfma_on)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < IHI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[ILO + i][j] = TNR_MFMA_16x16x32(bfr[j][s], af[i][s], acc[ILO + i][j], 0, 0, 0);
-        TNR_PP_MFMA_END();
+    // One K tile, written once for both parities of the B register roles: bfr[BL], bfr[BL + 1] hold B columns 0-31 of this K
+    // tile and bfr[BH], bfr[BH + 1] columns 32-63; the NEXT K tile's columns 0-31 are read in phase 3 into the BH pair (free
+    // after quadrant M2), which is that tile's BL pair - so phase 0 reads A only (8 instead of 12 ds_read_b128 per wave) and the
+    // per-phase counts are 8 / 4 / 8 / 4.  Worth -1.4 % over the 12 / 4 / 8 / 0 schedule (two-library A/B, tools/gemm_ab_lib.py;
+    // 10 of 12 shapes faster), far less than the 9-10 % a probe with phase 0's B reads simply removed suggested: the total LDS
+    // read volume, not its peak, is what the loop pays for.  Orders tried: B0 | B1, A1 | - | A0 (B1 lands too late for the
+    // phase-2 wait on long K: +1.3 %) and B two K tiles ahead from phase 3 (-0.6 %).
+    // LDS-DMA per phase: B0(kt+1), B1(kt+1) | A1(kt+1) | - | A0(kt+2).  Waits: end of phase 2 vmcnt(2) = all but A1(kt+1)
+    // -> B(kt+1) has landed one barrier (two for the staggered group) before phase 3 reads it; end of phase 3 vmcnt(2) =
+    // all but A0(kt+2) -> A1(kt+1) landed before the next K tile.  WAR: B(kt-1) was last read in phase 1 of K tile kt-1 (its
+    // columns 0-31 in phase 3 of kt-2), A1(kt-1) in group 1's phase 2 of kt-1, A0(kt) in group 0's phase 2 of kt.
+#define TNR_PP_KTILE(KT, BL, BH)                                                                                 \
+    {                                                                                                            \
+        const int kt = (KT);                                                                                     \
+        const char* sa = smem + (kt & 1) * STAGE3 + wm * TILE_BYTES;                                             \
+        const char* sb = smem + (kt & 1) * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;        \
+        const char* sbn = smem + ((kt + 1) & 1) * STAGE3 + (2 + (wn >> 1)) * TILE_BYTES + ((wn & 1) * 64) * 128;  \
+        const bool more = kt + 1 < nk;                                                                           \
+        /* ---- phase 0: A rows 0-63 (+ B columns 0-31 of the first K tile) ; quadrant (lo, lo) */               \
+        if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                            \
+            if (kt == 0)                                                                                         \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) bfr[BL + j][s] = *(const bf16x8*)(sb + j * 4 * 128 + boff[s]); \
+            _Pragma("unroll") for (int i = 0; i < ILO; ++i) af[i][s] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]); \
+        }                                                                                                        \
+        if (more) { issue(2, kt + 1); issue(3, kt + 1); }                                                        \
+        TNR_PP_SEG_END();                                                                                        \
+        if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
+            _Pragma("unroll") for (int i = 0; i < ILO; ++i)                                                      \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                    acc[i][j] = TNR_MFMA_16x16x32(bfr[BL + j][s], af[i][s], acc[i][j], 0, 0, 0);                 \
+        TNR_PP_MFMA_END();                                                                                       \
+        /* ---- phase 1: B columns 32-63 ; quadrant (lo, hi) */                                                  \
+        if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                              \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) bfr[BH + j][s] = *(const bf16x8*)(sb + (32 + j * 4) * 128 + boff[s]); \
+        if (more) issue(1, kt + 1);                                                                              \
+        TNR_PP_SEG_END();                                                                                        \
+        if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
+            _Pragma("unroll") for (int i = 0; i < ILO; ++i)                                                      \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                    acc[i][2 + j] = TNR_MFMA_16x16x32(bfr[BH + j][s], af[i][s], acc[i][2 + j], 0, 0, 0);         \
+        TNR_PP_MFMA_END();                                                                                       \
+        /* ---- phase 2: A rows 64-127 ; quadrant (hi, hi) ; B of K tile kt+1 must have landed before phase 3 reads it */ \
+        if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                              \
+            _Pragma("unroll") for (int i = 0; i < IHI; ++i) af[i][s] = *(const bf16x8*)(sa + (ILO + i) * 16 * 128 + foff[s]); \
+        if (more && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);                                           \
+        TNR_PP_SEG_END();                                                                                        \
+        if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
+            _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                    acc[ILO + i][2 + j] = TNR_MFMA_16x16x32(bfr[BH + j][s], af[i][s], acc[ILO + i][2 + j], 0, 0, 0); \
+        TNR_PP_MFMA_END();                                                                                       \
+        /* ---- phase 3: B columns 0-31 of K tile kt+1 into the BH pair ; quadrant (hi, lo) ; A1(kt+1) must have landed */ \
+        if (more) {                                                                                              \
+            if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                          \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) bfr[BH + j][s] = *(const bf16x8*)(sbn + j * 4 * 128 + boff[s]); \
+            if (kt + 2 < nk) issue(0, kt + 2);                                                                   \
+            if (kt + 2 < nk && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);                                \
+        }                                                                                                        \
+        TNR_PP_SEG_END();                                                                                        \
+        if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
+            _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                    acc[ILO + i][j] = TNR_MFMA_16x16x32(bfr[BL + j][s], af[i][s], acc[ILO + i][j], 0, 0, 0);     \
+        TNR_PP_MFMA_END();                                                                                       \
     }
+    for (int kt2 = 0; kt2 < nk; kt2 += 2) {              // two K tiles per trip: the B register roles alternate at compile time
+        TNR_PP_KTILE(kt2, 0, 2)
+        if (kt2 + 1 < nk) TNR_PP_KTILE(kt2 + 1, 2, 0)
+    }
+#undef TNR_PP_KTILE
 #undef TNR_PP_SEG_END
 #undef TNR_PP_MFMA_END
     if (wm == 0) __builtin_amdgcn_s_barrier();           // group 0 waits for group 1's last MFMA segment
