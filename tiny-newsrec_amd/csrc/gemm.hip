@@ -1142,7 +1142,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     // per-phase counts are 8 / 4 / 8 / 4.  Worth -1.4 % over the 12 / 4 / 8 / 0 schedule (two-library A/B, tools/gemm_ab_lib.py;
     // 10 of 12 shapes faster), far less than the 9-10 % a probe with phase 0's B reads simply removed suggested: the total LDS
     // read volume, not its peak, is what the loop pays for.  Orders tried: B0 | B1, A1 | - | A0 (B1 lands too late for the
-    // phase-2 wait on long K: +1.3 %) and B two K tiles ahead from phase 3 (-0.6 %).
+    // phase-2 wait on long K: +1.3 %), B two K tiles ahead from phase 3 (-0.6 %), A1 in phase 0 behind the B half tiles (six
+    // LDS-DMA issues in the 8-read phase: +3.0 % against this order).
     // LDS-DMA per phase: B0(kt+1), B1(kt+1) | A1(kt+1) | - | A0(kt+2).  Waits: end of phase 2 vmcnt(2) = all but A1(kt+1)
     // -> B(kt+1) has landed one barrier (two for the staggered group) before phase 3 reads it; end of phase 3 vmcnt(2) =
     // all but A0(kt+2) -> A1(kt+1) landed before the next K tile.  WAR: B(kt-1) was last read in phase 1 of K tile kt-1 (its
@@ -1335,8 +1336,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
 // run one interval apart, each alternating a LOAD segment (transposed fragment reads + the LDS-DMA of a later sub-tile)
 // with an MFMA segment of 16 MFMAs; dY0 / dY1 are private to a group (the A0 / A1 of the NT kernel), X0 / X1 shared (its
 // B0 / B1).  m step = 4 phases: L0 reads dY blocks 0-3 + X blocks 0-1, L1 X blocks 2-3, L2 dY blocks 4-7, L3 nothing;
-// M0..M3 = quadrants (y lo, x lo), (y lo, x hi), (y hi, x hi), (y hi, x lo).  DMA runs 5 sub-tiles ahead in the order
-// dY0 dY1 X0 X1: phase p of step t issues dY1(t+1), X0(t+1), X1(t+1), dY0(t+2); phase 3 waits vmcnt(2).  Hazards as there.
+// M0..M3 = quadrants (y lo, x lo), (y lo, x hi), (y hi, x hi), (y hi, x lo).  DMA: phase 0 of step t issues dY1(t+1), phase 3
+// dY0(t+2), X0(t+2), X1(t+2) and waits vmcnt(6) (everything of step t+1 has landed).  Both operands stream from HBM here, so
+// the order is chosen for latency budget (8 intervals for three of the four sub-tiles, 6 for dY1): with the NT kernel's old
+// order (X1 two intervals before its wait) this kernel was 3-5 % slower.
 __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1397,7 +1400,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
         issue(1, 0);
         issue(2, 0);
         issue(3, 0);
-        if (nk > 1) issue(0, 1);
+        if (nk > 1) {
+            issue(0, 1);
+            issue(2, 1);
+            issue(3, 1);
+        }
         bf16x8 yf[4][2], xf[4][2];
         auto read_y = [&](const char* sy, int blk, bf16x8 (&dst)[2]) {      // dY block blk (16 n) of the group's 128, both m halves
 #pragma unroll
@@ -1428,7 +1435,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
     __builtin_amdgcn_sched_barrier(0);                              \
     __builtin_amdgcn_s_barrier();                                   \
     __builtin_amdgcn_sched_barrier(0)
-        if (nk > 1) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);
+        if (nk > 1) TNR_WAIT_VMCNT(6); else TNR_WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();                    // m step 0 is in LDS
         if (wn == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one interval behind
         for (int t = 0; t < nk; ++t) {
@@ -1440,7 +1447,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
             for (int j = 0; j < 2; ++j) read_x(sx, j, xf[j]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) read_y(sy, i, yf[i]);
-            if (more) issue(1, t + 1);
+            if (more) issue(1, t + 1);                   // dY1(t+1): its buffer's last reader is group 1's phase 2 of step t-1
             TNR_PP_SEG_END();
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -1452,7 +1459,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
             // ---- phase 1: X blocks 2-3 ; quadrant (lo, hi)
 #pragma unroll
             for (int j = 2; j < 4; ++j) read_x(sx, j, xf[j]);
-            if (more) issue(2, t + 1);
             TNR_PP_SEG_END();
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -1464,7 +1470,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
             // ---- phase 2: dY blocks 4-7 ; quadrant (hi, hi)
 #pragma unroll
             for (int i = 0; i < 4; ++i) read_y(sy, 4 + i, yf[i]);
-            if (more) issue(3, t + 1);
             TNR_PP_SEG_END();
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -1473,10 +1478,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
 #pragma unroll
                     for (int j = 2; j < 4; ++j) acc[4 + i][j] = TNR_MFMA_16x16x32(xf[j][s], yf[i][s], acc[4 + i][j], 0, 0, 0);
             TNR_PP_MFMA_END();
-            // ---- phase 3: no reads ; quadrant (hi, lo) ; m step t+1 must have landed before the next phase 0
+            // ---- phase 3: no reads ; quadrant (hi, lo) ; dY0, X0, X1 of step t+2 (their buffers' last readers are phases 2 / 1 of
+            // this step: both operands stream from HBM, so everything but dY1 goes out two steps ahead); step t+1 must have
+            // landed before the next phase 0
             if (t + 2 < nk) {
                 issue(0, t + 2);
-                TNR_WAIT_VMCNT(2);
+                issue(2, t + 2);
+                issue(3, t + 2);
+                TNR_WAIT_VMCNT(6);
             } else {
                 TNR_WAIT_VMCNT(0);
             }
