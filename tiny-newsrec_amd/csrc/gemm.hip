@@ -10,6 +10,7 @@
 // next tile's loads issued before the current tile's MFMAs, one barrier per K tile; 64 KB LDS per
 // workgroup -> 2 workgroups per CU overlap each other's barrier stalls.
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 
@@ -29,6 +30,7 @@ struct NTArgs {
     int nt;                    // 1: streaming (non-temporal) accesses for once-touched epilogue operands
     int tile0;                 // first logical tile of this launch (0: one launch per GEMM)
     TnrDrop drop;              // TNR_EPI_DROPOUT: the site whose mask multiplies (acc + bias [-> activation]) before the residual add
+    unsigned* queue;           // ping-pong kernel: 8 tile counters (one per XCD label) + a done counter, all zero between launches
     int probe;                 // timing probes (tools only, TNR_PROBES builds): 1 no staging loads in the K loop, 2 no
                                // fragment reads / MFMAs (512: no MFMAs only, 1024: no reads only), 4 every row tile reads A rows
                                // 0-255 (A resident in L2), 8 no epilogue
@@ -1004,6 +1006,22 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
 // differ in bits 0-1 and 3-4; bit 0 selects the 128-byte half by itself, the other three go through the XOR).
 __device__ __forceinline__ int pp_bswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
+// Tile queue of the ping-pong kernel.  pp_q_fetch issues `old = (*ctr)++` from lane 0 of the calling wave when `on` (wave-
+// uniform) and does NOT wait: the compiler is not told about the operation (it would fold the single-lane atomic into a wave
+// reduction whose readfirstlane needs the result at once, and wait for it right behind the tile-start barrier), so `dst` is
+// valid only behind pp_q_wait, which every consumer goes through.  No branch around either: a phi copy of `dst` ahead of the
+// wait would read the register before the data is there.
+// (a counter set: 8 tile counters + the count of workgroups that have left, each on a 256-byte line of its own - the workgroups
+// of one XCD label then update a line that stays in their L2 instead of passing it between the eight)
+constexpr int PP_Q_STRIDE = 64, PP_Q_SET = 9 * PP_Q_STRIDE;
+__device__ __forceinline__ void pp_q_fetch(unsigned& dst, unsigned* ctr, bool on) {
+    const unsigned long long m = (unsigned)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                 : "=&v"(dst), "=&s"(sv) : "v"(0u), "v"(1u), "s"(ctr), "s"(m) : "memory");
+}
+__device__ __forceinline__ void pp_q_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0) ; tile queue: %0" : "+v"(v) :: "memory"); }
+
 template <int MI, int CF>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1015,17 +1033,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     const int wm = w >> 2, wn = w & 3;
     const int nbn = g.N >> 8;
     const int nbm = (g.M + BM - 1) / BM;
-    // Persistent: one workgroup per CU walks its XCD's contiguous run of the tile order (blocks b and b + 8 share an XCD;
-    // the 32 workgroups of an XCD take consecutive tiles, i.e. a GM x (32 / GM) patch that shares A / B panels through
-    // that XCD's L2 -- the order a plain launch of one workgroup per tile produces, without relying on dispatch order).
+    // Persistent: one workgroup per CU; the workgroups of an XCD label (blocks b and b + 8 share an XCD) PULL consecutive tiles
+    // of that label's contiguous run of the tile order from a counter, so the 32 of them work on a GM x (32 / GM) patch that
+    // shares A / B panels through the XCD's L2, as a plain launch of one workgroup per tile would - and a workgroup that starts
+    // late or not at all (CUs held by a collective on another stream: with static shares 8 held CUs cost 28 %, tools/
+    // cu_contention.py) only shifts work to the others.  The index of the next tile is fetched at the start of a tile's K loop
+    // and read at its end (in time for the next tile's first loads to go out ahead of the epilogue), so only the first fetch's
+    // latency shows; no deeper lookahead - a tile claimed early is a tile another workgroup cannot take (with two claims
+    // up front, a launch of one tile per workgroup ran two tiles on half of them).  The last workgroup to leave resets the
+    // counters.
     const int ntile = nbm * nbn;
-    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per = (G - xcd + 7) >> 3;                  // workgroups on this XCD label
+    const int xcd = blockIdx.x & 7;
     const int q8 = ntile >> 3, r8 = ntile & 7;
     const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
-    int tile = c0 + slot;
-    if (tile >= c1) return;                              // whole workgroup, before any barrier
+    int* const qlds = (int*)(smem + LDS3_BYTES);
+    unsigned q0;                                         // the first tile: in flight while the tables below are set up
+    pp_q_fetch(q0, g.queue + xcd * PP_Q_STRIDE, w == 0);
+    auto leave = [&]() {                                 // last workgroup out zeroes the counters for the next launch
+        if (tid == 0) {
+            const unsigned d = __hip_atomic_fetch_add(g.queue + 8 * PP_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == gridDim.x - 1)
+                for (int i = 0; i < 9; ++i)
+                    __hip_atomic_store(g.queue + i * PP_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
 #ifdef TNR_PROBES
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();   // shader clock probe
 #endif
@@ -1093,11 +1125,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         for (int s = 0; s < 2; ++s) boff[s] = rb * 128 + ((((4 * s) + (lane >> 4)) ^ pp_bswz(rb)) << 4);
     }
 
-    f32x2* lut = (f32x2*)(smem + EPI_BYTES);             // own LDS region, built while the first loads fly
+    f32x2* lut = (f32x2*)(smem + EPI_BYTES);             // own LDS region, built while the queue answers
+    if (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (flags & TNR_EPI_MULDGELU) != 0);
+    pp_q_wait(q0);
+    if (tid == 0) qlds[0] = c0 + (int)q0;
+    __syncthreads();
+    int tile = qlds[0];
+    if (tile >= c1) { leave(); return; }                 // whole workgroup, before any other barrier
     int par = 0;
     prologue(tile, par);
-    if (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU)) lut_build(lut, (flags & TNR_EPI_MULDGELU) != 0);
-    bool first = true;
 
     constexpr int ILO = MI < 4 ? MI : 4, IHI = MI - ILO; // 16-row blocks of the wave's lower / upper A half
     bf16x8 af[4][2], bfr[4][2];
@@ -1119,7 +1155,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     constexpr bool reads_on = true, mfma_on = true;
 #endif
   while (true) {
-    const int next = tile + per < c1 ? tile + per : -1;
     int bm, bn;
     tile_coords(tile, nbm, nbn, g.gm, bm, bn);
     f32x4 acc[MI][4];
@@ -1132,9 +1167,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     // (a counted wait that leaves the previous epilogue's stores in flight -- vmcnt(number of stores the epilogue issued
     // after the prologue), full tiles only -- measured the same as waiting for everything both with the first epilogue and with
     // this one (tools/gemm_ab.py, +-0.3 % per shape), so the simple form stays)
-    if (first && nk > 1 && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);
-    first = false;
+    // A wait the compiler can see, unlike the K loop's, and on every path from the epilogue to K tile 0 (its state merge at
+    // the loop head keeps an operation pending that any path leaves pending, so the wait has to sit here, not at the loop's
+    // bottom): instances whose epilogue loads into registers - residual, auxiliary operand - otherwise get a vmcnt(0) of the
+    // compiler's own in front of K tile 0's first MFMA, i.e. behind phase 0's LDS-DMA issues, once per tile.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_s_barrier();                        // K tile 0 is in LDS
+    unsigned qn;                                         // lane 0 of wave 0: the next tile, in flight during this K loop
+    pp_q_fetch(qn, g.queue + xcd * PP_Q_STRIDE, w == 0);
     if (wm == 1) __builtin_amdgcn_s_barrier();           // the stagger: group 1 runs one interval behind
     // One K tile, written once for both parities of the B register roles: bfr[BL], bfr[BL + 1] hold B columns 0-31 of this K
     // tile and bfr[BH], bfr[BH + 1] columns 32-63; the NEXT K tile's columns 0-31 are read in phase 3 into the BH pair (free
@@ -1209,7 +1249,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 #undef TNR_PP_KTILE
 #undef TNR_PP_SEG_END
 #undef TNR_PP_MFMA_END
+    pp_q_wait(qn);                                       // (the K loop's last waits were vmcnt(0) already)
+    if (tid == 0) {
+        qlds[1] = c0 + (int)qn;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     if (wm == 0) __builtin_amdgcn_s_barrier();           // group 0 waits for group 1's last MFMA segment
+    int next = qlds[1];                                  // behind that barrier (group 1: behind its last MFMA segment's) for everyone
+    if (next >= c1) next = -1;
     // every fragment read of this tile has completed (group 1's last MFMA segment is behind the barrier above): the stage
     // ring is free, so the next tile's first loads go out BEFORE this tile's epilogue and land under it
     if (next >= 0) prologue(next, par ^ 1);
@@ -1230,6 +1277,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     if (next < 0) break;
     tile = next;
   }
+  leave();
 }
 
 // wgrad v3: output tile 256 (n) x 256 (k); stage = [dY cols 0-127 | dY cols 128-255 | X cols 0-127 | X cols 128-255]
@@ -1581,14 +1629,44 @@ static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
     X(0) X(TNR_EPI_BIAS) X(TNR_EPI_RES) X(TNR_EPI_BIAS | TNR_EPI_RES) X(TNR_EPI_BIAS | TNR_EPI_GELU)                      \
     X(TNR_EPI_BIAS | TNR_EPI_GELU | TNR_EPI_AUXOUT) X(TNR_EPI_MULDGELU) X(TNR_EPI_MULDGELU | TNR_EPI_COLSUM)              \
     X(TNR_EPI_BIAS | TNR_EPI_TANH | TNR_EPI_OUTF32) X(TNR_EPI_BIAS | TNR_EPI_RES | TNR_EPI_DROPOUT)
+// Counter sets of the ping-pong kernel's tile queue: zero at load, returned to zero by every launch.  One set per (device,
+// stream): launches of a stream run in order, so each finds the set its predecessor zeroed, and launches of different streams
+// never share one.  When the table is full the device is drained and the table starts over.
+constexpr int PP_QUEUE_SETS = 128, PP_LDS = LDS3_BYTES + 64;
+__device__ unsigned g_pp_queue[PP_QUEUE_SETS * PP_Q_SET];
+static unsigned* pp_queue_of(hipStream_t st) {
+    struct Slot { int dev; hipStream_t st; };
+    static std::mutex mu;
+    static Slot slots[PP_QUEUE_SETS];
+    static int nslot = 0;
+    static unsigned* base[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_pp_queue)) != hipSuccess) return nullptr;
+    for (int i = 0; i < nslot; ++i)
+        if (slots[i].dev == dev && slots[i].st == st) return base[dev] + i * PP_Q_SET;
+    if (nslot == PP_QUEUE_SETS) {
+        int cur = dev;
+        for (int i = 0; i < nslot; ++i)
+            if (slots[i].dev != cur) { cur = slots[i].dev; (void)hipSetDevice(cur); (void)hipDeviceSynchronize(); }
+        (void)hipSetDevice(dev);
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+        nslot = 0;
+    }
+    slots[nslot] = Slot{dev, st};
+    return base[dev] + (nslot++) * PP_Q_SET;
+}
+
 template <int MI>
 static void pp_launch(const NTArgs& g, unsigned grid, hipStream_t st) {
     switch (g.flags) {
 #define TNR_PP_CASE(CF) \
-    case (CF): hipLaunchKernelGGL((gemm_nt_pp_kernel<MI, (CF)>), dim3(grid), dim3(512), LDS3_BYTES, st, g); break;
+    case (CF): hipLaunchKernelGGL((gemm_nt_pp_kernel<MI, (CF)>), dim3(grid), dim3(512), PP_LDS, st, g); break;
         TNR_PP_FLAG_SETS(TNR_PP_CASE)
 #undef TNR_PP_CASE
-    default: hipLaunchKernelGGL((gemm_nt_pp_kernel<MI, -1>), dim3(grid), dim3(512), LDS3_BYTES, st, g); break;
+    default: hipLaunchKernelGGL((gemm_nt_pp_kernel<MI, -1>), dim3(grid), dim3(512), PP_LDS, st, g); break;
     }
 }
 
@@ -1626,7 +1704,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
                   "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
     const TnrGemmOpts& o = *tnr_gemm_opts();
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0, dd, 0};
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0, dd, nullptr, 0};
 #ifdef TNR_PROBES
     g.probe = o.probe;
 #endif
@@ -1637,8 +1715,8 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
 #define TNR_PP_ATTR(CF)                                                                                                     \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<8, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES); \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<7, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<8, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<7, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         TNR_PP_FLAG_SETS(TNR_PP_ATTR)
         TNR_PP_ATTR(-1)
 #undef TNR_PP_ATTR
@@ -1654,10 +1732,12 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
         hipLaunchKernelGGL(gemm_nt256_kernel, dim3((unsigned)(((M + 255) / 256) * (N / 128))), dim3(512), RING2, st, g);
         break;
     case TNR_ROUTE_224x256:
+        if (o.pp && !(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
         if (o.pp) pp_launch<7>(g, (unsigned)std::min<int64_t>(((M + 223) / 224) * (N / 256), n_cu), st);
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<7>), dim3((unsigned)(((M + 223) / 224) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;
     default:
+        if (o.pp && !(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
         if (o.pp) pp_launch<8>(g, (unsigned)std::min<int64_t>(((M + 255) / 256) * (N / 256), n_cu), st);
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<8>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;
