@@ -30,6 +30,8 @@ struct NTArgs {
     int nt;                    // 1: streaming (non-temporal) accesses for once-touched epilogue operands
     int tile0;                 // first logical tile of this launch (0: one launch per GEMM)
     TnrDrop drop;              // TNR_EPI_DROPOUT: the site whose mask multiplies (acc + bias [-> activation]) before the residual add
+    int mix_p, mix_x;          // ping-pong kernel: mix_p row panels, mix_x of them full height (32 MI rows), the others 32 rows
+                               // shorter, spread evenly (pp_panel); mix_x == mix_p: the uniform tiling
     unsigned* queue;           // ping-pong kernel: 8 tile counters (one per XCD label) + a done counter, all zero between launches
     int probe;                 // timing probes (tools only, TNR_PROBES builds): 1 no staging loads in the K loop, 2 no
                                // fragment reads / MFMAs (512: no MFMAs only, 1024: no reads only), 4 every row tile reads A rows
@@ -823,15 +825,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
 // layout, prefetched one block ahead; column sums (bias gradient of the producing Linear) are reduced over the 16 rows
 // of a block by row-wise shuffles and over blocks in registers.
 template <int MI, int CF>
+// The tile is row panel bm, rows rs .. rs + 32 nblk - 1: nblk (MI, or MI - 1 for a short tile) 16-row blocks per wave group.
 __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[MI][4], const f32x2* lut, const float* bias_lds,
-                                                 int bm, int bn, int wm, int wn, int lane) {
-    constexpr int PR = 16 * MI, BM = 2 * PR;
+                                                 int bm, int bn, int rs, int nblk, int wm, int wn, int lane) {
     const int flags = CF >= 0 ? CF : g.flags;
     const int m16 = lane & 15, qd = lane >> 4;
     const int n0 = bn * 256 + wn * 64 + qd * 8;                  // this lane's columns: n0 .. n0 + 7 and n0 + 32 .. n0 + 39
-    const int row0 = bm * BM + wm * PR + m16;
+    const int row0 = rs + wm * 16 * nblk + m16;
 #if defined(TNR_PROBES) && TNR_PROBES >= 2
-    const int n0s = (g.probe & 32) ? wn * 64 + qd * 8 : n0, row0s = (g.probe & 32) ? wm * PR + m16 : row0;
+    const int n0s = (g.probe & 32) ? wn * 64 + qd * 8 : n0, row0s = (g.probe & 32) ? wm * 16 * MI + m16 : row0;
     const bool do_store = !(g.probe & 16);
 #else
     const int n0s = n0, row0s = row0;
@@ -870,8 +872,9 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
     if (pre_aux | pre_res) xload(0, x0, x1);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        if (i == MI - 1 && nblk < MI) break;                     // short tile
         bf16x8 y0 = x0, y1 = x1;
-        if ((pre_aux | pre_res) && i + 1 < MI) xload(i + 1, x0, x1);
+        if ((pre_aux | pre_res) && i + 1 < MI && i + 1 < nblk) xload(i + 1, x0, x1);
         const int m = row0 + i * 16;
         float v[16];
 #pragma unroll
@@ -1004,6 +1007,17 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
 //   16-byte slot of (row, chunk):  chunk ^ pp_bswz(row),  pp_bswz(row) = row bit 1 | row bits 3-4 << 1
 // which keeps every 16-lane group of a ds_read_b128 on 16 distinct slots of the 256-byte bank row (the rows of a group
 // differ in bits 0-1 and 3-4; bit 0 selects the 128-byte half by itself, the other three go through the XOR).
+// Row panels of two heights.  A launch's time is (tiles per workgroup, rounded UP) x (time per tile), and with one height the
+// rounding costs 3-9 % on the step's shapes (M = 52 800: N = 2304 is 8.3 rounds of 224-row tiles, N = 768 2.77).  With P panels
+// of which x are BMAX rows high and the rest BMAX - 32, P x (N / 256) can be made a multiple of the workgroup count and the
+// rows still add up to M; the kernel skips the last 16-row block of both wave groups in a short tile.  The tall panels are
+// spread evenly over the P (every XCD's run of the tile order gets the same mix; the queue evens out the rest):
+// panel p starts at row (BMAX - 32) p + 32 floor(p x / P) and is tall iff floor((p + 1) x / P) > floor(p x / P).
+__device__ __forceinline__ void pp_panel(int p, int P, int x, int bmax, int& row0, bool& tall) {
+    const int a = (p * x) / P, b = ((p + 1) * x) / P;
+    row0 = p * (bmax - 32) + 32 * a;
+    tall = b > a;
+}
 __device__ __forceinline__ int pp_bswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
 // Tile queue of the ping-pong kernel.  pp_q_fetch issues `old = (*ctr)++` from lane 0 of the calling wave when `on` (wave-
@@ -1032,7 +1046,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the stagger branches are scalar
     const int wm = w >> 2, wn = w & 3;
     const int nbn = g.N >> 8;
-    const int nbm = (g.M + BM - 1) / BM;
+    const int nbm = g.mix_p;
     // Persistent: one workgroup per CU; the workgroups of an XCD label (blocks b and b + 8 share an XCD) PULL consecutive tiles
     // of that label's contiguous run of the tile order from a counter, so the 32 of them work on a GM x (32 / GM) patch that
     // shares A / B panels through the XCD's L2, as a plain launch of one workgroup per tile would - and a workgroup that starts
@@ -1067,15 +1081,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     const bf16* srcB[2][2];
     const bool a_live = MI == 8 || 2 * w + 1 < APIECES;
     auto set_src = [&](int t) {
-        int bm_, bn_;
+        int bm_, bn_, rs_;
+        bool tall_;
         tile_coords(t, nbm, nbn, g.gm, bm_, bn_);
+        pp_panel(bm_, nbm, g.mix_x, BM, rs_, tall_);
+        const int pr_ = tall_ ? PR : PR - 16;            // rows per wave group; a short tile's last pieces re-read its last row
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int row = (2 * w + q) * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ (row & 7), chunkb = (lane & 7) ^ pp_bswz(row);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                int gm = bm_ * BM + h * PR + row;
+                int gm = rs_ + h * pr_ + (row < pr_ ? row : pr_ - 1);
 #if defined(TNR_PROBES) && TNR_PROBES >= 2
                 if (g.probe & 4) gm = h * PR + row;
 #endif
@@ -1155,8 +1172,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     constexpr bool reads_on = true, mfma_on = true;
 #endif
   while (true) {
-    int bm, bn;
+    int bm, bn, rs;
+    bool tall_v;
     tile_coords(tile, nbm, nbn, g.gm, bm, bn);
+    pp_panel(bm, nbm, g.mix_x, BM, rs, tall_v);
+    const bool tall = __builtin_amdgcn_readfirstlane(tall_v ? 1 : 0) != 0;   // wave-uniform: scalar branches in the K loop
     f32x4 acc[MI][4];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -1220,12 +1240,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         TNR_PP_MFMA_END();                                                                                       \
         /* ---- phase 2: A rows 64-127 ; quadrant (hi, hi) ; B of K tile kt+1 must have landed before phase 3 reads it */ \
         if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                              \
-            _Pragma("unroll") for (int i = 0; i < IHI; ++i) af[i][s] = *(const bf16x8*)(sa + (ILO + i) * 16 * 128 + foff[s]); \
+            _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
+                if (i + 1 < IHI || tall) af[i][s] = *(const bf16x8*)(sa + (ILO + i) * 16 * 128 + foff[s]);       \
         if (more && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);                                           \
         TNR_PP_SEG_END();                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                if (i + 1 < IHI || tall) _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
                     acc[ILO + i][2 + j] = TNR_MFMA_16x16x32(bfr[BH + j][s], af[i][s], acc[ILO + i][2 + j], 0, 0, 0); \
         TNR_PP_MFMA_END();                                                                                       \
         /* ---- phase 3: B columns 0-31 of K tile kt+1 into the BH pair ; quadrant (hi, lo) ; A1(kt+1) must have landed */ \
@@ -1238,7 +1259,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         TNR_PP_SEG_END();                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+                if (i + 1 < IHI || tall) _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
                     acc[ILO + i][j] = TNR_MFMA_16x16x32(bfr[BL + j][s], af[i][s], acc[ILO + i][j], 0, 0, 0);     \
         TNR_PP_MFMA_END();                                                                                       \
     }
@@ -1265,7 +1286,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         if (acc[0][0][0] == 12345.678f) *(f32x4*)g.C = acc[1][1];
     } else
 #endif
-    nt_epilogue_cols<MI, CF>(g, acc, lut, bias_lds + par * 256, bm, bn, wm, wn, lane);
+    nt_epilogue_cols<MI, CF>(g, acc, lut, bias_lds + par * 256, bm, bn, rs, tall ? MI : MI - 1, wm, wn, lane);
     par ^= 1;
 #ifdef TNR_PROBES
     if ((g.probe & 64) && next < 0 && g.colsum_part && tid == 0) {   // shader cycles / 100 MHz ticks of this workgroup's life
@@ -1607,6 +1628,43 @@ static int device_cus() {
     return cus[devid];
 }
 
+// Tiling of a ping-pong launch: instance (MI = 8: panels of 256 / 224 rows, MI = 7: 224 / 192), P row panels, x of them tall
+// (pp_panel).  Cost model: a tile costs its rows + a fixed 24 (prologue latency, bias, queue), every XCD label's 1/8 of the tiles
+// is pulled by 1/8 of the workgroups, a mixed launch pays half the height difference for the luck of the draw; candidates
+// are all P between "all tall" and "all short".  mix = 0 (option `mix`, or column sums riding along: their partial rows
+// are counted per 256-row panel, tnr_gemm_colsum_rows): the uniform tiling with the old 224 / 256 rule.
+struct PpPlan { int mi, P, x; };
+static PpPlan pp_plan(int64_t M, int64_t N, int flags, int n_cu) {
+    const TnrGemmOpts& o = *tnr_gemm_opts();
+    const int64_t ncol = N / 256;
+    if ((flags & TNR_EPI_COLSUM) || !o.mix || !o.pp) {
+        const int64_t t256 = ((M + 255) / 256) * ncol, t224 = ((M + 223) / 224) * ncol;
+        const int64_t c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
+        bool use224 = c224 * 108 < c256 * 100 && !(flags & TNR_EPI_COLSUM);   // per-tile fixed costs: need a clear win
+        if (o.bm) use224 = o.bm == 224 && !(flags & TNR_EPI_COLSUM);
+        const int P = (int)(use224 ? (M + 223) / 224 : (M + 255) / 256);
+        return PpPlan{use224 ? 7 : 8, P, P};
+    }
+    PpPlan best{8, (int)((M + 255) / 256), (int)((M + 255) / 256)};
+    double best_span = 1e30;
+    const int64_t W = n_cu >= 8 ? n_cu / 8 : 1;
+    for (int mi = 8; mi >= 7; --mi) {
+        if (o.bm && o.bm != 32 * mi) continue;
+        const int tall = 32 * mi, shrt = tall - 32;
+        const int64_t pmin = (M + tall - 1) / tall, pmax = (M + shrt - 1) / shrt;
+        for (int64_t p = pmin; p <= pmax; ++p) {
+            int64_t x = M - p * shrt;
+            x = x > 0 ? (x + 31) / 32 : 0;                          // tall panels needed to cover M rows
+            const double ct = tall + 24.0, cs = shrt + 24.0, f = (double)x / (double)p, cbar = f * ct + (1.0 - f) * cs;
+            const int64_t n = (p * ncol + 7) / 8, k = n / W, r = n % W;
+            double span = (double)k * cbar + (r ? cbar : 0.0) + (x > 0 && x < p ? 0.5 * (ct - cs) : 0.0);
+            if (k == 0) span = x > 0 ? ct : cs;
+            if (span < best_span - 1e-9) { best_span = span; best = PpPlan{mi, (int)p, (int)x}; }
+        }
+    }
+    return best;
+}
+
 static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
     const TnrGemmOpts& o = *tnr_gemm_opts();
     // short inputs (stage-1 title / body passes, small eval batches): when the 256x256 grid would leave more than 40 % of
@@ -1615,12 +1673,7 @@ static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
     const bool odd_gelu = (N % 256) != 0 && (flags & (TNR_EPI_GELU | TNR_EPI_MULDGELU));   // the 256x128 kernel has no table GELU
     if (o.ver == 1 || M <= 128 || odd_gelu || (sparse256 && o.allow_fine)) return TNR_ROUTE_128x128;
     if (o.ver == 2 || (N % 256) != 0) return TNR_ROUTE_256x128;
-    // tile height: 256 or 224 rows, whichever needs less (rounds of workgroups) x (rows per tile)
-    const int64_t t256 = ((M + 255) / 256) * (N / 256), t224 = ((M + 223) / 224) * (N / 256);
-    const int64_t c256 = ((t256 + n_cu - 1) / n_cu) * 256, c224 = ((t224 + n_cu - 1) / n_cu) * 224;
-    bool use224 = c224 * 108 < c256 * 100 && !(flags & TNR_EPI_COLSUM);   // per-tile fixed costs: need a clear win
-    if (o.bm) use224 = o.bm == 224 && !(flags & TNR_EPI_COLSUM);
-    return use224 ? TNR_ROUTE_224x256 : TNR_ROUTE_256x256;
+    return pp_plan(M, N, flags, n_cu).mi == 7 ? TNR_ROUTE_224x256 : TNR_ROUTE_256x256;
 }
 
 // the epilogue flag combinations of engine.py get an instance each with the flags at compile time (forward: QKV / pooled query,
@@ -1704,7 +1757,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
                   "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
     const TnrGemmOpts& o = *tnr_gemm_opts();
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0, dd, nullptr, 0};
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0, dd, 0, 0, nullptr, 0};
 #ifdef TNR_PROBES
     g.probe = o.probe;
 #endif
@@ -1732,13 +1785,21 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
         hipLaunchKernelGGL(gemm_nt256_kernel, dim3((unsigned)(((M + 255) / 256) * (N / 128))), dim3(512), RING2, st, g);
         break;
     case TNR_ROUTE_224x256:
-        if (o.pp && !(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
-        if (o.pp) pp_launch<7>(g, (unsigned)std::min<int64_t>(((M + 223) / 224) * (N / 256), n_cu), st);
+        if (o.pp) {
+            const PpPlan pl = pp_plan(M, N, flags, n_cu);
+            g.mix_p = pl.P; g.mix_x = pl.x;
+            if (!(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
+            pp_launch<7>(g, (unsigned)std::min<int64_t>((int64_t)pl.P * (N / 256), n_cu), st);
+        }
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<7>), dim3((unsigned)(((M + 223) / 224) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;
     default:
-        if (o.pp && !(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
-        if (o.pp) pp_launch<8>(g, (unsigned)std::min<int64_t>(((M + 255) / 256) * (N / 256), n_cu), st);
+        if (o.pp) {
+            const PpPlan pl = pp_plan(M, N, flags, n_cu);
+            g.mix_p = pl.P; g.mix_x = pl.x;
+            if (!(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
+            pp_launch<8>(g, (unsigned)std::min<int64_t>((int64_t)pl.P * (N / 256), n_cu), st);
+        }
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<8>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;
     }

@@ -1,5 +1,6 @@
 """Interleaved same-process A/B of a library GEMM option on the WHOLE training step (the bench.py workload: B=32, 4-layer
-student + 4 teachers, fwd + bwd + AMSGrad); GPU box.     AB=pp:0:1 DTYPE=fp16 python tools/step_ab.py"""
+student + 4 teachers, fwd + bwd + AMSGrad); GPU box.     AB=pp:0:1 DTYPE=fp16 python tools/step_ab.py
+AB=teacher_stream:0:1: the engine's second stream for the teacher side instead of a library option."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
@@ -21,10 +22,14 @@ def step(i):
     eng.forward_indexed(comb, hidx[s], mask[s], cidx[s], label[s], tables)
     eng.backward()
     eng.step(lr=1e-4)
+side = torch.cuda.Stream()
 res = {0: [], 1: []}
 for rnd in range(6):
     for v in ((0, 1) if rnd % 2 == 0 else (1, 0)):
-        T.lib().tnr_gemm_set_option(KEY.encode(), int(VALS[v]))
+        if KEY == "teacher_stream":        # engine-level switch: the teacher side of the forward on a second stream
+            eng.teacher_stream = side if int(VALS[v]) else None
+        else:
+            T.lib().tnr_gemm_set_option(KEY.encode(), int(VALS[v]))
         for i in range(3): step(i)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(S): step(i)
