@@ -101,7 +101,7 @@ int64_t tnr_gemm_colsum_rows(int64_t M);
 /* Debug / test hooks.  tnr_gemm_nt_route: which kernel tnr_gemm_nt(_ex) launches for a shape on the current
  * device (the decision depends on (M, N, K, flags) and the CU count only) -- the parity tests assert it so that
  * every tile variant is pinned at the shapes the training step issues.  tnr_gemm_set_option: process-wide A/B
- * switches for tools/ ("ver", "gm", "fine_pct", "allow_fine", "bm", "nt", "pp"); the library never reads the
+ * switches for tools/ ("ver", "gm", "fine_pct", "allow_fine", "bm", "nt", "pp", "tnpp", "mix"); the library never reads the
  * environment and the defaults are the shipped configuration. */
 #define TNR_ROUTE_128x128 128    /* 128x128 tile, 4 waves, 2 workgroups per CU */
 #define TNR_ROUTE_256x128 2128   /* 256x128 tile (N % 256 != 0) */
@@ -109,6 +109,11 @@ int64_t tnr_gemm_colsum_rows(int64_t M);
 #define TNR_ROUTE_224x256 224    /* 224-row variant of the same kernel (fewer wasted rows per round) */
 int tnr_gemm_nt_route(int64_t M, int64_t N, int64_t K, int flags);
 int tnr_gemm_set_option(const char* key, int value);
+/* The row tiling of the persistent 256-column kernel on a device with n_cu compute units (host arithmetic only, no device
+ * needed): *panels row panels, *tall of them 32 * *mi rows high and the others 32 rows shorter, spread evenly - panel p starts
+ * at row (32 * mi - 32) * p + 32 * floor(p * tall / panels).  Chosen so that panels * N / 256 tiles fill whole rounds of the
+ * workgroups (option "mix" = 0: one height).  Results do not depend on the tiling (a row's K order is the same). */
+int tnr_gemm_nt_plan(int64_t M, int64_t N, int flags, int n_cu, int* mi, int* panels, int* tall);
 
 /* dW[N,K] (fp32) = dY[M,N]^T . X[M,K] : weight gradient of a Linear.  Reduction over M is split into
  * `splits` slabs in `ws` (fp32, splits*N*K elements) and summed in fixed order (deterministic).

@@ -32,3 +32,40 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(T, "LIB_PATH", "/nonexistent/libtnr_hip.so")
     with pytest.raises(T.TnrError, match="not built"):
         E.Engine(E.EngineConfig(n_layers=1, trainable_layers=(0,), num_teachers=1), device="cpu", max_batch=1)
+
+
+def _plan(M, N, flags=0, n_cu=256):
+    mi, P, x = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    rc = T.lib().tnr_gemm_nt_plan(M, N, flags, n_cu, ctypes.cast(ctypes.byref(mi), ctypes.c_void_p),
+                                  ctypes.cast(ctypes.byref(P), ctypes.c_void_p), ctypes.cast(ctypes.byref(x), ctypes.c_void_p))
+    assert rc == 0
+    return mi.value, P.value, x.value
+
+
+def test_gemm_row_tiling_covers_every_row_exactly_once():
+    """Host logic of the persistent NT kernel (csrc/gemm.hip:pp_plan / pp_panel): P row panels, x of them 32*mi rows and the rest
+    32 rows shorter, spread evenly.  The panels must tile [0, >= M) without gaps or overlaps for every shape, and the column
+    sums' partial rows are counted per 256-row panel (tnr_gemm_colsum_rows), so a COLSUM launch keeps the uniform tiling."""
+    import random
+    rnd = random.Random(5)
+    shapes = [(52800, 768), (52800, 2304), (52800, 3072), (52800, 256), (1, 256), (129, 768), (3300, 3072)]
+    shapes += [(rnd.randint(129, 120000), 256 * rnd.randint(1, 12)) for _ in range(300)]
+    for M, N in shapes:
+        for n_cu in (256, 304, 64):
+            mi, P, x = _plan(M, N, 0, n_cu)
+            assert mi in (7, 8) and 0 <= x <= P and P >= 1, (M, N, mi, P, x)
+            tall, short = 32 * mi, 32 * mi - 32
+            start, rows = 0, 0
+            for p in range(P):
+                a, b = (p * x) // P, ((p + 1) * x) // P
+                assert short * p + 32 * a == start, (M, N, p)          # pp_panel's closed form == running sum
+                h = tall if b > a else short
+                start += h
+            assert start == x * tall + (P - x) * short >= M, (M, N, mi, P, x)
+            assert start - M < tall + short, (M, N, mi, P, x)           # never more than the last panels' slack
+        mi, P, x = _plan(M, N, T.EPI_COLSUM)
+        assert (mi, P, x) == (8, (M + 255) // 256, (M + 255) // 256)
+        assert 4 * P == T.query("tnr_gemm_colsum_rows", M)
+    # the headline step's shapes fill whole rounds of 256 workgroups
+    assert _plan(52800, 768) == (7, 256, 114)
+    assert _plan(52800, 2304)[0:2] == (8, 227)

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 
 // Backward: recompute P in both orientations, then dV = P^T dO, dS = P*(dP - rowsum(dP*P)),
 // dQ = dS K / 8, dK = dS^T Q / 8.
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                        const float* __restrict__ rel, const bf16* __restrict__ dctx,
                                                        bf16* __restrict__ dqkv, float* __restrict__ bias_part,
                                                        int64_t n_pairs, int L, int A, TnrDrop drop) {
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
 }
 
 // backward pass 2: dK, dV per (sequence, head, key tile), looping over the query tiles
-__global__ __launch_bounds__(256) void attn_long_bwd_dkv_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
+__global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                                 const float* __restrict__ rel, const bf16* __restrict__ dctx,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 bf16* __restrict__ dqkv, int64_t n_items, int L, int Lr, int A,

@@ -1723,6 +1723,16 @@ static void pp_launch(const NTArgs& g, unsigned grid, hipStream_t st) {
     }
 }
 
+#ifndef TNR_BUILD_F16
+// host-only (no HIP call): the tiling the persistent kernel would use on a device with n_cu compute units
+extern "C" int tnr_gemm_nt_plan(int64_t M, int64_t N, int flags, int n_cu, int* mi, int* panels, int* tall) {
+    TNR_CHECK_ARG(M >= 1 && N >= 256 && (N % 256) == 0 && n_cu >= 1 && mi && panels && tall, "tnr_gemm_nt_plan: bad argument");
+    const PpPlan pl = pp_plan(M, N, flags, n_cu);
+    *mi = pl.mi; *panels = pl.P; *tall = pl.x;
+    return TNR_OK;
+}
+#endif
+
 extern "C" int TNR_NAME(tnr_gemm_nt_route)(int64_t M, int64_t N, int64_t K, int flags) {
     return nt_route(M, N, K, flags, device_cus());
 }

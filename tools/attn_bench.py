@@ -26,3 +26,13 @@ def timeit(fn, reps=20):
 f = timeit(lambda: T.call("tnr_attn_l32_fwd" + sfx, qkv, mask, rel, ctx, N, L, A))
 b = timeit(lambda: T.call("tnr_attn_l32_bwd" + sfx, qkv, mask, rel, dctx, dqkv, bp, N, L, A))
 print("attn_l32 fwd %.1f us (%.0f GB/s of 324 MB)   bwd %.1f us (%.0f GB/s of 567 MB)" % (f, 324e6 / f / 1e3, b, 567e6 / b / 1e3))
+# the long-sequence kernels (stage-1 bodies): ~53 k tokens per launch as well
+for (Ll, Nl) in ((128, 416), (512, 104)):
+    q2 = (torch.randn(Nl * Ll, 3 * H, device=dev) * 0.5).to(td)
+    m2 = torch.zeros(Nl, Ll, device=dev); m2[:, Ll - 9:] = -10000.0
+    r2 = torch.randn(A, Ll, Ll, device=dev) * 0.1
+    c2 = torch.zeros(Nl * Ll, H, device=dev, dtype=td); dc2 = (torch.randn(Nl * Ll, H, device=dev) * 0.1).to(td)
+    lse = torch.zeros(Nl, A, Ll, device=dev); delta = torch.zeros(Nl, A, Ll, device=dev); dq2 = torch.zeros_like(q2)
+    f = timeit(lambda: T.call("tnr_attn_long_fwd" + sfx, q2, m2, r2, c2, lse, Nl, Ll, A), 10)
+    b = timeit(lambda: T.call("tnr_attn_long_bwd" + sfx, q2, m2, r2, c2, dc2, lse, delta, dq2, Nl, Ll, A), 10)
+    print("attn_long L=%d N=%d: fwd %.1f us   bwd (dq + dkv passes) %.1f us" % (Ll, Nl, f, b))
