@@ -217,6 +217,8 @@ int tnr_segment_sum_rows(const float* src, const int32_t* order, const int32_t* 
  * params are stacked per model: pad (n_model,D), w1 (n_model,Q,D), b1 (n_model,Q), w2 (n_model,Q), b2 (n_model).
  * epre (n_model, B*U, Q) = fc1 pre-activations v W1^T + b1 of every history slot in position order (one batched
  * tnr_sgemm) ; epad (n_model, Q) = fc1(pad_doc) of every model, or NULL to have each workgroup compute it ;
+ * epre == NULL: fc1 runs INSIDE the kernel on the fp32 MFMA (one launch per pass; needs D % 8 == 0 and
+ * 64 (D + 4) + U Q + D + 64 floats of LDS), epad is ignored ;
  * out: user (model z at user + z*user_stride, (B,D)), score (n_model,B,C), saved e (n_model,B,U,Q), alpha (n_model,B,U), den (n_model,B). */
 int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hidx, const int32_t* cidx, const float* mask,
                        const float* pad, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -337,16 +337,24 @@ def test_user_score_fwd_bwd(ulm):
     T.call("tnr_user_score_fwd", dev(vec), R, dev(hidx), dev(cidx), dev(mask), dv["pad"], dv["w1"], dv["b1"], dv["w2"],
            dv["b2"], ulm, dev(epre.astype(np.float32)), None if ulm else dev((pr["pad"][:, None, :] * pr["w1"]).sum(-1) + pr["b1"]),
            user, B * D, score, e, alpha, den, nm, B, U, C, D, Q)
+    # the same pass with fc1 inside the kernel (epre = NULL): what the engine issues
+    user_f, score_f = torch.zeros_like(user), torch.zeros_like(score)
+    e_f, alpha_f, den_f = torch.zeros_like(e), torch.zeros_like(alpha), torch.zeros_like(den)
+    T.call("tnr_user_score_fwd", dev(vec), R, dev(hidx), dev(cidx), dev(mask), dv["pad"], dv["w1"], dv["b1"], dv["w2"],
+           dv["b2"], ulm, None, None, user_f, B * D, score_f, e_f, alpha_f, den_f, nm, B, U, C, D, Q)
     torch.cuda.synchronize()
+    for got, ref in ((e_f, e), (alpha_f, alpha), (den_f, den)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
     caches = []
     for z in range(nm):
         P = {"p.pad_doc": pr["pad"][z][None], "p.attn.att_fc1.weight": pr["w1"][z], "p.attn.att_fc1.bias": pr["b1"][z],
              "p.attn.att_fc2.weight": pr["w2"][z][None], "p.attn.att_fc2.bias": pr["b2"][z:z + 1]}
         uref, c = O.user_encoder_fwd(P, "p.", vec[z][hidx], mask, bool(ulm))
         caches.append((P, c))
-        np.testing.assert_allclose(user[z].cpu().numpy(), uref, rtol=1e-4, atol=1e-5)
         sref = np.einsum("bcd,bd->bc", vec[z][cidx], uref)
-        np.testing.assert_allclose(score[z].cpu().numpy(), sref, rtol=1e-4, atol=1e-4)
+        for u_, s_ in ((user, score), (user_f, score_f)):
+            np.testing.assert_allclose(u_[z].cpu().numpy(), uref, rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(s_[z].cpu().numpy(), sref, rtol=1e-4, atol=1e-4)
     # backward of model 0
     duser = rnd((B, D), 7)
     P, c = caches[0]

@@ -92,6 +92,17 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 rounding of the outputs):
 // one v_rcp + one v_exp + 6 FMAs instead of libm erff's branches.  e = exp(-z*z) is returned for reuse.
+// tanh for the additive-attention pre-activations (model_bert.py:25, :37): 1 - 2 / (e^2x + 1) on the hardware exp2 / rcp, an odd
+// polynomial below |x| = 0.06 where that form cancels.  |error| <= 3e-7 (libm's tanhf: ~1e-7, at ~60 instructions with divergent
+// branches - it made the tanh epilogue of the pooling GEMM cost as much as its K loop and was a third of the user-encoder
+// kernel).  ONE function for every kernel: a news vector must not depend on which tile kernel encoded it.
+__device__ __forceinline__ float tnr_tanh(float x) {
+    const float x2 = x * x;
+    const float p = x * (1.f - x2 * (0.33333334f - x2 * 0.13333334f));
+    const float t = 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f);
+    return fabsf(x) < 0.06f ? p : t;
+}
+
 __device__ __forceinline__ float erf_as(float z, float& e) {
     float a = fabsf(z);
     float t = __frcp_rn(1.0f + 0.3275911f * a);

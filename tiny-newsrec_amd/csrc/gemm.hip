@@ -152,7 +152,7 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& g, f32x4 (&acc)[4][4],
             }
             if (flags & TNR_EPI_TANH) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = tnr_tanh(v[r]);
             }
             if (flags & TNR_EPI_MULDGELU) {
                 if (lut) {
@@ -674,7 +674,7 @@ __device__ __forceinline__ void nt_epilogue_coalesced(const NTArgs& g, f32x4 (&a
             }
             if (flags & TNR_EPI_TANH) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = tnr_tanh(v[e]);
             }
             if (flags & TNR_EPI_MULDGELU) {
 #pragma unroll
@@ -900,7 +900,7 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
         }
         if (flags & TNR_EPI_TANH) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = tanhf(v[e]);
+            for (int e = 0; e < 16; ++e) v[e] = tnr_tanh(v[e]);
         }
         if (flags & TNR_EPI_MULDGELU) {
 #pragma unroll
@@ -1799,7 +1799,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
             const PpPlan pl = pp_plan(M, N, flags, n_cu);
             g.mix_p = pl.P; g.mix_x = pl.x;
             if (!(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
-            pp_launch<7>(g, (unsigned)std::min<int64_t>((int64_t)pl.P * (N / 256), n_cu), st);
+            pp_launch<7>(g, (unsigned)std::min<int64_t>((int64_t)pl.P * (N / 256), std::max(n_cu, 8)), st);   // >= 8: every XCD label needs a workgroup
         }
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<7>), dim3((unsigned)(((M + 223) / 224) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;
@@ -1808,7 +1808,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
             const PpPlan pl = pp_plan(M, N, flags, n_cu);
             g.mix_p = pl.P; g.mix_x = pl.x;
             if (!(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
-            pp_launch<8>(g, (unsigned)std::min<int64_t>((int64_t)pl.P * (N / 256), n_cu), st);
+            pp_launch<8>(g, (unsigned)std::min<int64_t>((int64_t)pl.P * (N / 256), std::max(n_cu, 8)), st);
         }
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<8>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
         break;

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
     for (int idx = tid; idx < U * Q; idx += 256) {
         int u = idx / Q, q = idx - u * Q;
         float pre = (user_log_mask || mask[u] != 0.f) ? epre[idx] : epad[q];
-        float ev = tanhf(pre);
+        float ev = tnr_tanh(pre);
         es[idx] = ev;
         e_out[(((int64_t)z * B + b) * U) * Q + idx] = ev;
     }
@@ -360,6 +360,146 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
     }
     __syncthreads();
     for (int c = w; c < C; c += 4) {
+        const float* cr = vec + (int64_t)cidx[c] * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += cr[d] * us[d];
+        s = wave_sum(s);
+        if (lane == 0) score[((int64_t)z * B + b) * C + c] = s;
+    }
+}
+
+// The same forward with fc1 INSIDE (epre == NULL at the entry point): one launch per user-encoder pass instead of a batched fp32
+// GEMM + its split-K reduce + an M = 1 GEMM pair for fc1(pad_doc) + the kernel above (77 us of launches for 0.17 GFLOP at
+// B = 32).  One workgroup per (impression, model) as before; the blended history rows sit in LDS ([64][D + 4], rows >= U zero)
+// and are the A operand of 32x32x2 fp32 MFMAs against W1 rows read straight from global memory (205 KB per model, L2-resident
+// across the impressions): lane (j, h) of a 32 x 32 (slot, unit) block takes k = 8 t + 4 h .. + 3 of both operands with one
+// 16-byte access each and feeds four MFMAs - a fixed permutation of the fp32 sum over k.  fc1 of a masked slot is fc1 of the
+// blended row (= fc1(pad_doc) for a 0 / 1 mask, model_bert.py:162-164), so there is no separate pad path.
+#ifndef TNR_UF_SKIP
+#define TNR_UF_SKIP 0                          // probe builds: 1 no fc1 MFMA loop, 2 no tanh / e store, 4 no gather of the history rows
+#endif
+constexpr int UF_XTRA = 4;                     // LDS row pitch D + 4 floats: 16-byte aligned rows, banks shifted by 4 per row
+constexpr int UF_THREADS = 512;                // two waves per SIMD: one wave's W1 loads fly under the other's MFMAs
+__global__ __launch_bounds__(UF_THREADS) void user_fwd_fused_kernel(
+    const float* __restrict__ vec, int64_t R, const int32_t* __restrict__ hidx, const int32_t* __restrict__ cidx,
+    const float* __restrict__ mask, const float* __restrict__ pad, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int user_log_mask,
+    float* __restrict__ user, int64_t user_stride, float* __restrict__ score, float* __restrict__ e_out,
+    float* __restrict__ alpha, float* __restrict__ den, int B, int U, int C, int D, int Q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int P = D + UF_XTRA;
+    float* hv = (float*)smem;                 // [64][P]
+    float* es = hv + 64 * P;                  // [U][Q]
+    float* al = es + U * Q;                   // [MAXU]
+    float* us = al + MAXU;                    // [D]
+    const int b = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    vec += (int64_t)z * R * D;
+    pad += (int64_t)z * D;
+    w1 += (int64_t)z * Q * D;
+    b1 += (int64_t)z * Q;
+    w2 += (int64_t)z * Q;
+    hidx += (int64_t)b * U;
+    cidx += (int64_t)b * C;
+    mask += (int64_t)b * U;
+    for (int t = tid; t < 64 * (D / 4); t += UF_THREADS) {
+        const int u = t / (D / 4), c = (t - u * (D / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (u < U && !(TNR_UF_SKIP & 4)) {
+            v = *(const f32x4*)(vec + (int64_t)hidx[u] * D + c);
+            if (!user_log_mask) {
+                const float m = mask[u];
+                const f32x4 p = *(const f32x4*)(pad + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * m + p[r] * (1.f - m);
+            }
+        }
+        *(f32x4*)(hv + u * P + c) = v;
+    }
+    __syncthreads();
+    // e = tanh(hv W1^T + b1): (slot block, unit block) pairs round-robin over the waves
+    const int nub = (U + 31) >> 5, nqb = (Q + 31) >> 5;
+    const int j = lane & 31, h = lane >> 5;
+    for (int pr = w; pr < nub * nqb; pr += UF_THREADS / 64) {
+        const int ub = pr % nub, qb = pr / nub;
+        const int q = qb * 32 + j;
+        const float* ap = hv + (ub * 32 + j) * P + 4 * h;
+        const float* bp = w1 + (int64_t)(q < Q ? q : Q - 1) * D + 4 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        int t = 0;
+        f32x4 bn[4];                               // the W1 operand of the NEXT 32 k values: requested before this group's MFMAs
+        if (D >= 32) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bn[g] = *(const f32x4*)(bp + 8 * g);
+        }
+        if (TNR_UF_SKIP & 1) t = D;
+        for (; t + 32 <= D; t += 32) {
+            f32x4 a4[4], b4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                a4[g] = *(const f32x4*)(ap + t + 8 * g);
+                b4[g] = bn[g];
+            }
+            if (t + 64 <= D) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bn[g] = *(const f32x4*)(bp + t + 32 + 8 * g);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g][m], b4[g][m], acc, 0, 0, 0);
+        }
+        for (; t < D; t += 8) {
+            const f32x4 a4 = *(const f32x4*)(ap + t);
+            const f32x4 b4 = *(const f32x4*)(bp + t);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m], b4[m], acc, 0, 0, 0);
+        }
+        if (q < Q && !(TNR_UF_SKIP & 2)) {
+            const float bq = b1[q];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = ub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (u < U) {
+                    const float ev = tnr_tanh(acc[r] + bq);
+                    es[u * Q + q] = ev;
+                    e_out[(((int64_t)z * B + b) * U + u) * Q + q] = ev;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int u = w; u < U; u += UF_THREADS / 64) {
+        float s = 0.f;
+        for (int q = lane; q < Q; q += 64) s += es[u * Q + q] * w2[q];
+        s = wave_sum(s);
+        if (lane == 0) {
+            float a = __expf(s + b2[z]);
+            if (user_log_mask) a *= mask[u];
+            al[u] = a;
+        }
+    }
+    __syncthreads();
+    float dsum = 0.f;
+    for (int u = 0; u < U; ++u) dsum += al[u];
+    dsum += 1e-8f;
+    __syncthreads();                           // everyone has read the un-normalised weights
+    if (tid < U) {
+        const float a = al[tid] / dsum;
+        al[tid] = a;
+        alpha[((int64_t)z * B + b) * U + tid] = a;
+    }
+    if (tid == 0) den[(int64_t)z * B + b] = dsum;
+    __syncthreads();
+    for (int d = tid; d < D; d += UF_THREADS) {
+        float s = 0.f;
+        for (int u = 0; u < U; ++u) s += al[u] * hv[u * P + d];
+        us[d] = s;
+        user[(int64_t)z * user_stride + (int64_t)b * D + d] = s;
+    }
+    __syncthreads();
+    for (int c = w; c < C; c += UF_THREADS / 64) {
         const float* cr = vec + (int64_t)cidx[c] * D;
         float s = 0.f;
         for (int d = lane; d < D; d += 64) s += cr[d] * us[d];
@@ -875,10 +1015,24 @@ extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hi
                                   int64_t user_stride,
                                   float* score, float* e, float* alpha, float* den, int n_model, int B, int U, int C, int D,
                                   int Q, void* stream) {
-    TNR_CHECK_ARG(vec && hidx && cidx && mask && pad && w1 && b1 && w2 && b2 && epre && user && score && e && alpha && den,
+    TNR_CHECK_ARG(vec && hidx && cidx && mask && pad && w1 && b1 && w2 && b2 && user && score && e && alpha && den,
                   "tnr_user_score_fwd: null pointer");
     TNR_CHECK_ARG(user_shape_ok(B, U, C, D, Q) && n_model >= 1 && user_stride >= (int64_t)B * D,
                   "tnr_user_score_fwd: bad shape (U <= %d)", MAXU);
+    if (!epre) {                               // fc1 inside the kernel
+        size_t lf = sizeof(float) * ((size_t)64 * (D + UF_XTRA) + (size_t)U * Q + MAXU + D);
+        TNR_CHECK_ARG((D % 8) == 0 && lf <= 160 * 1024, "tnr_user_score_fwd: fused fc1 needs D %% 8 == 0 and 64 (D + 4) + U Q floats of LDS");
+        static bool fattr_set = false;
+        if (!fattr_set) {
+            (void)hipFuncSetAttribute((const void*)user_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            fattr_set = true;
+        }
+        hipLaunchKernelGGL(user_fwd_fused_kernel, dim3((unsigned)B, (unsigned)n_model), dim3(UF_THREADS), lf, (hipStream_t)stream,
+                           vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, user, user_stride, score, e, alpha, den,
+                           B, U, C, D, Q);
+        TNR_CHECK_LAUNCH("tnr_user_score_fwd");
+        return TNR_OK;
+    }
     size_t lds = sizeof(float) * ((size_t)U * D + (size_t)U * Q + MAXU + D + Q + 4);
     TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_score_fwd: U*D + U*Q too large for LDS");
     static bool attr_set = false;
