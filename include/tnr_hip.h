@@ -86,7 +86,12 @@ int tnr_embed_ln_fwd_indexed(const int32_t* news_combined, const int32_t* nidx, 
 
 /* C[M,N] = epilogue(A[M,K] . B[N,K]^T).  bf16 operands, fp32 MFMA accumulation.
  * Forward Linear (tnlrv3/modeling.py:236-248, transformers BertSelfOutput/BertIntermediate/BertOutput),
- * and its dgrad when B is the transposed weight copy.  N % 128 == 0, K % 64 == 0, any M >= 1. */
+ * and its dgrad when B is the transposed weight copy.  N % 128 == 0, K % 64 == 0, any M >= 1.
+ * Streams and threads: every entry point enqueues on `stream` and returns; calls may come from any thread.  The
+ * persistent 256-column kernel hands its tiles out from a small counter block the library keeps per (device, stream) and
+ * that the last workgroup of a launch zeroes again - launches of one stream are ordered, so each finds it zeroed; launches
+ * on different streams use different blocks and may overlap (e.g. a collective on another stream: the workgroups that do
+ * get a CU pull the tiles of those that do not). */
 int tnr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                 int64_t M, int64_t N, int64_t K, const float* bias, const void* res, int64_t ldres,
                 void* aux, int64_t ldaux, int flags, void* stream);

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libtnr_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -46,6 +47,20 @@ struct TnrGemmOpts {
     int probe;       // timing probes of the ping-pong kernel (only in -DTNR_PROBES builds, tools/probe_build.sh)
 };
 TnrGemmOpts* tnr_gemm_opts();
+
+// Runs `body` once per device of this process (function attributes such as the dynamic LDS limit are set per device); two
+// threads racing through it both run the idempotent body.
+#define TNR_ONCE_PER_DEVICE(body)                                                       \
+    do {                                                                                \
+        static std::atomic<unsigned long long> tnr_done_{0};                            \
+        int tnr_dev_ = 0;                                                               \
+        (void)hipGetDevice(&tnr_dev_);                                                  \
+        const unsigned long long tnr_bit_ = 1ull << (tnr_dev_ & 63);                    \
+        if (!(tnr_done_.load(std::memory_order_acquire) & tnr_bit_)) {                  \
+            body;                                                                       \
+            tnr_done_.fetch_or(tnr_bit_, std::memory_order_release);                    \
+        }                                                                               \
+    } while (0)
 
 #define TNR_CHECK_ARG(cond, ...)          \
     do {                                  \

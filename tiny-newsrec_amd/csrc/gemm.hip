@@ -1771,20 +1771,18 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
 #ifdef TNR_PROBES
     g.probe = o.probe;
 #endif
-    static bool attr_set = false;       // function attributes are per code object, not per device
-    if (!attr_set) {
+#define TNR_PP_ATTR(CF)                                                                                                     \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<8, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<7, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+    TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + LUT_N * 8);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt256x256_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES);
-#define TNR_PP_ATTR(CF)                                                                                                     \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<8, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); \
-        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<7, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         TNR_PP_FLAG_SETS(TNR_PP_ATTR)
         TNR_PP_ATTR(-1)
+    });
 #undef TNR_PP_ATTR
-        attr_set = true;
-    }
     hipStream_t st = (hipStream_t)stream;
     const int n_cu = device_cus();
     switch (nt_route(M, N, K, flags, n_cu)) {
@@ -1836,13 +1834,11 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
     splits = (Mt + tps - 1) / tps;
     TNArgs g{(const bf16*)dY, lddy, (const bf16*)X, ldx, ws, Mt, (int)N, (int)K, tps, splits};
     const int ver = tnr_gemm_opts()->ver;
-    static bool attr_set = false;
-    if (!attr_set) {
+    TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_tn256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
-        attr_set = true;
-    }
+    });
     if (ver == 1 || (N % 256) != 0) {
         dim3 grid((unsigned)((N / 128) * (K / 128) * splits));
         hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 2 * BUF_BYTES, (hipStream_t)stream, g);

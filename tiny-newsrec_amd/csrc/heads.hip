@@ -1022,11 +1022,9 @@ extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hi
     if (!epre) {                               // fc1 inside the kernel
         size_t lf = sizeof(float) * ((size_t)64 * (D + UF_XTRA) + (size_t)U * Q + MAXU + D);
         TNR_CHECK_ARG((D % 8) == 0 && lf <= 160 * 1024, "tnr_user_score_fwd: fused fc1 needs D %% 8 == 0 and 64 (D + 4) + U Q floats of LDS");
-        static bool fattr_set = false;
-        if (!fattr_set) {
+        TNR_ONCE_PER_DEVICE({
             (void)hipFuncSetAttribute((const void*)user_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            fattr_set = true;
-        }
+        });
         hipLaunchKernelGGL(user_fwd_fused_kernel, dim3((unsigned)B, (unsigned)n_model), dim3(UF_THREADS), lf, (hipStream_t)stream,
                            vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, user, user_stride, score, e, alpha, den,
                            B, U, C, D, Q);
@@ -1035,11 +1033,9 @@ extern "C" int tnr_user_score_fwd(const float* vec, int64_t R, const int32_t* hi
     }
     size_t lds = sizeof(float) * ((size_t)U * D + (size_t)U * Q + MAXU + D + Q + 4);
     TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_score_fwd: U*D + U*Q too large for LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)user_score_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(user_score_fwd_kernel, dim3((unsigned)B, (unsigned)n_model), dim3(256), lds, (hipStream_t)stream,
                        vec, R, hidx, cidx, mask, pad, w1, b1, w2, b2, user_log_mask, epre, epad, user, user_stride, score, e, alpha,
                        den, B, U, C, D, Q);
@@ -1056,11 +1052,9 @@ extern "C" int tnr_user_bwd_pre(const float* vec, const int32_t* hidx, const flo
     TNR_CHECK_ARG(user_shape_ok(B, U, 0, D, Q), "tnr_user_bwd_pre: bad shape (U <= %d)", MAXU);
     size_t lds = sizeof(float) * ((size_t)U * D + 2 * MAXU);
     TNR_CHECK_ARG(lds <= 160 * 1024, "tnr_user_bwd_pre: too large for LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)user_bwd_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(user_bwd_pre_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, vec, hidx, mask, pad, w2,
                        user_log_mask, duser, e, alpha, hv, dpre, part, U, D, Q);
     TNR_CHECK_LAUNCH("tnr_user_bwd_pre");
@@ -1110,11 +1104,9 @@ extern "C" int tnr_nrms_attn_fwd(const float* qkv, const float* mask, int use_ma
     TNR_CHECK_ARG(qkv && ctx && (!use_mask || mask) && n_model >= 1 && B >= 1 && ctx_rows >= (int64_t)B * U,
                   "tnr_nrms_attn_fwd: bad argument");
     TNR_CHECK_ARG(nrms_lds_ok(U, n_heads, &lds, false), "tnr_nrms_attn_fwd: U * heads * 16 too large for LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)nrms_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(nrms_attn_fwd_kernel, dim3((unsigned)B, (unsigned)n_model), dim3(256), lds, (hipStream_t)stream, qkv,
                        mask, use_mask, ctx, ctx_rows, B, U, n_heads);
     TNR_CHECK_LAUNCH("tnr_nrms_attn_fwd");
@@ -1126,11 +1118,9 @@ extern "C" int tnr_nrms_attn_bwd(const float* qkv, const float* mask, int use_ma
     size_t lds;
     TNR_CHECK_ARG(qkv && dctx && dqkv && (!use_mask || mask) && B >= 1, "tnr_nrms_attn_bwd: bad argument");
     TNR_CHECK_ARG(nrms_lds_ok(U, n_heads, &lds, true), "tnr_nrms_attn_bwd: U * heads * 16 too large for LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)nrms_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(nrms_attn_bwd_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, qkv, mask, use_mask, dctx,
                        dqkv, U, n_heads);
     TNR_CHECK_LAUNCH("tnr_nrms_attn_bwd");
