@@ -6,7 +6,7 @@ B=32 synthetic MIND-shaped impressions per GPU (run.py:178-195), 4-layer student
 Inputs (token table, teacher tables, pre-drawn impression indices) are resident in HBM before the
 timed region.  Prints ONE JSON line on rank 0 (contract in the task statement).
 
-  python bench.py --gpus 1 --steps 50 --warmup 10
+  python bench.py --gpus 1 --steps 200 --warmup 20      (the defaults: SURVEY 8-d)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 """
@@ -115,8 +115,8 @@ def lib_sha16():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)       # 20 warm-up + 200 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="impressions per GPU per step (demo.sh:8)")
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--trainable", type=int, nargs="+", default=None)
@@ -279,18 +279,19 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (tools/pmc.sh); it is only quoted while
             # the profiled library is byte-identical to the one running now
-            traffic, pj = None, os.path.join(ROOT, "profiles", "r02_gemm_nt_pmc.json")
+            traffic, busy, pj = None, None, os.path.join(ROOT, "profiles", "r02_gemm_nt_pmc.json")
             if os.path.exists(pj):
                 pm = json.load(open(pj))
                 if pm.get("lib_sha16") == lib_sha16() and pm.get("dtype") == a.dtype:
                     traffic = pm.get("hbm_bytes_per_launch")
+                    busy = pm.get("mfma_busy_frac")          # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE): SURVEY 8-d's "MFMA utilisation"
             names = {128: "gemm_nt_kernel(128x128)", 2128: "gemm_nt256_kernel(256x128)", 256: "gemm_nt_pp_kernel<8,*>(256-row tiles)",
                      224: "gemm_nt_pp_kernel<7,*>(224-row tiles)"}
             out["roofline"] = {"bound": "mfma",
                                "kernel": "NT GEMM family (%s MFMA 16x16x32, every forward / dgrad Linear incl. fused epilogues): %s"
                                          % (a.dtype, ", ".join(sorted({names.get(r, str(r)) for r in routes.values()}))),
                                "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                               "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": traffic,
+                               "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": traffic, "mfma_busy_pmc": busy,
                                "launches": len(rec), "launches_timed_every_nth_step": EVENT_EVERY,
                                "avg_launch_us": round(1e3 * ms / len(rec), 2),
                                "algorithmic_flops_per_launch": fl / len(rec)}
