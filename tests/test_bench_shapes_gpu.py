@@ -228,3 +228,36 @@ def test_b32_forward_matches_oracle(dtype):
     rms = float(np.sqrt((err.astype(np.float64) ** 2).mean()))
     print("B=32 forward %s: score err / max(1,|ref|): max %.2e rms %.2e, |logit| max %.2f" % (dtype, err.max(), rms, np.abs(rs_).max()))
     assert err.max() <= tol_max and rms <= tol_rms
+
+
+def test_b32_training_is_bit_reproducible_run_to_run():
+    """Two identical runs of the benchmark's step (B=32: multi-round grids of the queue-fed GEMM, one-round weight gradients,
+    fixed-order reductions everywhere): every loss and the parameters after the updates agree bit for bit - the tile queue
+    changes which workgroup computes a tile, never what it computes (tools/scratch/determinism_soak.py: the same over 400 steps)."""
+    import engine as E
+    import hashinit
+    import synth
+    from schema import FULL, state_shapes
+    nl, T_, B, n_news, steps = 4, 4, 32, 4000, 4
+    cfg = E.EngineConfig(n_layers=nl, trainable_layers=(2, 3), num_teachers=T_)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    comb, tabs = d(synth.news_table(1234, n_news, cfg.L)), d(synth.teacher_tables(1234, T_, n_news, cfg.D))
+    hidx, mask, cidx, label = [d(x) for x in synth.impressions(1235, steps * B, n_news, cfg.U, cfg.C)]
+    P = hashinit.init_state_dict(1234, state_shapes(FULL, nl, cfg.D, T_))
+
+    def run():
+        eng = E.Engine(cfg, DEV, max_batch=B, dtype="fp16")
+        eng.load_state_dict(P)
+        ls = []
+        for i in range(steps):
+            s = slice(i * B, (i + 1) * B)
+            l, _ = eng.forward_indexed(comb, hidx[s], mask[s], cidx[s], label[s], tabs)
+            ls.append(l.clone())
+            eng.backward()
+            eng.step(lr=1e-4)
+        torch.cuda.synchronize()
+        return torch.stack(ls).cpu(), eng.flat[True].cpu().clone(), eng.flat_g.cpu().clone()
+
+    a, b = run(), run()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
