@@ -119,6 +119,10 @@ int tnr_gemm_set_option(const char* key, int value);
  * at row (32 * mi - 32) * p + 32 * floor(p * tall / panels).  Chosen so that panels * N / 256 tiles fill whole rounds of the
  * workgroups (option "mix" = 0: one height).  Results do not depend on the tiling (a row's K order is the same). */
 int tnr_gemm_nt_plan(int64_t M, int64_t N, int flags, int n_cu, int* mi, int* panels, int* tall);
+/* Test hook: n_wg workgroups that each occupy a whole CU (all of its LDS) for `us` microseconds on `stream` - what an overlapped
+ * collective's kernel does to the CUs.  The parity tests run the persistent GEMM beside it (late-starting workgroups, tiles
+ * taken over by the others); tools/cu_contention.py times it. */
+int tnr_debug_cu_hog(int n_wg, int us, void* stream);
 
 /* dW[N,K] (fp32) = dY[M,N]^T . X[M,K] : weight gradient of a Linear.  Reduction over M is split into
  * `splits` slabs in `ws` (fp32, splits*N*K elements) and summed in fixed order (deterministic).

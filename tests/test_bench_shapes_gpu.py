@@ -261,3 +261,56 @@ def test_b32_training_is_bit_reproducible_run_to_run():
     a, b = run(), run()
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_gemm_beside_held_cus_is_bit_identical():
+    """The persistent NT kernel while another stream's kernel holds 24 CUs (tnr_debug_cu_hog: what the RCCL kernels of an
+    overlapped all-reduce do): the workgroups that get no CU at launch start late and find the queue drained, the others take
+    their tiles - same bits as the undisturbed launch, for a plain, a residual and a gelu' + column-sum launch; the
+    weight-gradient kernel (a static one-round grid) as well."""
+    M = M_BENCH
+    td = torch.float16
+    side = torch.cuda.Stream()
+    rs = np.random.RandomState(3)
+    for (N, K, flags) in ((3072, 768, 0), (768, 3072, T.EPI_BIAS | T.EPI_RES), (3072, 768, T.EPI_MULDGELU | T.EPI_COLSUM)):
+        a = torch.from_numpy(rs.randn(M, K).astype(np.float32) * 0.5).to(DEV).to(td)
+        b = torch.from_numpy(rs.randn(N, K).astype(np.float32) * 0.05).to(DEV).to(td)
+        bias = torch.from_numpy(rs.randn(N).astype(np.float32)).to(DEV)
+        res = torch.from_numpy(rs.randn(M, N).astype(np.float32) * 0.3).to(DEV).to(td) if flags & (T.EPI_RES | T.EPI_MULDGELU) else None
+        csrows = T.query("tnr_gemm_colsum_rows_f16", M)
+        outs = []
+        for hog in (0, 24):
+            c = torch.zeros((M, N), device=DEV, dtype=td)
+            cs = torch.zeros((csrows, N), device=DEV) if flags & T.EPI_COLSUM else None
+            torch.cuda.synchronize()
+            if hog:
+                with torch.cuda.stream(side):
+                    T.call("tnr_debug_cu_hog", hog, 1500)
+                torch.cuda._sleep(400000)                # let it take its CUs first
+            for _ in range(3):                           # three launches inside the 1.5 ms: a late workgroup of one must not disturb the next
+                T.call("tnr_gemm_nt_ex_f16", a, K, b, K, c, N, M, N, K, bias if flags & T.EPI_BIAS else None,
+                       res if flags & T.EPI_RES else None, N if flags & T.EPI_RES else 0,
+                       res if flags & T.EPI_MULDGELU else None, N if flags & T.EPI_MULDGELU else 0, flags, cs)
+            torch.cuda.synchronize()
+            outs.append((c, cs))
+        assert torch.equal(outs[0][0], outs[1][0]), (N, K, flags)
+        if outs[0][1] is not None:
+            assert torch.equal(outs[0][1], outs[1][1])
+    N, K = 3072, 768
+    Mp = (M + 127) // 128 * 128
+    dy = torch.zeros((Mp, N), device=DEV, dtype=td); dy[:M] = torch.from_numpy(rs.randn(M, N).astype(np.float32) * 0.1).to(DEV).to(td)
+    x = torch.zeros((Mp, K), device=DEV, dtype=td); x[:M] = torch.from_numpy(rs.randn(M, K).astype(np.float32)).to(DEV).to(td)
+    sp = 7
+    ws = torch.zeros(int(T.query("tnr_gemm_tn_ws_elems", N, K, sp)), device=DEV)
+    dws = []
+    for hog in (0, 24):
+        dw = torch.zeros((N, K), device=DEV)
+        torch.cuda.synchronize()
+        if hog:
+            with torch.cuda.stream(side):
+                T.call("tnr_debug_cu_hog", hog, 1500)
+            torch.cuda._sleep(400000)
+        T.call("tnr_gemm_tn_wgrad_f16", dy, N, x, K, dw, K, M, N, K, ws, sp, 0)
+        torch.cuda.synchronize()
+        dws.append(dw)
+    assert torch.equal(dws[0], dws[1])
