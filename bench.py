@@ -285,8 +285,8 @@ def main():
                 if pm.get("lib_sha16") == lib_sha16() and pm.get("dtype") == a.dtype:
                     traffic = pm.get("hbm_bytes_per_launch")
                     busy = pm.get("mfma_busy_frac")          # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE): SURVEY 8-d's "MFMA utilisation"
-            names = {128: "gemm_nt_kernel(128x128)", 2128: "gemm_nt256_kernel(256x128)", 256: "gemm_nt_pp_kernel<8,*>(256-row tiles)",
-                     224: "gemm_nt_pp_kernel<7,*>(224-row tiles)"}
+            names = {128: "gemm_nt_kernel(128x128)", 2128: "gemm_nt256_kernel(256x128)", 256: "gemm_nt_pp_kernel<8,*>(256- / 224-row tiles)",
+                     224: "gemm_nt_pp_kernel<7,*>(224- / 192-row tiles)"}
             out["roofline"] = {"bound": "mfma",
                                "kernel": "NT GEMM family (%s MFMA 16x16x32, every forward / dgrad Linear incl. fused epilogues): %s"
                                          % (a.dtype, ", ".join(sorted({names.get(r, str(r)) for r in routes.values()}))),
