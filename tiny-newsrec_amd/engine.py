@@ -525,11 +525,12 @@ class Engine:
 
     def _sgemm(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, ksplit=None, alpha=1.0,
                beta=0.0):
-        """ksplit None: K is split into slices of >= 128 (a workgroup's time on the fp32 MFMA is ~K * 32 cycles whatever the
-        tile count, and these GEMMs have few tiles).  The split depends on K ALONE, never on the row count: a news vector must
+        """ksplit None: K is split into slices of >= 256 (a workgroup's time on the fp32 MFMA is ~K * 32 cycles whatever the
+        tile count, and these GEMMs have few tiles; slices of 128 cost a split-reduce launch for the K = 256 GEMMs and were 0.3 %
+        slower on the step, `AB=sg_kdiv:128:256 tools/step_ab.py`).  The split depends on K ALONE, never on the row count: a news vector must
         come out with the same bits whatever batch it is encoded in (in-batch de-duplication, frozen-layer cache)."""
         if ksplit is None:
-            ksplit = max(1, min(K // 128, 8))
+            ksplit = max(1, min(K // getattr(self, "sg_kdiv", 256), 8))
             assert ksplit * batch * M * N <= self.sg_part.numel(), "fp32 GEMM workspace too small for its K split"
         T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, alpha, beta,
                ksplit, self.sg_part if ksplit > 1 else None)

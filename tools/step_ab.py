@@ -28,6 +28,8 @@ for rnd in range(6):
     for v in ((0, 1) if rnd % 2 == 0 else (1, 0)):
         if KEY == "teacher_stream":        # engine-level switch: the teacher side of the forward on a second stream
             eng.teacher_stream = side if int(VALS[v]) else None
+        elif KEY == "sg_kdiv":             # engine-level: K per split of the small fp32 GEMMs
+            eng.sg_kdiv = int(VALS[v])
         else:
             T.lib().tnr_gemm_set_option(KEY.encode(), int(VALS[v]))
         for i in range(3): step(i)
