@@ -784,7 +784,7 @@ class Engine:
         cfg = self.cfg
         U, D, Qu, ulm = cfg.U, cfg.D, cfg.Qu, int(cfg.user_log_mask)
         if not cfg.nrms_heads:
-            if D % 8 == 0 and 4 * (64 * (D + 4) + U * Qu + 64 + D) <= 160 * 1024:
+            if getattr(self, "fused_user_fwd", True) and D % 8 == 0 and 4 * (64 * (D + 4) + U * Qu + 64 + D) <= 160 * 1024:
                 # fc1 inside the kernel: one launch per pass (was: batched fp32 GEMM + split reduce + fc1(pad) pair + this kernel)
                 T.call("tnr_user_score_fwd", vec, R, hidx, cidx, mask, p["pad"], p["w1"], p["b1"], p["w2"], p["b2"], ulm, None, None,
                        user, user_stride, score, e, alpha, den, nm, B, U, C, D, Qu)

@@ -44,7 +44,11 @@ for case in range(n_cases):
     ec = E.EngineConfig(n_layers=nl, trainable_layers=tr, num_teachers=T_, user_log_length=U, npratio=C - 1, num_words=L, news_dim=D,
                         news_query=Q, user_query=Q, user_log_mask=ulm, temperature=tau, coef=coef, pooling=pooling,
                         nrms_heads=16 if nrms else 0)
+    if os.environ.get("ONLY") and case != int(os.environ["ONLY"]):     # same random stream, one case (ONLY=35), e.g. with
+        continue                                                         # USER_FUSED=0 / SG_KDIV=128 to bisect a failure
     eng = E.Engine(ec, "cuda:0", max_batch=B, dtype=DTYPE)
+    if os.environ.get("USER_FUSED") == "0": eng.fused_user_fwd = False
+    if os.environ.get("SG_KDIV"): eng.sg_kdiv = int(os.environ["SG_KDIV"])
     eng.load_state_dict(P)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
     losses, score = eng.forward(t(hist), t(mask), t(cand), t(label), [t(x) for x in th], [t(x) for x in tc])
@@ -63,6 +67,7 @@ for case in range(n_cases):
         if rn < 1e-4 * top: continue
         err = np.sqrt(((eng.grad(k).cpu().numpy() - ref).astype(np.float64) ** 2).sum()) / rn
         if err > worst: worst, wk = err, k
+        if os.environ.get("ONLY") and err > 0.5 * TOLS[2]: print("   %-60s |ref| %.3e (top %.3e) err %.2e" % (k, rn, top, err))
     ok = le < TOLS[0] and se < TOLS[1] and worst < TOLS[2] and np.isfinite(le + se + worst)
     bad += not ok
     print("%s case %2d nl=%d tr=%s B=%d U=%d C=%d L=%d D=%d Q=%d T=%d ulm=%d pool=%s nrms=%d : loss %.1e score %.1e grad %.1e %s" % (
