@@ -11,7 +11,10 @@
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
  *   - return 0 on success, a negative TNR_E* code otherwise; tnr_last_error()
  *     returns a thread-local message; no C++ exception crosses the boundary;
- *   - the library never calls hipSetDevice: the caller's current device rules;
+ *   - the library never calls hipSetDevice / hipDeviceSynchronize / hipStreamSynchronize: the caller's current device
+ *     rules and nothing ever blocks the host;
+ *   - device state kept by the library: ONE thing, the tile-queue counters of the persistent GEMM (see
+ *     tnr_gemm_queue_reset below); everything else lives in caller-owned buffers;
  *   - 16-bit activations are bf16 (TNR_BF16); "ld" arguments are row strides in
  *     ELEMENTS; row-major everywhere.
  */
@@ -61,7 +64,8 @@ const char* tnr_last_error(void);
 /* Collectives are NOT part of this ABI: the gradient average of the reference (hvd.DistributedOptimizer / hvd.allreduce,
  * Tiny-NewsRec/run.py:141-149, utils.py:43-60) is done by the caller with torch.distributed (backend "nccl" = RCCL) on the
  * flat gradient buffer (tiny-newsrec_amd/dist.py); every entry point here is a single-device operation on the stream passed
- * last and the library holds no communicator, device or stream state of its own. */
+ * last and the library holds no communicator; the only per-(device, stream) state it keeps is the GEMM's tile-queue counter
+ * table described at tnr_gemm_queue_reset. */
 
 /* ---- encoder --------------------------------------------------------------------------------- */
 
@@ -119,10 +123,15 @@ int tnr_gemm_set_option(const char* key, int value);
  * at row (32 * mi - 32) * p + 32 * floor(p * tall / panels).  Chosen so that panels * N / 256 tiles fill whole rounds of the
  * workgroups (option "mix" = 0: one height).  Results do not depend on the tiling (a row's K order is the same). */
 int tnr_gemm_nt_plan(int64_t M, int64_t N, int flags, int n_cu, int* mi, int* panels, int* tall);
-/* Test hook: n_wg workgroups that each occupy a whole CU (all of its LDS) for `us` microseconds on `stream` - what an overlapped
- * collective's kernel does to the CUs.  The parity tests run the persistent GEMM beside it (late-starting workgroups, tiles
- * taken over by the others); tools/cu_contention.py times it. */
-int tnr_debug_cu_hog(int n_wg, int us, void* stream);
+/* The persistent 256-column GEMM kernel (tnr_gemm_nt* on the TNR_ROUTE_256x256 / 224x256 routes) hands out its tiles through
+ * nine 32-bit counters per (device, stream) pair, kept in a 128-entry table inside the library (a __device__ array; 288 KB).
+ * A pair is bound at its first launch (its counters are zeroed by a hipMemsetAsync on that stream) and every completed launch
+ * returns them to zero, so launches need no workspace argument.  The table is never drained and the current device is never
+ * changed: the 129th distinct pair is refused with TNR_EUNSUPPORTED (run fewer streams, or tnr_gemm_set_option("pp", 0) for
+ * the non-persistent kernel).  tnr_gemm_queue_reset zeroes the calling stream's counters again (stream-ordered): only needed
+ * after a launch on that stream was aborted (a device fault survived by the process), never in normal operation.
+ * (Test hooks such as the CU hog live in libtnr_testhooks.so, built beside this library for tests/ and tools/ only.) */
+int tnr_gemm_queue_reset(void* stream);
 
 /* dW[N,K] (fp32) = dY[M,N]^T . X[M,K] : weight gradient of a Linear.  Reduction over M is split into
  * `splits` slabs in `ws` (fp32, splits*N*K elements) and summed in fixed order (deterministic).

@@ -10,6 +10,16 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 from schema import FULL, TINY, state_shapes  # noqa: E402,F401  (kept importable from tests.helpers)
 
 
+def test_hooks():
+    """libtnr_testhooks.so (csrc/testhooks.hip): the CU hog used by the contention tests.  Not part of the product library."""
+    import ctypes
+    import tnr_hip
+    L = ctypes.CDLL(os.path.join(os.path.dirname(tnr_hip.LIB_PATH), "libtnr_testhooks.so"))
+    L.tnr_debug_cu_hog.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.tnr_debug_cu_hog.restype = ctypes.c_int
+    return L
+
+
 def load_case(name):
     """-> (z npz, P weights, cfg, inputs tuple)."""
     z = np.load(os.path.join(GOLDEN, name))

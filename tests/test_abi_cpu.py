@@ -20,6 +20,22 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(T.EXPORTS), declared ^ set(T.EXPORTS)
 
 
+def test_library_never_switches_or_drains_a_device():
+    """include/tnr_hip.h: the library never calls hipSetDevice / hipDeviceSynchronize / hipStreamSynchronize (the caller's current
+    device rules, nothing blocks the host) -- checked on the dynamic symbol table of the shipped .so; and it exports no test
+    hook (those live in libtnr_testhooks.so)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", T.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    undefined = set(re.findall(r"\bU\s+(\w+)", out))
+    assert "hipLaunchKernel" in undefined or any(u.startswith("hipLaunch") or u.startswith("__hipPushCallConfiguration") for u in undefined)
+    for banned in ("hipSetDevice", "hipDeviceSynchronize", "hipStreamSynchronize", "hipDeviceReset", "hipMalloc", "hipFree"):
+        assert banned not in undefined, "libtnr_hip.so imports %s" % banned
+    exported = subprocess.run(["nm", "-D", "--defined-only", T.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "tnr_debug" not in exported
+    hooks = os.path.join(os.path.dirname(T.LIB_PATH), "libtnr_testhooks.so")
+    assert os.path.exists(hooks) and hasattr(ctypes.CDLL(hooks), "tnr_debug_cu_hog")
+
+
 def test_version_without_gpu():
     assert T.query("tnr_version") == 1
 

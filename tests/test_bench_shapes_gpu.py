@@ -268,6 +268,8 @@ def test_gemm_beside_held_cus_is_bit_identical():
     overlapped all-reduce do): the workgroups that get no CU at launch start late and find the queue drained, the others take
     their tiles - same bits as the undisturbed launch, for a plain, a residual and a gelu' + column-sum launch; the
     weight-gradient kernel (a static one-round grid) as well."""
+    from helpers import test_hooks
+    hooks = test_hooks()
     M = M_BENCH
     td = torch.float16
     side = torch.cuda.Stream()
@@ -285,7 +287,7 @@ def test_gemm_beside_held_cus_is_bit_identical():
             torch.cuda.synchronize()
             if hog:
                 with torch.cuda.stream(side):
-                    T.call("tnr_debug_cu_hog", hog, 1500)
+                    assert hooks.tnr_debug_cu_hog(hog, 1500, side.cuda_stream) == 0
                 torch.cuda._sleep(400000)                # let it take its CUs first
             for _ in range(3):                           # three launches inside the 1.5 ms: a late workgroup of one must not disturb the next
                 T.call("tnr_gemm_nt_ex_f16", a, K, b, K, c, N, M, N, K, bias if flags & T.EPI_BIAS else None,
@@ -308,7 +310,7 @@ def test_gemm_beside_held_cus_is_bit_identical():
         torch.cuda.synchronize()
         if hog:
             with torch.cuda.stream(side):
-                T.call("tnr_debug_cu_hog", hog, 1500)
+                assert hooks.tnr_debug_cu_hog(hog, 1500, side.cuda_stream) == 0
             torch.cuda._sleep(400000)
         T.call("tnr_gemm_tn_wgrad_f16", dy, N, x, K, dw, K, M, N, K, ws, sp, 0)
         torch.cuda.synchronize()

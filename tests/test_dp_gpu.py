@@ -16,12 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "workers", "dp_rank.py")
 
 
-def _launch(tmp_path, world, dtype, B, steps, tag, port):
+def _launch(tmp_path, world, dtype, B, steps, tag, port, mode="stage2"):
     out = str(tmp_path / (tag + "_rank%d.npz"))
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, WORKER, out, dtype, str(B), str(steps)], env=env,
+        procs.append(subprocess.Popen([sys.executable, WORKER, out, dtype, str(B), str(steps), mode], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=900)[0] for p in procs]
     for p, lg in zip(procs, logs):
@@ -49,3 +49,67 @@ def test_two_ranks_equal_one_rank_with_the_concatenated_batch(tmp_path, dtype):
     dp = np.abs(two[0]["params"].astype(np.float64) - one["params"].astype(np.float64))
     print("%s: |param diff| mean %.2e max %.2e (lr %.0e)" % (dtype, dp.mean(), dp.max(), lr))
     assert dp.mean() < 0.02 * lr and dp.max() <= 2.05 * lr * steps
+
+
+def test_stage1_two_ranks_equal_one_rank_with_the_concatenated_batch(tmp_path):
+    """post_train_kd.py's data-parallel path (stage1.py:143-154: the title pass writes the gradients, the body pass accumulates
+    and fires the buckets, so title + body gradients are summed BEFORE the all-reduce): two ranks x B/2 == one rank x B."""
+    B, steps = 4, 2
+    two = _launch(tmp_path, 2, "fp16", B, steps, "s1w2", 29621, "stage1")
+    one = _launch(tmp_path, 1, "fp16", B, steps, "s1w1", 29622, "stage1")[0]
+    assert np.array_equal(two[0]["grads"], two[1]["grads"]) and np.array_equal(two[0]["params"], two[1]["params"])
+    g2, g1 = two[0]["grads"][0].astype(np.float64), one["grads"][0].astype(np.float64)
+    cut = int(one["head0"])
+    for name, sl in (("encoder + pooling", slice(0, cut)), ("heads", slice(cut, None))):
+        rel = np.linalg.norm(g2[sl] - g1[sl]) / np.linalg.norm(g1[sl])
+        print("stage 1 %s: rel. L2 difference of the averaged gradient %.2e" % (name, rel))
+        assert rel < 1e-3, (name, rel)
+    dp = np.abs(two[0]["params"].astype(np.float64) - one["params"].astype(np.float64))
+    print("stage 1: |param diff| mean %.2e max %.2e" % (dp.mean(), dp.max()))
+    assert dp.mean() < 0.02 * 1e-5 and dp.max() <= 2.05 * 1e-5 * steps
+
+
+class _FakeSync:
+    """A GradSync whose collectives are already complete: Engine.step(sync=...) must take the bucket-by-bucket path."""
+
+    def __init__(self, ranges):
+        self.ranges, self.pending, self.waited, self.scale = list(ranges), {b: None for b in range(len(ranges))}, [], 0.5
+
+    def wait_bucket(self, b):
+        self.pending.pop(b, None)
+        self.waited.append(b)
+
+    def wait(self):
+        for b in list(self.pending):
+            self.wait_bucket(b)
+
+
+@pytest.mark.parametrize("rates", [(1e-4, None, None), (1e-5, 1e-6, None), (1e-4, 2e-5, 3e-5)])
+def test_bucketwise_optimiser_step_is_bit_identical_to_one_launch(rates):
+    """Engine.step(sync=...) runs AMSGrad bucket by bucket in completion order (bucket ranges intersected with the learning-rate
+    ranges, then a sweep over the alignment gaps): every element must get exactly one update with ITS rate -- parameters and all
+    three state buffers bit-identical to the one-launch step, for one rate, the two rates of PLM-NR / the notebooks, and three."""
+    import torch
+    import engine as E
+    import hashinit
+    from schema import FULL, state_shapes
+    lr, lr_bert, lr_head = rates
+    cfg = E.EngineConfig(n_layers=2, trainable_layers=(0, 1), num_teachers=2)
+    P = hashinit.init_state_dict(3, state_shapes(FULL, 2, cfg.D, 2))
+    outs = []
+    for bucketed in (False, True):
+        eng = E.Engine(cfg, "cuda:0", max_batch=2, dtype="fp16")
+        eng.load_state_dict(P)
+        g = torch.Generator(device="cuda:0").manual_seed(5)
+        for step in range(3):
+            eng.flat_g.copy_(torch.randn(eng.n_train, device="cuda:0", generator=g) * 1e-3)
+            sync = _FakeSync(eng.bucket_ranges()) if bucketed else None
+            eng.step(lr, grad_scale=0.5, lr_bert=lr_bert, lr_news_head=lr_head, sync=sync)
+            if bucketed:
+                assert sync.waited == list(range(len(sync.ranges))) and not sync.pending      # completion order, each once
+        torch.cuda.synchronize()
+        outs.append([x.clone() for x in (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax)] + [eng.sh[1]["w1"].clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    rng = outs[0][0]
+    assert not torch.equal(rng, torch.from_numpy(np.zeros(1, np.float32)).to(rng.device).expand_as(rng))

@@ -322,3 +322,71 @@ def test_state_dict_schema_of_pooling_and_nrms_variants(pooling, heads):
         assert eng.off("teachers.1.multi_head_self_attn.W_Q.weight") == eng.off("teachers.0.multi_head_self_attn.W_Q.weight") + 3 * 256 * 256
     br = sorted(eng.bucket_ranges())
     assert br[0][0] == 0 and br[-1][1] == eng.n_train and all(a[1] == b[0] for a, b in zip(br, br[1:]))
+
+
+def _epoch_cap_worker(rank, world, port, data_dir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import dist
+    from dataloader import DataLoaderTrain
+    from streaming import get_stat
+    dist.init("gloo")
+    args = types.SimpleNamespace(npratio=4, user_log_length=5, batch_size=8, shuffle_buffer_size=16, num_teachers=0, dedup_news=False)
+    news_index = {"N%d" % i: i for i in range(1, 30)}
+    loader = DataLoaderTrain(data_dir=data_dir, filename_pat="behaviors_*.tsv", args=args, world_size=world, worker_rank=rank,
+                             cuda_device_idx=0, news_index=news_index, news_combined=np.zeros((30, 8), np.int32), teacher_embs=[],
+                             enable_prefetch=True, enable_shuffle=True, enable_gpu=False, resident=False)
+    stat = get_stat(data_dir, "behaviors_*.tsv")
+    out = []
+    for ep in range(3):
+        mine = loader.next_epoch_batches(stat)               # what THIS epoch's re-sharded file set gives this worker
+        cap = dist.min_over_ranks(mine)                      # run.py: before every epoch
+        got = steps = 0
+        t = torch.zeros(1)
+        for batch in loader:                                 # the loop of run.py: one collective per step, `cap` steps on every rank
+            got += 1
+            if steps < cap:
+                torch.distributed.all_reduce(t)
+                steps += 1
+        out.append((mine, cap, got, steps))
+    loader.join()
+    dist.barrier()
+    q.put((rank, out))
+
+
+def test_step_cap_follows_the_per_epoch_resharding_gloo(tmp_path):
+    """The loader re-shards the files EVERY epoch (shuffle seed = epoch number, dataloader.py:61-70), so with unequal files a
+    worker's batch count changes from epoch to epoch: the cap is recomputed per epoch from the loader's own arguments
+    (DataLoaderTrain.next_epoch_batches + dist.min_over_ranks) -- a cap taken once from the epoch-0 file set would let a rank
+    run dry in a later epoch while the other waits in the all-reduce."""
+    import torch.multiprocessing as mp
+    from streaming import get_worker_files, shard_files
+    sizes = {"behaviors_0.tsv": 100, "behaviors_1.tsv": 37, "behaviors_2.tsv": 71, "behaviors_3.tsv": 9, "behaviors_4.tsv": 55}
+    for name, n in sizes.items():
+        with open(tmp_path / name, "w") as f:
+            for i in range(n):
+                f.write("%d\tU%d\tt\tN1 N2 N3\tN4\tN5 N6 N7 N8\n" % (i, i))
+    d = str(tmp_path)
+    for seed in range(6):                                    # the side-effect-free shard rule == the reference's (which seeds `random`)
+        for r in range(2):
+            st = random.getstate()
+            assert shard_files(d, r, 2, "behaviors_*.tsv", True, seed) == get_worker_files(d, r, 2, "behaviors_*.tsv", True, seed)
+            random.setstate(st)
+            assert shard_files(d, r, 2, "behaviors_*.tsv", False, seed) == get_worker_files(d, r, 2, "behaviors_*.tsv", False, seed)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    ps = [ctx.Process(target=_epoch_cap_worker, args=(r, 2, port, d, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+    caps_seen = set()
+    for ep in range(3):
+        (m0, c0, g0, s0), (m1, c1, g1, s1) = res[0][ep], res[1][ep]
+        assert g0 == m0 and g1 == m1                         # the prediction is what the iterator really yields
+        assert c0 == c1 == min(m0, m1) and s0 == s1 == c0    # both ranks ran the same number of collectives
+        files = [shard_files(d, r, 2, "behaviors_*.tsv", True, ep) for r in range(2)]
+        assert [m0, m1] == [-(-sum(sizes[os.path.basename(f)] for f in fs) // 8) for fs in files]
+        caps_seen.add((m0, m1))
+    assert len(caps_seen) > 1                                # the file sets really changed between epochs

@@ -81,7 +81,9 @@ static inline int tnr_make_drop(const tnr_dropout_t* d, TnrDrop* o, const char* 
     o->site = d->site;
     o->call = d->call;
     o->thresh = (uint32_t)(d->p * 65536.0 + 0.5);
-    o->scale = (float)(1.0 / (1.0 - d->p));
+    // p below 2^-17 rounds to "keep everything": then nothing is scaled either (forward kernels test thresh, backward ones
+    // multiply by scale -- both must see the same effective dropout)
+    o->scale = o->thresh ? (float)(1.0 / (1.0 - d->p)) : 1.0f;
     return TNR_OK;
 }
 

@@ -1682,35 +1682,62 @@ static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
     X(0) X(TNR_EPI_BIAS) X(TNR_EPI_RES) X(TNR_EPI_BIAS | TNR_EPI_RES) X(TNR_EPI_BIAS | TNR_EPI_GELU)                      \
     X(TNR_EPI_BIAS | TNR_EPI_GELU | TNR_EPI_AUXOUT) X(TNR_EPI_MULDGELU) X(TNR_EPI_MULDGELU | TNR_EPI_COLSUM)              \
     X(TNR_EPI_BIAS | TNR_EPI_TANH | TNR_EPI_OUTF32) X(TNR_EPI_BIAS | TNR_EPI_RES | TNR_EPI_DROPOUT)
-// Counter sets of the ping-pong kernel's tile queue: zero at load, returned to zero by every launch.  One set per (device,
-// stream): launches of a stream run in order, so each finds the set its predecessor zeroed, and launches of different streams
-// never share one.  When the table is full the device is drained and the table starts over.
+// Counter sets of the ping-pong kernel's tile queue (the ONE piece of device state the library keeps, include/tnr_hip.h):
+// 128 sets in a __device__ array, one per (device, stream) the kernel has been launched on -- launches of a stream run in order,
+// so each finds the set its predecessor returned to zero, and launches of different streams never share one.  A set is zeroed
+// by a hipMemsetAsync on its stream when the stream is first bound and again by tnr_gemm_queue_reset(); every launch leaves
+// it at zero (the last workgroup out resets it).  The table never drains a device and never changes the current device: when
+// it is full the launch is refused (TNR_EUNSUPPORTED) and the caller either reuses fewer streams or runs with option "pp" = 0.
 constexpr int PP_QUEUE_SETS = 128, PP_LDS = LDS3_BYTES + 64;
 __device__ unsigned g_pp_queue[PP_QUEUE_SETS * PP_Q_SET];
-static unsigned* pp_queue_of(hipStream_t st) {
+static unsigned* pp_queue_of(hipStream_t st, bool reset = false) {
     struct Slot { int dev; hipStream_t st; };
     static std::mutex mu;
     static Slot slots[PP_QUEUE_SETS];
     static int nslot = 0;
     static unsigned* base[64] = {};
     int dev = 0;
-    (void)hipGetDevice(&dev);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { tnr_set_error("tnr_gemm_nt: no current device"); return nullptr; }
     std::lock_guard<std::mutex> lk(mu);
-    if (dev < 0 || dev >= 64) return nullptr;
-    if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_pp_queue)) != hipSuccess) return nullptr;
-    for (int i = 0; i < nslot; ++i)
-        if (slots[i].dev == dev && slots[i].st == st) return base[dev] + i * PP_Q_SET;
-    if (nslot == PP_QUEUE_SETS) {
-        int cur = dev;
-        for (int i = 0; i < nslot; ++i)
-            if (slots[i].dev != cur) { cur = slots[i].dev; (void)hipSetDevice(cur); (void)hipDeviceSynchronize(); }
-        (void)hipSetDevice(dev);
-        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-        nslot = 0;
+    if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_pp_queue)) != hipSuccess) {
+        tnr_set_error("tnr_gemm_nt: tile-queue symbol not found");
+        return nullptr;
     }
-    slots[nslot] = Slot{dev, st};
-    return base[dev] + (nslot++) * PP_Q_SET;
+    unsigned* set = nullptr;
+    for (int i = 0; i < nslot && !set; ++i)
+        if (slots[i].dev == dev && slots[i].st == st) set = base[dev] + i * PP_Q_SET;
+    const bool fresh = !set;
+    if (!set) {
+        if (nslot == PP_QUEUE_SETS) {
+            tnr_set_error("tnr_gemm_nt: more than %d (device, stream) pairs have launched the persistent GEMM in this process", PP_QUEUE_SETS);
+            return nullptr;
+        }
+        slots[nslot] = Slot{dev, st};
+        set = base[dev] + (nslot++) * PP_Q_SET;
+    }
+    if ((fresh || reset) && hipMemsetAsync(set, 0, PP_Q_SET * sizeof(unsigned), st) != hipSuccess) {
+        tnr_set_error("tnr_gemm_nt: could not zero the tile-queue counters");
+        return nullptr;
+    }
+#ifdef TNR_DEBUG_QUEUE
+    {   // debug builds: the counters must be zero between launches (a launch that died half way leaves them non-zero, and every
+        // later launch on the stream would then skip tiles silently)
+        unsigned host[PP_Q_SET];
+        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(host, set, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+        for (int i = 0; i < 9; ++i)
+            if (host[i * PP_Q_STRIDE]) { tnr_set_error("tnr_gemm_nt: tile-queue counter %d is %u at launch", i, host[i * PP_Q_STRIDE]); return nullptr; }
+    }
+#endif
+    return set;
 }
+
+#ifndef TNR_BUILD_F16
+// Zero the calling stream's tile-queue counters (stream-ordered).  Only needed after a launch on that stream was aborted (device
+// fault, process-level recovery): a completed launch always leaves them at zero.
+extern "C" int tnr_gemm_queue_reset(void* stream) {
+    return pp_queue_of((hipStream_t)stream, true) ? TNR_OK : TNR_EUNSUPPORTED;
+}
+#endif
 
 template <int MI>
 static void pp_launch(const NTArgs& g, unsigned grid, hipStream_t st) {
@@ -1796,7 +1823,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
         if (o.pp) {
             const PpPlan pl = pp_plan(M, N, flags, n_cu);
             g.mix_p = pl.P; g.mix_x = pl.x;
-            if (!(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
+            if (!(g.queue = pp_queue_of(st))) return TNR_EUNSUPPORTED;
             pp_launch<7>(g, (unsigned)std::min<int64_t>((int64_t)pl.P * (N / 256), std::max(n_cu, 8)), st);   // >= 8: every XCD label needs a workgroup
         }
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<7>), dim3((unsigned)(((M + 223) / 224) * (N / 256))), dim3(512), LDS3_BYTES, st, g);
@@ -1805,7 +1832,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
         if (o.pp) {
             const PpPlan pl = pp_plan(M, N, flags, n_cu);
             g.mix_p = pl.P; g.mix_x = pl.x;
-            if (!(g.queue = pp_queue_of(st))) return TNR_ELAUNCH;
+            if (!(g.queue = pp_queue_of(st))) return TNR_EUNSUPPORTED;
             pp_launch<8>(g, (unsigned)std::min<int64_t>((int64_t)pl.P * (N / 256), std::max(n_cu, 8)), st);
         }
         else hipLaunchKernelGGL((gemm_nt256x256_kernel<8>), dim3((unsigned)(((M + 255) / 256) * (N / 256))), dim3(512), LDS3_BYTES, st, g);

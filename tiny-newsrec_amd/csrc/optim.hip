@@ -106,23 +106,3 @@ extern "C" int TNR_NAME(tnr_refresh_shadows)(const int64_t* desc, int n_desc, in
     TNR_CHECK_LAUNCH("tnr_refresh_shadows");
     return TNR_OK;
 }
-
-#if !defined(TNR_BUILD_F16)
-// Test hook (tests/test_bench_shapes_gpu.py, tools/cu_contention.py): n_wg workgroups that each take a whole CU (all of its LDS) and
-// spin for `us` microseconds -- a stand-in for a communication kernel holding CUs while the step's GEMMs run on another stream
-namespace {
-__global__ __launch_bounds__(1024) void cu_hog_kernel(unsigned long long ticks) {
-    extern __shared__ char hog_lds[];
-    if (threadIdx.x == 0) hog_lds[0] = 1;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
-}
-}  // namespace
-extern "C" int tnr_debug_cu_hog(int n_wg, int us, void* stream) {
-    TNR_CHECK_ARG(n_wg >= 1 && n_wg <= 1024 && us >= 0 && us <= 100000, "tnr_debug_cu_hog: 1..1024 workgroups, at most 100 ms");
-    TNR_ONCE_PER_DEVICE({ (void)hipFuncSetAttribute((const void*)cu_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    hipLaunchKernelGGL(cu_hog_kernel, dim3((unsigned)n_wg), dim3(1024), 160 * 1024, (hipStream_t)stream, (unsigned long long)us * 100ull);
-    TNR_CHECK_LAUNCH("tnr_debug_cu_hog");
-    return TNR_OK;
-}
-#endif

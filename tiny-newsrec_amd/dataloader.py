@@ -17,7 +17,7 @@ import threading
 import numpy as np
 import torch
 
-from streaming import StreamSampler
+from streaming import StreamSampler, _count_lines, shard_files
 
 _END = object()
 
@@ -102,6 +102,17 @@ class DataLoaderTrain:
                                      enable_shuffle=self.enable_shuffle, shuffle_buffer_size=self.shuffle_buffer_size,
                                      shuffle_seed=self.epoch)   # epoch id as shuffle seed (dataloader.py:69)
         return iter(self.sampler)
+
+    def next_epoch_batches(self, stat=None):
+        """Number of batches the NEXT iter(self) yields on this worker: the sampler it builds re-shards the files with the
+        epoch number as the shuffle seed (dataloader.py:61-70 of the reference), so a worker's file set -- and with unequal
+        files its batch count -- changes from epoch to epoch.  run.py all-reduces the minimum of this before every epoch
+        (dist.min_over_ranks): a rank that ran out of batches earlier than the others would leave them waiting in the
+        gradient all-reduce.  stat: {path: lines} (streaming.get_stat) or None to count here."""
+        files = shard_files(self.data_dir, self.worker_rank, self.world_size, self.filename_pat, self.enable_shuffle,
+                            self.epoch + 1)
+        n = sum(stat[f] if stat is not None and f in stat else _count_lines(f) for f in files)
+        return -(-n // self.batch_size)
 
     def _produce(self):
         try:

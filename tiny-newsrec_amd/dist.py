@@ -29,35 +29,74 @@ class GradSync:
 
     launch(i) is called by Engine.backward right after the last kernel that writes bucket i was enqueued on the current
     stream; the collective is stream-ordered behind it (ProcessGroupNCCL makes its own stream wait for the current one),
-    so a bucket can never be reduced before it is complete.  Under the gloo backend (CPU tests, or two ranks sharing one
-    GPU in the data-parallel equivalence test) device buckets are staged through host memory, synchronously."""
+    so a bucket can never be reduced before it is complete.  It runs ASYNCHRONOUSLY (pending[i] holds its work handle) and
+    wait_bucket(i) puts the current stream behind it -- Engine.step(sync=...) calls that bucket by bucket, so each AMSGrad slice
+    waits for its own collective only.
+    Under the gloo backend (CPU tests, or two ranks sharing one GPU in the data-parallel equivalence tests) a device bucket is
+    staged through a pinned host mirror: launch() copies it out (the host waits for that copy -- gloo needs the bytes) and starts
+    the all-reduce asynchronously on the mirror; wait_bucket() waits for it and copies the sum back on the current stream.  The
+    bookkeeping (pending / wait_bucket order / per-bucket optimiser slices behind in-flight collectives) is the same code path
+    RCCL takes.
+    timing = True: wait_bucket brackets its wait with events on the current stream; exposed_ms() = the time the compute stream
+    actually stood still behind collectives (what overlap did not hide), per bucket, since the last call."""
 
-    def __init__(self, flat_g, ranges, world, force=False):
+    def __init__(self, flat_g, ranges, world, force=False, timing=False):
         self.flat_g, self.ranges, self.world = flat_g, list(ranges), world
         self.force = force and dist.is_initialized()      # exercise the collective path even with one rank
-        self.pending = {}                                 # bucket -> outstanding work handle
+        self.pending = {}                                 # bucket -> (work handle, pinned host mirror or None)
         self.host_staged = dist.is_initialized() and dist.get_backend() == "gloo" and flat_g.is_cuda
+        self._mirror = {}
+        self.timing = timing and flat_g.is_cuda
+        self._events = []                                 # (bucket, start event, end event)
+
+    def bucket_bytes(self):
+        return [4 * (e - s) for s, e in self.ranges]
 
     def launch(self, bucket):
         if self.world == 1 and not self.force:
             return
         s, e = self.ranges[bucket]
         if self.host_staged:
-            h = self.flat_g[s:e].cpu()                    # synchronises with the stream that wrote the bucket
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            self.flat_g[s:e].copy_(h)
+            h = self._mirror.get(bucket)
+            if h is None:
+                h = self._mirror[bucket] = torch.empty(e - s, dtype=self.flat_g.dtype, pin_memory=True)
+            h.copy_(self.flat_g[s:e], non_blocking=True)  # stream-ordered behind the kernels that wrote the bucket
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
+            self.pending[bucket] = (dist.all_reduce(h, op=dist.ReduceOp.SUM, async_op=True), h)
             return
-        self.pending[bucket] = dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True)
+        self.pending[bucket] = (dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True), None)
 
     def wait_bucket(self, bucket):
-        """Make the current stream wait for bucket's all-reduce (no-op when it was not launched asynchronously)."""
+        """Make the current stream wait for bucket's all-reduce (no-op when it was not launched)."""
         w = self.pending.pop(bucket, None)
-        if w is not None:
-            w.wait()
+        if w is None:
+            return
+        work, h = w
+        if self.timing:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        work.wait()
+        if h is not None:
+            s, e = self.ranges[bucket]
+            self.flat_g[s:e].copy_(h, non_blocking=True)
+        if self.timing:
+            e1.record()
+            self._events.append((bucket, e0, e1))
 
     def wait(self):
         for b in list(self.pending):
             self.wait_bucket(b)
+
+    def exposed_ms(self):
+        """-> {bucket: [ms, ...]} of the waits recorded since the last call (synchronises the device)."""
+        torch.cuda.synchronize()
+        out = {}
+        for b, e0, e1 in self._events:
+            out.setdefault(b, []).append(e0.elapsed_time(e1))
+        self._events = []
+        return out
 
     @property
     def scale(self):

@@ -57,7 +57,8 @@ def parse_args(argv=None):
     p.add_argument("--save_dir", default=".")
     p.add_argument("--log_steps", type=int, default=10)
     p.add_argument("--max_steps", type=int, default=0, help="stop an epoch early (0 = whole corpus)")
-    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--seed", type=int, default=0, help="shuffle / sampling / dropout-mask seed; the mask counter restarts at 0 in every process, so a run "
+                   "continued from a checkpoint should pass a different seed (as a fixed torch seed would replay the notebook's masks)")
     p.add_argument("--enable_hvd", type=b, default=True, help="data-parallel when launched by torch.distributed.run")
     p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
     p.add_argument("--hidden_dropout_prob", type=float, default=None,

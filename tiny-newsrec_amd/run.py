@@ -103,11 +103,7 @@ def train(args):
         paths = get_worker_files(args.train_data_dir, rank, size, args.filename_pat, args.enable_shuffle, 0)
         n = sum(stat[f] for f in paths)
         logging.info("[{}] contains {} samples {} steps".format(rank, n, n // args.batch_size))
-        # uneven shards: every rank runs the step count the shortest shard allows (the last batch may be short, streaming.py:76),
-        # otherwise the rank that finishes first leaves the others waiting in the gradient all-reduce
-        steps_cap = dist.min_over_ranks(-(-n // args.batch_size))
-        if size > 1:
-            logging.info("[{}] {} steps per epoch on every rank (shortest shard)".format(rank, steps_cap))
+        steps_cap = None          # per epoch, below: the loader re-shards the files every epoch
         loader = DataLoaderTrain(teacher_embs=teacher_embs, news_index=news_index, news_combined=news_combined, word_dict=None,
                                  data_dir=args.train_data_dir, filename_pat=args.filename_pat, args=args, world_size=size,
                                  worker_rank=rank, cuda_device_idx=local, enable_prefetch=True, enable_shuffle=True,
@@ -115,12 +111,23 @@ def train(args):
         dev_news, dev_tab = getattr(loader, "dev_news", None), loader.dev_tables
         batches = lambda: iter(loader)
 
+        def epoch_cap():
+            # uneven shards: every rank runs the step count the shortest shard of THIS epoch allows (the loader re-shards the
+            # files with the epoch number as shuffle seed; the last batch may be short, streaming.py:76), otherwise the rank
+            # that finishes first leaves the others waiting in the gradient all-reduce
+            cap = dist.min_over_ranks(loader.next_epoch_batches(stat))
+            if size > 1:
+                logging.info("[{}] {} steps this epoch on every rank (shortest shard)".format(rank, cap))
+            return cap
+
     if args.cache_frozen_layers and dev_news is not None and eng.build_frozen_cache(dev_news):
         logging.info("[%d] frozen layers 0..%d cached for %d news (%.2f GB)" % (
             rank, eng.lo - 1, dev_news.shape[0], eng.fcache[0].numel() * 4 / 1e9))
     logging.info("Training...")
     for ep in range(args.start_epoch, args.epochs):
         loss_sum, acc_sum, t0 = torch.zeros((), device="cuda"), torch.zeros((), device="cuda"), time.time()
+        if not args.synthetic:
+            steps_cap = epoch_cap()
         for cnt, batch in enumerate(batches()):
             if cnt > args.max_steps_per_epoch or cnt >= steps_cap:
                 break

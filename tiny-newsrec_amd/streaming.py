@@ -55,6 +55,16 @@ def get_worker_files(dirname, worker_rank, world_size, filename_pat="*", shuffle
     return mine
 
 
+def shard_files(dirname, worker_rank, world_size, filename_pat="*", shuffle=False, seed=0):
+    """The same file list as get_worker_files WITHOUT its side effect on Python's global `random` (and without its log
+    line): random.shuffle under random.seed(seed) is random.Random(seed).shuffle.  For asking "which files will epoch e
+    give this worker" from the main thread while the producer thread owns the global generator."""
+    ordered = sorted(_matching(dirname, filename_pat))
+    if shuffle:
+        random.Random(seed).shuffle(ordered)
+    return ordered[worker_rank::world_size]
+
+
 class StreamReader:
     BLOCK = 128
 

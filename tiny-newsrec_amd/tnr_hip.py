@@ -42,7 +42,7 @@ _SIG = {
     "tnr_gemm_colsum_rows": [_L],
     "tnr_gemm_nt_route": [_L, _L, _L, _I],
     "tnr_gemm_nt_plan": [_L, _L, _I, _I, _P, _P, _P],
-    "tnr_debug_cu_hog": [_I, _I, _P],
+    "tnr_gemm_queue_reset": [_P],
     "tnr_gemm_set_option": [_c.c_char_p, _I],
     "tnr_gemm_tn_wgrad": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _P],
     "tnr_gemm_tn_wgrad_ex": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _F, _P],

@@ -1,13 +1,13 @@
 """What happens to the step's GEMMs while another stream holds some CUs (a collective kernel during the overlapped gradient
-all-reduce)?  tnr_debug_cu_hog(n_wg, us) (a test hook of the library): n_wg workgroups that each own a whole CU and spin.
+all-reduce)?  tnr_debug_cu_hog(n_wg, us) (libtnr_testhooks.so, a test-only library built beside the product one): n_wg workgroups that each own a whole CU and spin.
 Times NT / TN launches alone and beside 8 / 16 / 32 held CUs.  LIB=tools/_probe/libtnr_old.so: the same for another build."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
 import torch, tnr_hip as T
-L = ctypes.CDLL(T.LIB_PATH)                                                   # the hog (tnr_debug_cu_hog) comes from the shipped library ...
+L = ctypes.CDLL(os.path.join(os.path.dirname(T.LIB_PATH), "libtnr_testhooks.so"))   # the hog comes from the test-hooks library ...
 L.tnr_debug_cu_hog.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-if os.environ.get("LIB"): T.LIB_PATH = os.path.join(ROOT, os.environ["LIB"])  # ... the GEMMs too, or from LIB=<another build>
+if os.environ.get("LIB"): T.LIB_PATH = os.path.join(ROOT, os.environ["LIB"])  # ... the GEMMs from the shipped one, or from LIB=<another build>
 T.lib()
 dev, M, td, sfx = "cuda:0", 52800, torch.float16, "_f16"
 side = torch.cuda.Stream()
