@@ -11,6 +11,7 @@
 // workgroup -> 2 workgroups per CU overlap each other's barrier stalls.
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 
@@ -73,6 +74,7 @@ __device__ __forceinline__ void tile_coords(int wg, int nbm, int nbn, int GM, in
 // ~35 slots per element and made the FFN epilogues VALU-bound (13 us per 256x256 tile).
 constexpr int LUT_N = 2048;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // node i holds {f(x_i), f(x_i+1) - f(x_i)}: ONE 8-byte gather per element on the 64-bank ds_read_b64 path
 __device__ __forceinline__ void lut_build(f32x2* lut, bool grad) {
     for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
@@ -1036,6 +1038,8 @@ __device__ __forceinline__ void pp_q_fetch(unsigned& dst, unsigned* ctr, bool on
 }
 __device__ __forceinline__ void pp_q_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0) ; tile queue: %0" : "+v"(v) :: "memory"); }
 
+template <int N_> __device__ __forceinline__ void tnr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
 template <int MI, int CF>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1208,6 +1212,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     // -> B(kt+1) has landed one barrier (two for the staggered group) before phase 3 reads it; end of phase 3 vmcnt(2) =
     // all but A0(kt+2) -> A1(kt+1) landed before the next K tile.  WAR: B(kt-1) was last read in phase 1 of K tile kt-1 (its
     // columns 0-31 in phase 3 of kt-2), A1(kt-1) in group 1's phase 2 of kt-1, A0(kt) in group 0's phase 2 of kt.
+#if defined(TNR_PROBES) && TNR_PROBES >= 2
+    /* probe 128: can stores spread thinly over the K loop hide beside the MFMAs?  One 16-byte store per lane in the load segment
+       of every phase of K tiles 0, 3, 6, 9 (16 per wave and tile, what the epilogue issues), into this tile's own C rows; the waits
+       count them as younger than the LDS-DMA pieces they follow.  Outputs are garbage; use with probe 8 (no epilogue). */
+    const unsigned dlc = (unsigned)(((rs + wm * PR + (lane & 15)) * (int)g.ldc + bn * 256 + wn * 64 + (lane >> 4) * 8) * 2);
+    const __amdgpu_buffer_rsrc_t drC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((int64_t)g.M * g.ldc * 2), 0x00020000);
+#define TNR_PP_DUMMY_ON ((g.probe & 128) && (kt % 3) == 0)
+#define TNR_PP_DUMMY_STORE(P)                                                                                    \
+    if (TNR_PP_DUMMY_ON) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, af[P][0]), drC, dlc + (unsigned)((P) * 16 * (int)g.ldc * 2), 0, 0)
+#define TNR_PP_DUMMY_WAIT(P)                                                                                     \
+    if (TNR_PP_DUMMY_ON) {                                                                                       \
+        if ((P) == 2) { if (more && a_live) tnr_wait_vm<2 + 2>(); else tnr_wait_vm<2>(); }                       \
+        else { if (kt + 2 < nk && a_live) tnr_wait_vm<2 + 2>(); else tnr_wait_vm<2>(); }                         \
+    } else if ((P) == 2) { if (more && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0); }                      \
+    else { if (kt + 2 < nk && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0); }
+#else
+#define TNR_PP_DUMMY_STORE(P)
+#define TNR_PP_DUMMY_WAIT(P)                                                                                     \
+    if ((P) == 2) { if (more && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0); }                             \
+    else { if (kt + 2 < nk && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0); }
+#endif
 #define TNR_PP_KTILE(KT, BL, BH)                                                                                 \
     {                                                                                                            \
         const int kt = (KT);                                                                                     \
@@ -1222,6 +1247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
             _Pragma("unroll") for (int i = 0; i < ILO; ++i) af[i][s] = *(const bf16x8*)(sa + i * 16 * 128 + foff[s]); \
         }                                                                                                        \
         if (more) { issue(2, kt + 1); issue(3, kt + 1); }                                                        \
+        TNR_PP_DUMMY_STORE(0);                                                                                   \
         TNR_PP_SEG_END();                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < ILO; ++i)                                                      \
@@ -1232,6 +1258,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                              \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) bfr[BH + j][s] = *(const bf16x8*)(sb + (32 + j * 4) * 128 + boff[s]); \
         if (more) issue(1, kt + 1);                                                                              \
+        TNR_PP_DUMMY_STORE(1);                                                                                   \
         TNR_PP_SEG_END();                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < ILO; ++i)                                                      \
@@ -1242,7 +1269,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                              \
             _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
                 if (i + 1 < IHI || tall) af[i][s] = *(const bf16x8*)(sa + (ILO + i) * 16 * 128 + foff[s]);       \
-        if (more && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);                                           \
+        TNR_PP_DUMMY_WAIT(2);                                                                                    \
+        TNR_PP_DUMMY_STORE(2);                                                                                   \
         TNR_PP_SEG_END();                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
@@ -1254,8 +1282,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
             if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                          \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j) bfr[BH + j][s] = *(const bf16x8*)(sbn + j * 4 * 128 + boff[s]); \
             if (kt + 2 < nk) issue(0, kt + 2);                                                                   \
-            if (kt + 2 < nk && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0);                                \
+            TNR_PP_DUMMY_WAIT(3);                                                                                \
         }                                                                                                        \
+        TNR_PP_DUMMY_STORE(3);                                                                                   \
         TNR_PP_SEG_END();                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
@@ -1268,6 +1297,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         if (kt2 + 1 < nk) TNR_PP_KTILE(kt2 + 1, 2, 0)
     }
 #undef TNR_PP_KTILE
+#undef TNR_PP_DUMMY_STORE
+#undef TNR_PP_DUMMY_WAIT
 #undef TNR_PP_SEG_END
 #undef TNR_PP_MFMA_END
     pp_q_wait(qn);                                       // (the K loop's last waits were vmcnt(0) already)
