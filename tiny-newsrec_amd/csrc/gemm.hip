@@ -292,6 +292,7 @@ struct TNArgs {
     int N, K;
     int tiles_per_split;
     int splits;
+    unsigned* queue;           // ping-pong kernel: the stream's tile-queue counters (8 per-XCD-label unit counters + a done counter)
 };
 
 __device__ __forceinline__ int tn_swz(int row) { return (((row & 3) | (((row >> 3) & 1) << 2)) << 1); }
@@ -1447,13 +1448,54 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
     const int wn = w >> 2, wk = w & 3;          // wave tile: 128 n x 64 k
     const int nbk = g.K >> 8;
     const int ntile = (g.N >> 8) * nbk;
-    const int wg = xcd_remap(blockIdx.x, ntile * g.splits);
-    const int z = wg / ntile, tile = wg - z * ntile;
+    // Persistent: the work units (split z, output tile) -- one fp32 slab tile each, unit id = z * ntile + tile -- are PULLED from the
+    // stream's queue counters exactly as the NT kernel pulls its tiles: the workgroups of an XCD label take consecutive units of
+    // that label's contiguous run (units of one split read the same rows of dY / X: they share them through the XCD's L2), and a
+    // workgroup whose CU is held by another stream's kernel (the all-reduce of a finished gradient bucket) simply takes fewer.
+    // With one unit per workgroup -- the single-GPU choice of splits, one round -- this is the old static grid; the data-parallel
+    // engine cuts the M range finer (Engine._wgrad_splits) so that a late workgroup costs a fraction of a unit, not a round.
+    // The partition into units is fixed by (N, K, splits, M) alone and the slabs are summed in a fixed order: who computes a unit
+    // never changes a bit of the result.
+    const int nunit = ntile * g.splits;
+    const int xcd = blockIdx.x & 7;
+    const int q8 = nunit >> 3, r8 = nunit & 7;
+    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
+    int* const qlds = (int*)(smem + RING3);
+    unsigned q0;
+    pp_q_fetch(q0, g.queue + xcd * PP_Q_STRIDE, w == 0);
+    auto leave = [&]() {                                 // last workgroup out zeroes the counters for the next launch
+        if (tid == 0) {
+            const unsigned d = __hip_atomic_fetch_add(g.queue + 8 * PP_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == gridDim.x - 1)
+                for (int i = 0; i < 9; ++i)
+                    __hip_atomic_store(g.queue + i * PP_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    int roff[2][2], rswz[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = 32 * s + 8 * g16 + q4 + 4 * h;
+            roff[s][h] = row * 256 + (p4 & 1) * 8;
+            rswz[s][h] = tn_swz(row);
+        }
+    pp_q_wait(q0);
+    if (tid == 0) qlds[0] = c0 + (int)q0;
+    __syncthreads();
+    int unit = qlds[0];
+    if (unit >= c1) { leave(); return; }                 // whole workgroup, before any other barrier
+  while (true) {
+    const int z = unit / ntile, tile = unit - z * ntile;
     const int bn = tile / nbk, bk = tile - bn * nbk;
     const int mt0 = z * g.tiles_per_split;
     int mt1 = mt0 + g.tiles_per_split;
     if (mt1 > g.Mt) mt1 = g.Mt;
     const int nk = mt1 - mt0;
+    unsigned qn;                                         // lane 0 of wave 0: the next unit, in flight during this one (oldest operation)
+    pp_q_fetch(qn, g.queue + xcd * PP_Q_STRIDE, w == 0);
 
     // staging: every wave issues pieces 2w, 2w+1 (4 rows x 256 B each) of every sub-tile
     const bf16* srcY[2][2];
@@ -1479,16 +1521,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
             glds16(srcX[which - 2][1] + t * stepX, base + 1024);
         }
     };
-    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    int roff[2][2], rswz[2][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int row = 32 * s + 8 * g16 + q4 + 4 * h;
-            roff[s][h] = row * 256 + (p4 & 1) * 8;
-            rswz[s][h] = tn_swz(row);
-        }
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -1602,6 +1634,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
 #undef TNR_PP_MFMA_END
         if (wn == 0) __builtin_amdgcn_s_barrier();       // all waves execute the same number of barriers
     }
+    // the next unit: the answer is older than anything the loop's last wait left in flight (and behind a vmcnt(0) when nk == 0)
+    pp_q_wait(qn);
+    if (tid == 0) qlds[1] = c0 + (int)qn;
     float* slab = g.ws + (int64_t)z * g.N * g.K;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1612,6 +1647,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
             *(f32x4*)(slab + (int64_t)n * g.K + k) = acc[i][j];
         }
     }
+    __syncthreads();                                     // qlds[1] visible ; every fragment read of this unit is long complete
+    const int next = qlds[1];
+    if (next >= c1) break;
+    unit = next;
+    __syncthreads();                                     // qlds[1] is rewritten only after everybody has read it
+  }
+    leave();
 }
 
 __global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t NK, int K, float* out,
@@ -1890,12 +1932,12 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
     if (splits > Mt) splits = Mt;
     int tps = (Mt + splits - 1) / splits;
     splits = (Mt + tps - 1) / tps;
-    TNArgs g{(const bf16*)dY, lddy, (const bf16*)X, ldx, ws, Mt, (int)N, (int)K, tps, splits};
+    TNArgs g{(const bf16*)dY, lddy, (const bf16*)X, ldx, ws, Mt, (int)N, (int)K, tps, splits, nullptr};
     const int ver = tnr_gemm_opts()->ver;
     TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_tn256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
-        (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3 + 64);
     });
     if (ver == 1 || (N % 256) != 0) {
         dim3 grid((unsigned)((N / 128) * (K / 128) * splits));
@@ -1905,7 +1947,13 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
         hipLaunchKernelGGL(gemm_tn256_kernel, grid, dim3(512), RING2, (hipStream_t)stream, g);
     } else {
         dim3 grid((unsigned)((N / 256) * (K / 256) * splits));
-        if (tnr_gemm_opts()->tnpp) hipLaunchKernelGGL(gemm_tn_pp_kernel, grid, dim3(512), RING3, (hipStream_t)stream, g);
+        if (tnr_gemm_opts()->tnpp) {
+            // persistent: at most one workgroup per CU (and at least one per XCD label) pulls the (split, tile) units
+            if (!(g.queue = pp_queue_of((hipStream_t)stream))) return TNR_EUNSUPPORTED;
+            const int n_cu = device_cus();
+            dim3 pgrid((unsigned)std::min<int64_t>((int64_t)grid.x, std::max(n_cu, 8)));
+            hipLaunchKernelGGL(gemm_tn_pp_kernel, pgrid, dim3(512), RING3 + 64, (hipStream_t)stream, g);
+        }
         else hipLaunchKernelGGL(gemm_tn256x256_kernel, grid, dim3(512), RING3, (hipStream_t)stream, g);
     }
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad");

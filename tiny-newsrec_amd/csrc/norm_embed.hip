@@ -1,6 +1,8 @@
 // HBM-bound row kernels: embedding gather + LayerNorm, LayerNorm fwd/bwd, rel-pos table, column sums.
-// One wave per row of H = 256*V elements; each lane owns V runs of 4 consecutive elements
-// (8-byte bf16 / 16-byte fp32 accesses, 512 B coalesced per wave-instruction).
+// LayerNorm forward / backward: HALF a wave per row of H = 256*V elements, each lane owning V runs of 8 consecutive elements, so that
+// every access of the 16-bit rows is 16 bytes wide (512 contiguous bytes per half wave and instruction; the 8-byte form of
+// rounds 1-2 ran at 0.50-0.60 of the HBM rate).  The embedding kernel keeps one wave per row: its rows are fp32 (16-byte accesses
+// already).
 #include "common.h"
 #include "dropout.h"
 
@@ -78,41 +80,62 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const TokT* __restrict__ 
     }
 }
 
+__device__ __forceinline__ float half_sum(float v) {      // over the 32 lanes of this lane's half wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ xin, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, bf16* __restrict__ y,
                                                      float* __restrict__ stats, int64_t M) {
     const int H = 256 * V;
-    const int lane = threadIdx.x & 63;
-    int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int hl = threadIdx.x & 31;
+    int64_t m = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
     if (m >= M) return;
-    float x[V][4];
+    float x[V][8];
+    float s = 0.f;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        bf16x4 a = *(const bf16x4*)(xin + m * H + v * 256 + lane * 4);
+        const bf16x8 a = *(const bf16x8*)(xin + m * H + v * 256 + hl * 8);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[v][r] = (float)a[r];
+        for (int r = 0; r < 8; ++r) {
+            x[v][r] = (float)a[r];
+            s += x[v][r];
+        }
     }
-    float mean, rstd;
-    row_stats<V>(x, H, mean, rstd, eps);
-    if (stats && lane == 0) {
+    const float mean = half_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float d = x[v][r] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(half_sum(q) / (float)H + eps);
+    if (stats && hl == 0) {
         stats[m * 2] = mean;
         stats[m * 2 + 1] = rstd;
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        int c = v * 256 + lane * 4;
-        f32x4 gm = *(const f32x4*)(gamma + c);
-        f32x4 bt = *(const f32x4*)(beta + c);
-        bf16x4 o;
+        const int c = v * 256 + hl * 8;
+        const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+        bf16x8 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)((x[v][r] - mean) * rstd * gm[r] + bt[r]);
-        *(bf16x4*)(y + m * H + c) = o;
+        for (int r = 0; r < 4; ++r) {
+            o[r] = (bf16)((x[v][r] - mean) * rstd * g0[r] + b0[r]);
+            o[4 + r] = (bf16)((x[v][4 + r] - mean) * rstd * g1[r] + b1[r]);
+        }
+        *(bf16x8*)(y + m * H + c) = o;
     }
 }
 
 // dx = rstd * (dxh - mean(dxh) - xh * mean(dxh*xh)), dxh = dy*gamma ; per-block partial dgamma/dbeta
-constexpr int LNB_ROWS = 128;  // rows per block (4 waves x 32 rows); short inputs use 32 so that every CU gets work
+constexpr int LNB_ROWS = 128;  // rows per block (8 half waves x 16 rows); short inputs use 32 so that every CU gets work
 static inline int lnb_rows(int64_t M) { return M >= 32768 ? LNB_ROWS : 32; }
 static inline int64_t lnb_blocks(int64_t M) { return (M + lnb_rows(M) - 1) / lnb_rows(M); }
 template <int V>
@@ -122,32 +145,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      int rows_per_block, bf16* __restrict__ dxm, TnrDrop drop) {
     const int H = 256 * V;
     __shared__ float red[4][3][256 * V];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float gm[V][4], dg[V][4], db[V][4], dxs[V][4];
+    const int lane = threadIdx.x & 63, hl = lane & 31, w = threadIdx.x >> 6, hw = threadIdx.x >> 5;
+    float gm[V][8], dg[V][8], db[V][8], dxs[V][8];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        f32x4 t = *(const f32x4*)(gamma + v * 256 + lane * 4);
+        const f32x4 t0 = *(const f32x4*)(gamma + v * 256 + hl * 8), t1 = *(const f32x4*)(gamma + v * 256 + hl * 8 + 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            gm[v][r] = t[r];
-            dg[v][r] = 0.f;
-            db[v][r] = 0.f;
-            dxs[v][r] = 0.f;
-        }
+        for (int r = 0; r < 4; ++r) { gm[v][r] = t0[r]; gm[v][4 + r] = t1[r]; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { dg[v][r] = 0.f; db[v][r] = 0.f; dxs[v][r] = 0.f; }
     }
-    for (int it = 0; it < rows_per_block / 4; ++it) {
-        int64_t m = (int64_t)blockIdx.x * rows_per_block + it * 4 + w;
+    for (int it = 0; it < rows_per_block / 8; ++it) {
+        const int64_t m = (int64_t)blockIdx.x * rows_per_block + it * 8 + hw;
         if (m >= M) break;
-        float mean = stats[m * 2], rstd = stats[m * 2 + 1];
-        float xh[V][4], g[V][4];
+        const float mean = stats[m * 2], rstd = stats[m * 2 + 1];
+        float xh[V][8], g[V][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            bf16x4 a = *(const bf16x4*)(xin + m * H + v * 256 + lane * 4);
-            bf16x4 d = *(const bf16x4*)(dy + m * H + v * 256 + lane * 4);
+            const bf16x8 a = *(const bf16x8*)(xin + m * H + v * 256 + hl * 8);
+            const bf16x8 d = *(const bf16x8*)(dy + m * H + v * 256 + hl * 8);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float dyv = (float)d[r];
+            for (int r = 0; r < 8; ++r) {
+                const float dyv = (float)d[r];
                 xh[v][r] = ((float)a[r] - mean) * rstd;
                 g[v][r] = dyv * gm[v][r];
                 s1 += g[v][r];
@@ -156,44 +176,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                 db[v][r] += dyv;
             }
         }
-        s1 = wave_sum(s1) / (float)H;
-        s2 = wave_sum(s2) / (float)H;
+        s1 = half_sum(s1) / (float)H;
+        s2 = half_sum(s2) / (float)H;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            bf16x4 o;
+            bf16x8 o;
             if (dxm) {
                 // the Linear in front of this LayerNorm was followed by dropout (BertSelfOutput / BertOutput): its output
                 // gradient is dx * mask / (1 - p) (second output, what its wgrad / dgrad / bias gradient consume), the
                 // residual branch takes dx itself
-                float dm[4];
-                tnr_drop4(drop, (uint64_t)m * H + v * 256 + lane * 4, dm);
-                bf16x4 om;
+                float dm[8];
+                tnr_drop8(drop, ((uint64_t)m * H + v * 256 + hl * 8) >> 3, dm);
+                bf16x8 om;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 8; ++r) {
                     const float t = rstd * (g[v][r] - s1 - xh[v][r] * s2);
                     o[r] = (bf16)t;
                     om[r] = (bf16)(t * dm[r]);
                     dxs[v][r] += (float)om[r];
                 }
-                *(bf16x4*)(dxm + m * H + v * 256 + lane * 4) = om;
+                *(bf16x8*)(dxm + m * H + v * 256 + hl * 8) = om;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 8; ++r) {
                     o[r] = (bf16)(rstd * (g[v][r] - s1 - xh[v][r] * s2));
                     dxs[v][r] += (float)o[r];          // the rounded value the wgrad kernels will see
                 }
             }
-            *(bf16x4*)(dx + m * H + v * 256 + lane * 4) = o;
+            *(bf16x8*)(dx + m * H + v * 256 + hl * 8) = o;
         }
     }
     if (part == nullptr) return;
+    // the two half waves of a wave own the same columns: combine them, then the four waves through LDS (fixed order)
 #pragma unroll
     for (int v = 0; v < V; ++v)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            red[w][0][v * 256 + lane * 4 + r] = dg[v][r];
-            red[w][1][v * 256 + lane * 4 + r] = db[v][r];
-            red[w][2][v * 256 + lane * 4 + r] = dxs[v][r];
+        for (int r = 0; r < 8; ++r) {
+            const float a = dg[v][r] + __shfl_xor(dg[v][r], 32, 64);
+            const float b = db[v][r] + __shfl_xor(db[v][r], 32, 64);
+            const float c = dxs[v][r] + __shfl_xor(dxs[v][r], 32, 64);
+            if (lane < 32) {
+                red[w][0][v * 256 + hl * 8 + r] = a;
+                red[w][1][v * 256 + hl * 8 + r] = b;
+                red[w][2][v * 256 + hl * 8 + r] = c;
+            }
         }
     __syncthreads();
     for (int c = threadIdx.x; c < 3 * H; c += 256) {
@@ -464,7 +490,7 @@ extern "C" int TNR_NAME(tnr_ln_fwd)(const void* x, const float* gamma, const flo
                           int64_t M, int H, void* stream) {
     TNR_CHECK_ARG(x && gamma && beta && y && M >= 1, "tnr_ln_fwd: null pointer");
     TNR_CHECK_ARG(H == 768 || H == 256 || H == 512 || H == 1024, "tnr_ln_fwd: H must be 256/512/768/1024");
-    dim3 grid((unsigned)((M + 3) / 4)), blk(256);
+    dim3 grid((unsigned)((M + 7) / 8)), blk(256);        // half a wave per row
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(V) hipLaunchKernelGGL(ln_fwd_kernel<V>, grid, blk, 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)y, stats, M)
     switch (H / 256) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }

@@ -12,7 +12,8 @@ T.lib()
 dev, M, td, sfx = "cuda:0", 52800, torch.float16, "_f16"
 side = torch.cuda.Stream()
 import engine as E
-for (kind, N, K) in (("nt", 3072, 768), ("nt", 768, 3072), ("tn", 3072, 768)):
+MULT = int(os.environ.get("UNITS", 1))          # weight gradient: UNITS x the single-GPU split count (finer work units for the queue)
+for (kind, N, K) in (("nt", 3072, 768), ("nt", 768, 3072), ("tn", 3072, 768), ("tn", 768, 768), ("tn", 2304, 768)):
     if kind == "nt":
         a = (torch.randn((M, K), device=dev) * 0.5).to(td); b = (torch.randn((N, K), device=dev) * 0.05).to(td)
         c = torch.zeros((M, N), device=dev, dtype=td)
@@ -21,7 +22,7 @@ for (kind, N, K) in (("nt", 3072, 768), ("nt", 768, 3072), ("tn", 3072, 768)):
         Mp = (M + 127) // 128 * 128
         dy = torch.zeros((Mp, N), device=dev, dtype=td); x = torch.zeros((Mp, K), device=dev, dtype=td)
         dy[:M] = (torch.randn((M, N), device=dev) * 0.1).to(td); x[:M] = torch.randn((M, K), device=dev).to(td)
-        dw = torch.zeros((N, K), device=dev); sp = E.Engine._wgrad_splits(N, K)[0]; ws = torch.zeros(N * K * sp, device=dev)
+        dw = torch.zeros((N, K), device=dev); sp = min(64, E.Engine._wgrad_splits(N, K)[0] * MULT); ws = torch.zeros(N * K * sp, device=dev)
         run = lambda: T.call("tnr_gemm_tn_wgrad" + sfx, dy, N, x, K, dw, K, M, N, K, ws, sp, 0)
     for _ in range(3): run()
     torch.cuda.synchronize()
