@@ -314,12 +314,14 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (tools/pmc.sh); it is only quoted while
             # the profiled library is byte-identical to the one running now
-            traffic, busy, pj = None, None, os.path.join(ROOT, "profiles", "r02_gemm_nt_pmc.json")
-            if os.path.exists(pj):
+            traffic, busy = None, None
+            import glob
+            for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_nt_pmc.json")), reverse=True):
                 pm = json.load(open(pj))
                 if pm.get("lib_sha16") == lib_sha16() and pm.get("dtype") == a.dtype:
                     traffic = pm.get("hbm_bytes_per_launch")
                     busy = pm.get("mfma_busy_frac")          # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE): SURVEY 8-d's "MFMA utilisation"
+                    break
             names = {128: "gemm_nt_kernel(128x128)", 2128: "gemm_nt256_kernel(256x128)", 256: "gemm_nt_pp_kernel<8,*>(256- / 224-row tiles)",
                      224: "gemm_nt_pp_kernel<7,*>(224- / 192-row tiles)"}
             out["roofline"] = {"bound": "mfma",

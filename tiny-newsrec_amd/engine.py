@@ -497,12 +497,17 @@ class Engine:
         self.ws = f(max(self._wgrad_splits(n_, k_)[1] for n_, k_ in ((3 * H, H), (H, H), (I, H), (H, I), (QPAD, H))))
         self._rel_stale = True       # filled by the first encode() (no kernel launch at construction time)
 
+    WGRAD_UNITS = 1     # work units (split, tile) per workgroup of the queue-fed weight-gradient kernel.  1 = one full round
+                        # (fastest alone).  Beside CUs held by an overlapped all-reduce a late workgroup costs a whole unit:
+                        # x1.65 at 1, x1.25 at 2, x1.1-1.15 at 4 -- but every doubling adds a round of fp32 slab traffic
+                        # (alone: +10 % at 2, +24 % at 4 for the 3072 x 768 gradient; tools/cu_contention.py)
+
     @staticmethod
-    def _wgrad_splits(N, K):
-        """-> (splits over M, workspace elems): one full round of workgroups on the 256 CUs (one 256x256 output
-        tile x split each); more splits only add fp32 slab traffic (N*K*4 B written and re-read per split)."""
+    def _wgrad_splits(N, K, units=None):
+        """-> (splits over M, workspace elems): `units` (default Engine.WGRAD_UNITS) rounds of workgroups on the 256 CUs (one
+        256x256 output tile x split each); more splits only add fp32 slab traffic (N*K*4 B written and re-read per split)."""
         tiles = (N // 256) * (K // 256) if (N % 256 == 0 and K % 256 == 0) else (N // 128) * (K // 128)
-        splits = max(1, min(64, 256 // max(tiles, 1)))
+        splits = max(1, min(64, (units or Engine.WGRAD_UNITS) * 256 // max(tiles, 1)))
         return splits, T.query("tnr_gemm_tn_ws_elems", N, K, splits)
 
     # ------------------------------------------------------------------ kernel wrappers
@@ -837,8 +842,9 @@ class Engine:
         g = self.p
         S, dS = self.S[:Rt], self.dS
         hidx, cidx = self._idx(B)
+        rbh = self.red.setdefault(("heads", 0, N if self.plan is None else self.plan.n_enc), _ReduceBatch(self.dev))
         if T_ > 0:
-            self._transform_grads(Rt)
+            self._transform_grads(Rt, rbh)
         # scorer + user encoder
         T.call("tnr_score_bwd", S, cidx, S[N:], self.dscore, dS, dS[N:], B, C, D)
         ue = "student.user_encoder."
@@ -871,8 +877,7 @@ class Engine:
             T.call("tnr_user_blend_bwd", self.nr_dhv, self.mask, hidx, ulm, dS, self.user_part[:, 2 * Qu:], self.user_part.shape[1],
                    B, U, D)
         ps = self.user_part.shape[1]
-        rb = self.red.setdefault(("heads", 0, N if self.plan is None else self.plan.n_enc), _ReduceBatch(self.dev))
-        rb.add(self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.bias", ps, (ps,), grad=True))
+        rbh.add(self.user_part, B, ps, ps, self._view(ue + "attn.att_fc1.bias", ps, (ps,), grad=True))
         if self.plan is None:
             self.backward_encoder(dS[:N], N, after_bucket=after_bucket)
         else:
@@ -880,14 +885,16 @@ class Engine:
             T.call("tnr_segment_sum_rows", dS, p.order, p.seg, p.n_enc, D, self.dSv)
             self.backward_encoder(self.dSv, p.n_enc, after_bucket=after_bucket)
 
-    def _transform_grads(self, Rt):
-        """dW_i = dP_i^T X_i ; db_i = colsum(dP_i)   (transform_matrix, model_bert.py:278,283)"""
+    def _transform_grads(self, Rt, rb):
+        """dW_i = dP_i^T X_i ; db_i = colsum(dP_i)   (transform_matrix, model_bert.py:278,283).  The bias column sums ride in the
+        heads' batched reduction `rb` (flushed in backward_encoder, after the GEMM above has read dP: its first level sums in place)."""
         D, T_ = self.cfg.D, self.cfg.T
         dWt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D), grad=True)
         dbt = self._view("transform_matrix.0.bias", T_ * D, (T_, D), grad=True)
         self._sgemm(self.dP, 1, D, Rt * D, self.X, 1, D, self.X.stride(0), dWt, D, D * D, None, 0, D, D, Rt, batch=T_,
                     ksplit=self.KS)
-        self._c("tnr_colsum_batched", self.dP, D, Rt * D, T.F32, Rt, D, T_, dbt, self.cs_part, 0)
+        for i in range(T_):
+            rb.add(self.dP[i], Rt, D, D, dbt[i])
 
     def backward_encoder(self, dvec, N, acc=0, after_bucket=None):
         """NewsEncoder backward for the N sequences of the last encode(): dvec (N,D) fp32 = d loss / d news vectors.
@@ -903,8 +910,8 @@ class Engine:
         wd = g(PFX + "dense.weight")
         self._sgemm(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N, ksplit=self.KS,
                     beta=float(acc))
-        self._c("tnr_colsum", dvec, D, T.F32, N, D, gr[PFX + "dense.bias"], self.cs_part, acc)
         self._sgemm(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D, alpha=self.gscale)   # loss scale enters here
+        rb.add(dvec, N, D, D, gr[PFX + "dense.bias"], acc)       # column sums; in place, behind the two GEMMs that read dvec
         y = self.y_last
         if cfg.pooling == "att":
             self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,

@@ -23,7 +23,7 @@ csrc/dropout.h; the title and the body pass draw independent masks, as two passe
 import torch
 
 import tnr_hip as T
-from engine import Engine, EngineConfig
+from engine import Engine, EngineConfig, _ReduceBatch
 
 
 class Stage1Engine:
@@ -148,7 +148,7 @@ class Stage1Engine:
         C, D = self.cfg_t.C, self.cfg_t.D
         S, dS = t.S[:Rt], t.dS
         if self.cfg_t.T:
-            t._transform_grads(Rt)
+            t._transform_grads(Rt, t.red.setdefault(("heads", 0, N), _ReduceBatch(t.dev)))
         T.call("tnr_score_bwd", S, t.cidx, S[N:], t.dscore, dS, dS[N:], B, C, D)
         t.backward_encoder(dS[:N], N, acc=0)
         b.backward_encoder(dS[N:Rt], B, acc=1, after_bucket=after_bucket)
