@@ -216,6 +216,23 @@ int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA, const int3
               int64_t M, int64_t N, int64_t K, int batch, float alpha, float beta,
               int ksplit, float* part, void* stream);
 
+/* Up to 8 independent tnr_sgemm problems in ONE launch (+ one launch that reduces every split problem): the heads' GEMMs are
+ * latency-sized, so problems that do not depend on each other cost the longest of them instead of their sum.  Each problem is
+ * computed exactly as tnr_sgemm computes it (same tiles, same K split rule, same summation order): identical bits.  The
+ * problem array is HOST memory, read at the call. */
+typedef struct tnr_sgemm_problem {
+    const float* A; int64_t a_rs, a_cs, sA;
+    const float* B; int64_t b_rs, b_cs, sB;
+    float* C; int64_t ldc, sC;
+    const float* bias; int64_t sBias;
+    int64_t M, N, K;
+    int batch;
+    float alpha, beta;
+    int ksplit;
+    float* part;             /* ksplit > 1: (ksplit, batch, M, N) fp32 workspace of THIS problem (not shared inside a group) */
+} tnr_sgemm_problem_t;
+int tnr_sgemm_group(const tnr_sgemm_problem_t* problems, int n, void* stream);
+
 /* out[z, out_row0 + r, :] = tbl[z, idx[r], :]  (dataloader.py:140-144 teacher-embedding gather, done on
  * device from resident tables instead of on the host) */
 int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, int64_t n_idx, int D, int n_model,

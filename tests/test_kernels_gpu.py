@@ -679,3 +679,43 @@ def test_cls_and_mean_pooling(mean):
     torch.cuda.synchronize()
     want = np.repeat(dnv[:, None, :] / L, L, 1) if mean else np.concatenate([dnv[:, None, :], np.zeros((n_seq, L - 1, H), np.float32)], 1)
     np.testing.assert_allclose(dy.float().cpu().numpy().reshape(n_seq, L, H), want, rtol=1e-2, atol=1e-3)
+
+
+def test_sgemm_group_equals_separate_calls_bit_for_bit():
+    """tnr_sgemm_group: several independent fp32 GEMMs (plain, transposed-A split-K with accumulation, batched with bias, batched
+    split-K) in one launch + one grouped split reduce -- every output bit-identical to its own tnr_sgemm call."""
+    rs = np.random.RandomState(11)
+    r = lambda *shape: dev(rs.standard_normal(shape).astype(np.float32))
+    dvec, nv, wd = r(1760, 256), r(1760, 768), r(256, 768)
+    dP, X = r(4, 1792, 256), r(4, 1792, 256)
+    Wt, bt = r(4, 256, 256), r(4, 256)
+    c0 = r(256, 768)
+    probs = [
+        dict(A=dvec, a_rs=1, a_cs=256, sA=0, B=nv, b_rs=1, b_cs=768, sB=0, C=None, ldc=768, sC=0, bias=None, sBias=0, M=256, N=768, K=1760,
+             batch=1, alpha=1.0, beta=1.0, ksplit=8, shape=(256, 768), init=c0),                                  # dW = dY^T X, accumulated
+        dict(A=dvec, a_rs=256, a_cs=1, sA=0, B=wd, b_rs=1, b_cs=768, sB=0, C=None, ldc=768, sC=0, bias=None, sBias=0, M=1760, N=768, K=256,
+             batch=1, alpha=1024.0, beta=0.0, ksplit=1, shape=(1760, 768), init=None),                            # dX = dY W, scaled
+        dict(A=X, a_rs=256, a_cs=1, sA=1792 * 256, B=Wt, b_rs=256, b_cs=1, sB=65536, C=None, ldc=256, sC=1792 * 256, bias=bt, sBias=256,
+             M=1792, N=256, K=256, batch=4, alpha=1.0, beta=0.0, ksplit=1, shape=(4, 1792, 256), init=None),      # batched projection + bias
+        dict(A=dP, a_rs=1, a_cs=256, sA=1792 * 256, B=X, b_rs=1, b_cs=256, sB=1792 * 256, C=None, ldc=256, sC=65536, bias=None, sBias=0,
+             M=256, N=256, K=1792, batch=4, alpha=1.0, beta=0.0, ksplit=8, shape=(4, 256, 256), init=None),       # batched split-K
+    ]
+    outs = {}
+    for mode in ("separate", "group"):
+        cs, parts = [], []
+        for q in probs:
+            c = q["init"].clone() if q["init"] is not None else torch.full(q["shape"], 3.0, device=DEV)
+            cs.append(c)
+            parts.append(torch.zeros(q["ksplit"] * q["batch"] * q["M"] * q["N"], device=DEV) if q["ksplit"] > 1 else None)
+        if mode == "separate":
+            for q, c, p_ in zip(probs, cs, parts):
+                T.call("tnr_sgemm", q["A"], q["a_rs"], q["a_cs"], q["sA"], None, q["B"], q["b_rs"], q["b_cs"], q["sB"], c, q["ldc"], q["sC"],
+                       q["bias"], q["sBias"], q["M"], q["N"], q["K"], q["batch"], q["alpha"], q["beta"], q["ksplit"], p_)
+        else:
+            T.sgemm_group([dict({k: v for k, v in q.items() if k not in ("shape", "init")}, C=c, part=p_) for q, c, p_ in zip(probs, cs, parts)])
+        torch.cuda.synchronize()
+        outs[mode] = cs
+    for a, b in zip(outs["separate"], outs["group"]):
+        assert torch.equal(a, b)
+    want = c0.cpu().numpy() + dvec.cpu().numpy().T @ nv.cpu().numpy()
+    np.testing.assert_allclose(outs["group"][0].cpu().numpy(), want, rtol=1e-4, atol=2e-3)

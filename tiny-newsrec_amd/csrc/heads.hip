@@ -113,21 +113,21 @@ struct SgemmArgs {
     int M, N, K;
     float alpha, beta;
     int ksplit, kchunk, batch;      // ksplit > 1: C = partials (ksplit, batch, M, N), no bias / beta
+    float* A_out;                   // grouped launches: the destination of a split problem (its C is the partial buffer)
 };
 
 // One K step is 64 deep: 16 + 16 scalar loads per thread issued together (the next step's fly under this step's 32 MFMAs), so
 // a step costs about one memory latency OR its MFMA time (32 x 64 cycles), whichever is longer -- with 16-deep steps every
 // step paid a full latency for 8 MFMAs (44 us for the 1760 x 256 x 768 dense layer, 13 us for an M = 1 call).
 constexpr int SG_BK = 64;
-__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
-    __shared__ float As[64][SG_BK + 1], Bs[64][SG_BK + 1];
+__device__ __forceinline__ void sgemm_tile(const SgemmArgs& g, int bx, int by, int bz, float (&As)[64][SG_BK + 1], float (&Bs)[64][SG_BK + 1]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    const int zb = blockIdx.z / g.ksplit, zk = blockIdx.z - zb * g.ksplit;
+    const int zb = bz / g.ksplit, zk = bz - zb * g.ksplit;
     const float* A = g.A + zb * g.sA;
     const float* B = g.B + zb * g.sB;
     float* C = g.ksplit > 1 ? g.C + ((int64_t)zk * g.batch + zb) * g.M * g.N : g.C + zb * g.sC;
     const int64_t ldc = g.ksplit > 1 ? g.N : g.ldc;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = by * 64, n0 = bx * 64;
     const int kbeg = zk * g.kchunk;
     const int kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
     f32x16 acc;
@@ -184,6 +184,56 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
+    __shared__ float As[64][SG_BK + 1], Bs[64][SG_BK + 1];
+    sgemm_tile(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Several independent GEMMs in ONE launch (tnr_sgemm_group): the heads' fp32 GEMMs are latency-sized (a workgroup's time is its
+// K loop, few tiles each), so problems that do not depend on each other cost the longest of them instead of their sum.
+constexpr int SG_MAXP = 8;
+struct SgemmGroup {
+    SgemmArgs a[SG_MAXP];
+    int start[SG_MAXP + 1];        // first block of each problem ; start[n] = grid size
+    int gx[SG_MAXP], gy[SG_MAXP];  // column / row tiles of each problem
+    int64_t rstart[SG_MAXP + 1];   // split-K reduce: first element of each problem (problems without a split have none)
+    float alpha[SG_MAXP], beta[SG_MAXP];
+    int n;
+};
+__global__ __launch_bounds__(256) void sgemm_group_kernel(SgemmGroup g) {
+    __shared__ float As[64][SG_BK + 1], Bs[64][SG_BK + 1];
+    const int b = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < SG_MAXP; ++k)
+        if (k < g.n && b >= g.start[k]) i = k;
+    const int l = b - g.start[i];
+    const int per = g.gx[i] * g.gy[i];
+    const int bz = l / per, r = l - bz * per;
+    const int by = r / g.gx[i], bx = r - by * g.gx[i];
+    sgemm_tile(g.a[i], bx, by, bz, As, Bs);
+}
+__global__ __launch_bounds__(256) void sgemm_group_reduce_kernel(SgemmGroup g) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.rstart[g.n]) return;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < SG_MAXP; ++k)
+        if (k < g.n && e >= g.rstart[k]) i = k;
+    const SgemmArgs& a = g.a[i];
+    const int64_t per = (int64_t)a.M * a.N, total = per * a.batch, j = e - g.rstart[i];
+    const float* part = a.C;                             // split problems carry their partial buffer in C ...
+    float t = part[j];
+    for (int s = 1; s < a.ksplit; ++s) t += part[(int64_t)s * total + j];
+    const int z = (int)(j / per);
+    const int64_t rr = j - (int64_t)z * per;
+    const int m = (int)(rr / a.N), n = (int)(rr - (int64_t)m * a.N);
+    float* c = (float*)a.A_out + (int64_t)z * a.sC + (int64_t)m * a.ldc + n;      // ... and the real output here
+    float v = g.alpha[i] * t + (a.bias ? a.bias[(int64_t)z * a.sBias + n] : 0.f);
+    if (g.beta[i] != 0.f) v += g.beta[i] * *c;
+    *c = v;
 }
 
 // split-K epilogue: C_z[m,n] = alpha * sum_s part[s][z][m][n] + bias_z[n] + beta * C_z[m,n], slices summed in order
@@ -971,7 +1021,7 @@ extern "C" int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA,
         ksplit = (int)((K + kchunk - 1) / kchunk);
     }
     SgemmArgs g{A, a_rs, a_cs, sA, B, b_rs, b_cs, sB, ksplit > 1 ? part : C, ldc, sC, bias, sBias, (int)M, (int)N, (int)K,
-                alpha, ksplit > 1 ? 0.f : beta, ksplit, kchunk, batch};
+                alpha, ksplit > 1 ? 0.f : beta, ksplit, kchunk, batch, C};
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(batch * ksplit));
     hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     TNR_CHECK_LAUNCH("tnr_sgemm");
@@ -980,6 +1030,41 @@ extern "C" int tnr_sgemm(const float* A, int64_t a_rs, int64_t a_cs, int64_t sA,
         hipLaunchKernelGGL(sgemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
                            ksplit, batch, (int)M, (int)N, C, ldc, sC, bias, sBias, alpha, beta);
         TNR_CHECK_LAUNCH("tnr_sgemm/reduce");
+    }
+    return TNR_OK;
+}
+
+extern "C" int tnr_sgemm_group(const tnr_sgemm_problem_t* p, int n, void* stream) {
+    TNR_CHECK_ARG(p && n >= 1 && n <= SG_MAXP, "tnr_sgemm_group: 1..%d problems", SG_MAXP);
+    SgemmGroup g;
+    g.n = n;
+    g.start[0] = 0;
+    g.rstart[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const tnr_sgemm_problem_t& q = p[i];
+        TNR_CHECK_ARG(q.A && q.B && q.C && q.M >= 1 && q.N >= 1 && q.K >= 1 && q.batch >= 1, "tnr_sgemm_group: bad problem %d", i);
+        int ksplit = q.ksplit < 1 ? 1 : q.ksplit;
+        int kchunk = (int)q.K;
+        if (ksplit > 1) {
+            TNR_CHECK_ARG(q.part != nullptr, "tnr_sgemm_group: split-K needs the partial buffer (problem %d)", i);
+            kchunk = (int)(((q.K + ksplit - 1) / ksplit + 15) / 16 * 16);       // the same split rule as tnr_sgemm: identical bits
+            ksplit = (int)((q.K + kchunk - 1) / kchunk);
+        }
+        g.a[i] = SgemmArgs{q.A, q.a_rs, q.a_cs, q.sA, q.B, q.b_rs, q.b_cs, q.sB, ksplit > 1 ? q.part : q.C, q.ldc, q.sC, q.bias, q.sBias,
+                           (int)q.M, (int)q.N, (int)q.K, q.alpha, ksplit > 1 ? 0.f : q.beta, ksplit, kchunk, q.batch, q.C};
+        g.gx[i] = (int)((q.N + 63) / 64);
+        g.gy[i] = (int)((q.M + 63) / 64);
+        g.start[i + 1] = g.start[i] + g.gx[i] * g.gy[i] * q.batch * ksplit;
+        g.rstart[i + 1] = g.rstart[i] + (ksplit > 1 ? (int64_t)q.batch * q.M * q.N : 0);
+        g.alpha[i] = q.alpha;
+        g.beta[i] = q.beta;
+    }
+    for (int i = n; i < SG_MAXP; ++i) { g.start[i + 1] = g.start[n]; g.rstart[i + 1] = g.rstart[n]; g.gx[i] = g.gy[i] = 1; g.a[i] = g.a[0]; g.alpha[i] = g.beta[i] = 0.f; }
+    hipLaunchKernelGGL(sgemm_group_kernel, dim3((unsigned)g.start[n]), dim3(256), 0, (hipStream_t)stream, g);
+    TNR_CHECK_LAUNCH("tnr_sgemm_group");
+    if (g.rstart[n] > 0) {
+        hipLaunchKernelGGL(sgemm_group_reduce_kernel, dim3((unsigned)((g.rstart[n] + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g);
+        TNR_CHECK_LAUNCH("tnr_sgemm_group/reduce");
     }
     return TNR_OK;
 }

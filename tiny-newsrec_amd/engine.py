@@ -494,6 +494,7 @@ class Engine:
         self.epre_t = f(T_, B * cfg.U, cfg.Qu)
         self.KS = 8                                                        # split-K of the long-K small GEMMs
         self.sg_part = f(self.KS * max(T_ * D * D, D * H, 3 * D * D, T_ * Rt * D, N * max(H, D), T_ * B * cfg.U * max(cfg.Qu, 3 * D)))
+        self.sg_part2 = f(self.KS * max(cfg.Qu * D, 3 * D * D if cfg.nrms_heads else 1))       # second split problem of a grouped launch
         self.ws = f(max(self._wgrad_splits(n_, k_)[1] for n_, k_ in ((3 * H, H), (H, H), (I, H), (H, I), (QPAD, H))))
         self._rel_stale = True       # filled by the first encode() (no kernel launch at construction time)
 
@@ -540,6 +541,27 @@ class Engine:
         T.call("tnr_sgemm", A, a_rs, a_cs, sA, None, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch, alpha, beta,
                ksplit, self.sg_part if ksplit > 1 else None)
 
+    def _sgemm_problem(self, A, a_rs, a_cs, sA, Bm, b_rs, b_cs, sB, C, ldc, sC, bias, sBias, M, N, K, batch=1, ksplit=None, alpha=1.0,
+                       beta=0.0, part=None):
+        """The arguments of _sgemm as one member of a grouped launch (T.sgemm_group: independent small GEMMs in one launch, each
+        computed exactly as its own tnr_sgemm call would).  A split problem needs a partial buffer of its own (`part`)."""
+        if ksplit is None:
+            ksplit = max(1, min(K // getattr(self, "sg_kdiv", 256), 8))
+        if ksplit > 1:
+            part = self.sg_part if part is None else part
+            assert ksplit * batch * M * N <= part.numel(), "fp32 GEMM workspace too small for its K split"
+        return dict(A=A, a_rs=a_rs, a_cs=a_cs, sA=sA, B=Bm, b_rs=b_rs, b_cs=b_cs, sB=sB, C=C, ldc=ldc, sC=sC, bias=bias, sBias=sBias,
+                    M=M, N=N, K=K, batch=batch, alpha=alpha, beta=beta, ksplit=ksplit, part=part if ksplit > 1 else None)
+
+    def _sgemm_group(self, problems):
+        """Independent fp32 GEMMs in one launch (Engine.group_sgemm = False: one tnr_sgemm each, the same bits; tools/step_ab.py)."""
+        if getattr(self, "group_sgemm", True):
+            T.sgemm_group(problems)
+            return
+        for q in problems:
+            T.call("tnr_sgemm", q["A"], q["a_rs"], q["a_cs"], q["sA"], None, q["B"], q["b_rs"], q["b_cs"], q["sB"], q["C"], q["ldc"], q["sC"],
+                   q["bias"], q["sBias"], q["M"], q["N"], q["K"], q["batch"], q["alpha"], q["beta"], q["ksplit"], q["part"])
+
     # ------------------------------------------------------------------ forward
     def build_frozen_cache(self, news_combined):
         """The layers below the first trainable one never change during training (run.py:101-112), so for a resident
@@ -577,7 +599,7 @@ class Engine:
             self._pos_cache = (key, pid)
         return pid
 
-    def encode(self, tok, n_seq, nidx=None, out=None, stop_at=None, train=True):
+    def encode(self, tok, n_seq, nidx=None, out=None, stop_at=None, train=True, extra=None):
         """NewsEncoder.forward model_bert.py:119-137 -> news vectors S[:n_seq] (fp32).
         tok (n_seq, 2L) int64 on device, or (nidx given) tok = resident news_combined (n+1, 2L) int32 and
         nidx (n_seq,) int32 news indices.  stop_at = l: return the hidden states entering layer l instead."""
@@ -652,7 +674,11 @@ class Engine:
             self._c("tnr_pool_fwd", x, self.nv, n_seq, L, H, int(cfg.pooling == "mean"))
         wd = g(PFX + "dense.weight")
         dst = self.S if out is None else out
-        self._sgemm(self.nv, H, 1, 0, wd, H, 1, 0, dst, cfg.D, 0, g(PFX + "dense.bias"), 0, n_seq, cfg.D, H)
+        dense = (self.nv, H, 1, 0, wd, H, 1, 0, dst, cfg.D, 0, g(PFX + "dense.bias"), 0, n_seq, cfg.D, H)
+        if extra:      # independent fp32 GEMMs the caller had pending (the teachers' projection): one launch with the dense layer
+            self._sgemm_group([self._sgemm_problem(*dense)] + list(extra))
+        else:
+            self._sgemm(*dense)
         return dst[:n_seq]
 
     # ------------------------------------------------------------------ forward-only paths
@@ -737,16 +763,21 @@ class Engine:
                                    self.den_t, B, C, getattr(self, "nr_t", None))
                 Wt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
                 bt = self._view("transform_matrix.0.bias", T_ * D, (T_, D))
-                self._sgemm(self.X, D, 1, self.X.stride(0), Wt, D, 1, D * D, self.Pm, D, self.Pm.stride(0), bt, D, Rt, D, D,
-                            batch=T_)
+                proj = (self.X, D, 1, self.X.stride(0), Wt, D, 1, D * D, self.Pm, D, self.Pm.stride(0), bt, D, Rt, D, D)
+                if side is main:       # the projection rides in the launch of the news encoder's dense layer (encode(extra=...))
+                    extra = [self._sgemm_problem(*proj, batch=T_)]
+                else:
+                    self._sgemm(*proj, batch=T_)
+        if T_ == 0 or side is not main:
+            extra = None
         if news_combined is not None:
             self.plan = plan
             if plan is None:
-                self.encode(news_combined, N, nidx=self.nidx)
+                self.encode(news_combined, N, nidx=self.nidx, extra=extra)
             else:
                 # encode each distinct news once, expand to the slots (dedup.py); everything downstream is unchanged
                 assert plan.n_slots == N and plan.n_enc <= self.N_alloc
-                self.encode(news_combined, plan.n_enc, nidx=plan.uniq, out=self.Sv)
+                self.encode(news_combined, plan.n_enc, nidx=plan.uniq, out=self.Sv, extra=extra)
                 T.call("tnr_gather_rows", self.Sv, plan.n_enc, plan.inv, N, D, 1, self.S, self.S.shape[0], 0)
         else:
             assert history.shape[1:] == (U, 2 * L) and candidate.shape[1:] == (C, 2 * L)
@@ -754,7 +785,7 @@ class Engine:
             tok = self.tok[:N]
             tok[:B * U].copy_(history.reshape(B * U, 2 * L))
             tok[B * U:].copy_(candidate.reshape(B * C, 2 * L))
-            self.encode(tok, N)
+            self.encode(tok, N, extra=extra)
         S = self.S[:Rt]
         g = self.p
         Qu = cfg.Qu
@@ -843,8 +874,9 @@ class Engine:
         S, dS = self.S[:Rt], self.dS
         hidx, cidx = self._idx(B)
         rbh = self.red.setdefault(("heads", 0, N if self.plan is None else self.plan.n_enc), _ReduceBatch(self.dev))
+        pend = []                 # fp32 GEMMs that depend on nothing computed below: launched together with the user encoder's
         if T_ > 0:
-            self._transform_grads(Rt, rbh)
+            self._transform_grads(Rt, rbh, pend)
         # scorer + user encoder
         T.call("tnr_score_bwd", S, cidx, S[N:], self.dscore, dS, dS[N:], B, C, D)
         ue = "student.user_encoder."
@@ -857,9 +889,10 @@ class Engine:
         T.call("tnr_user_bwd_pre", pv, ph, pm, g(ue + "pad_doc"), g(ue + "attn.att_fc2.weight"), pu, dS[N:], self.e_u,
                self.alpha_u, self.hv_u, self.dpre_u, self.user_part, B, U, D, Qu)
         # dW1 = dpre^T hv (straight into the gradient) ; dhv = dpre W1      -- fp32 MFMA GEMMs
-        self._sgemm(self.dpre_u, 1, Qu, 0, self.hv_u, 1, D, 0, self.grads[ue + "attn.att_fc1.weight"], D, 0, None, 0,
-                    Qu, D, B * U, ksplit=self.KS)
-        self._sgemm(self.dpre_u, Qu, 1, 0, w1u, 1, D, 0, self.dhv_u, D, 0, None, 0, B * U, D, Qu)
+        self._sgemm_group(pend + [
+            self._sgemm_problem(self.dpre_u, 1, Qu, 0, self.hv_u, 1, D, 0, self.grads[ue + "attn.att_fc1.weight"], D, 0, None, 0,
+                                Qu, D, B * U, ksplit=self.KS, part=self.sg_part2),
+            self._sgemm_problem(self.dpre_u, Qu, 1, 0, w1u, 1, D, 0, self.dhv_u, D, 0, None, 0, B * U, D, Qu)])
         if nrms:
             pd.zero_()
         T.call("tnr_user_bwd_post", self.dhv_u, self.alpha_u, dS[N:], pm, ph, pu, pd, self.user_part, B, U, D, Qu)
@@ -885,14 +918,17 @@ class Engine:
             T.call("tnr_segment_sum_rows", dS, p.order, p.seg, p.n_enc, D, self.dSv)
             self.backward_encoder(self.dSv, p.n_enc, after_bucket=after_bucket)
 
-    def _transform_grads(self, Rt, rb):
+    def _transform_grads(self, Rt, rb, pend=None):
         """dW_i = dP_i^T X_i ; db_i = colsum(dP_i)   (transform_matrix, model_bert.py:278,283).  The bias column sums ride in the
         heads' batched reduction `rb` (flushed in backward_encoder, after the GEMM above has read dP: its first level sums in place)."""
         D, T_ = self.cfg.D, self.cfg.T
         dWt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D), grad=True)
         dbt = self._view("transform_matrix.0.bias", T_ * D, (T_, D), grad=True)
-        self._sgemm(self.dP, 1, D, Rt * D, self.X, 1, D, self.X.stride(0), dWt, D, D * D, None, 0, D, D, Rt, batch=T_,
-                    ksplit=self.KS)
+        dwt = (self.dP, 1, D, Rt * D, self.X, 1, D, self.X.stride(0), dWt, D, D * D, None, 0, D, D, Rt)
+        if pend is None:
+            self._sgemm(*dwt, batch=T_, ksplit=self.KS)
+        else:          # the caller groups it with other independent GEMMs (one launch)
+            pend.append(self._sgemm_problem(*dwt, batch=T_, ksplit=self.KS))
         for i in range(T_):
             rb.add(self.dP[i], Rt, D, D, dbt[i])
 
@@ -908,9 +944,10 @@ class Engine:
         rb = self.red.setdefault(("heads", acc, N), _ReduceBatch(self.dev))
         # dense + pooling of the news encoder
         wd = g(PFX + "dense.weight")
-        self._sgemm(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N, ksplit=self.KS,
-                    beta=float(acc))
-        self._sgemm(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D, alpha=self.gscale)   # loss scale enters here
+        self._sgemm_group([
+            self._sgemm_problem(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N, ksplit=self.KS,
+                                beta=float(acc)),
+            self._sgemm_problem(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D, alpha=self.gscale)])   # loss scale enters here
         rb.add(dvec, N, D, D, gr[PFX + "dense.bias"], acc)       # column sums; in place, behind the two GEMMs that read dvec
         y = self.y_last
         if cfg.pooling == "att":

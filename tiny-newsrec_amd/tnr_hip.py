@@ -31,6 +31,25 @@ class Dropout(_c.Structure):
 
 _D = _c.POINTER(Dropout)
 
+
+class SgemmProblem(_c.Structure):
+    """tnr_sgemm_problem_t (include/tnr_hip.h): one member of a tnr_sgemm_group launch."""
+    _fields_ = [("A", _P), ("a_rs", _L), ("a_cs", _L), ("sA", _L), ("B", _P), ("b_rs", _L), ("b_cs", _L), ("sB", _L),
+                ("C", _P), ("ldc", _L), ("sC", _L), ("bias", _P), ("sBias", _L), ("M", _L), ("N", _L), ("K", _L),
+                ("batch", _I), ("alpha", _F), ("beta", _F), ("ksplit", _I), ("part", _P)]
+
+
+def sgemm_group(problems):
+    """problems: list of dicts with the keyword names of SgemmProblem (tensors or None for the pointers)."""
+    arr = (SgemmProblem * len(problems))()
+    for i, q in enumerate(problems):
+        for k, _ in SgemmProblem._fields_:
+            v = q.get(k, 0)
+            setattr(arr[i], k, _ptr(v) if (isinstance(v, torch.Tensor) or v is None) else v)
+    rc = lib().tnr_sgemm_group(arr, len(problems), stream())
+    if rc != 0:
+        raise TnrError("tnr_sgemm_group failed (%d): %s" % (rc, lib().tnr_last_error().decode()))
+
 # name -> argument types (return type int unless listed in _RET)
 _SIG = {
     "tnr_version": [],
@@ -63,6 +82,7 @@ _SIG = {
     "tnr_attpool_fwd": [_P, _P, _L, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P],
     "tnr_attpool_bwd": [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _I, _I, _P],
     "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _I, _P, _P],
+    "tnr_sgemm_group": [_c.POINTER(SgemmProblem), _I, _P],
     "tnr_gather_rows": [_P, _L, _P, _L, _I, _I, _P, _L, _L, _P],
     "tnr_segment_sum_rows": [_P, _P, _P, _L, _I, _P, _P],
     "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
