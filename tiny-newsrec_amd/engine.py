@@ -764,11 +764,11 @@ class Engine:
                 Wt = self._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
                 bt = self._view("transform_matrix.0.bias", T_ * D, (T_, D))
                 proj = (self.X, D, 1, self.X.stride(0), Wt, D, 1, D * D, self.Pm, D, self.Pm.stride(0), bt, D, Rt, D, D)
-                if side is main:       # the projection rides in the launch of the news encoder's dense layer (encode(extra=...))
+                if side == main:       # the projection rides in the launch of the news encoder's dense layer (encode(extra=...))
                     extra = [self._sgemm_problem(*proj, batch=T_)]
                 else:
                     self._sgemm(*proj, batch=T_)
-        if T_ == 0 or side is not main:
+        if T_ == 0 or side != main:
             extra = None
         if news_combined is not None:
             self.plan = plan
