@@ -827,6 +827,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256x256_kernel(NTArgs g) {
 // vmcnt(0), i.e. for the next tile's first operand loads); residual / pre-activation operands are read in the same
 // layout, prefetched one block ahead; column sums (bias gradient of the producing Linear) are reduced over the 16 rows
 // of a block by row-wise shuffles and over blocks in registers.
+// Full-line stores.  Lane (m = lane & 15, q = lane >> 4) holds two 16-byte pieces of ONE output row: columns 8 q .. 8 q + 7 and
+// 32 + 8 q .. of the wave's 64.  Stored as they stand, one instruction writes 16 rows x 64 bytes and the next the other halves
+// of the same 128-byte lines: 77-80 cycles per store instruction and CU, against 45-59 when ADJACENT lanes write the two halves of
+// a line in one instruction (tools/scratch/store_path.hip: lane pairs (m, m ^ 1) reach the rate of fully contiguous stores, pairs
+// (m, m ^ 4) or (m, m ^ 8) do not - the coalescer looks at neighbouring lanes; the store path is what the epilogue costs, DESIGN.md
+// section 4 item 15).  So the lanes of rows m and m ^ 1 trade a piece first: afterwards `u` is a piece of the pair's EVEN row and
+// `v` one of its ODD row, at columns 8 q (even lane) or 32 + 8 q (odd lane) - each instruction then writes 8 rows x 128 bytes.
+// One v_cndmask_b32_dpp per register (quad_perm [1, 0, 3, 2] on the first source, lane parity in VCC); the s_nop covers the
+// VALU-write -> DPP-read hazard the compiler does not pad inside an asm statement.
+__device__ __forceinline__ void pp_pair_exchange(const bf16x8& o0, const bf16x8& o1, u32x4& u, u32x4& v) {
+    const u32x4 a = __builtin_bit_cast(u32x4, o0), b = __builtin_bit_cast(u32x4, o1);
+    unsigned u0, u1, u2, u3, v0, v1, v2, v3;
+    // u = even lane ? own first piece : the even partner's second piece
+    asm("s_mov_b64 vcc, %12\n\ts_nop 1\n\t"
+        "v_cndmask_b32_dpp %0, %4, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %5, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %2, %6, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %7, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "s"(0x5555555555555555ull)
+        : "vcc");
+    // v = odd lane ? own second piece : the odd partner's first piece
+    asm("s_mov_b64 vcc, %12\n\ts_nop 1\n\t"
+        "v_cndmask_b32_dpp %0, %4, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %5, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %2, %6, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %7, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "s"(0xAAAAAAAAAAAAAAAAull)
+        : "vcc");
+    u = (u32x4){u0, u1, u2, u3};
+    v = (u32x4){v0, v1, v2, v3};
+}
+
 template <int MI, int CF>
 // The tile is row panel bm, rows rs .. rs + 32 nblk - 1: nblk (MI, or MI - 1 for a short tile) 16-row blocks per wave group.
 __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[MI][4], const f32x2* lut, const float* bias_lds,
@@ -835,13 +869,18 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
     const int m16 = lane & 15, qd = lane >> 4;
     const int n0 = bn * 256 + wn * 64 + qd * 8;                  // this lane's columns: n0 .. n0 + 7 and n0 + 32 .. n0 + 39
     const int row0 = rs + wm * 16 * nblk + m16;
+    const bool odd = (m16 & 1) != 0;
+    const int rowp = row0 - (m16 & 1), n0p = n0 + (odd ? 32 : 0);   // full-line stores: the pair's even row, this lane's column piece
 #if defined(TNR_PROBES) && TNR_PROBES >= 2
     const int n0s = (g.probe & 32) ? wn * 64 + qd * 8 : n0, row0s = (g.probe & 32) ? wm * 16 * MI + m16 : row0;
+    const int n0ps = (g.probe & 32) ? wn * 64 + qd * 8 + (odd ? 32 : 0) : n0p, rowps = (g.probe & 32) ? wm * 16 * MI + m16 - (m16 & 1) : rowp;
     const bool do_store = !(g.probe & 16);
 #else
     const int n0s = n0, row0s = row0;
+    const int n0ps = n0p, rowps = rowp;
     constexpr bool do_store = true;
 #endif
+    (void)n0s; (void)row0s;
     float bb[16];
     if (flags & TNR_EPI_BIAS) {
         const float* bl = bias_lds + wn * 64 + qd * 8;
@@ -891,10 +930,12 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
             bf16x8 o0, o1;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { o0[e] = (bf16)v[e]; o1[e] = (bf16)v[8 + e]; }
-            if (live && do_store) {
-                bf16* p = g.aux + (int64_t)(row0s + i * 16) * g.ldaux + n0s;
-                *(bf16x8*)p = o0;
-                *(bf16x8*)(p + 32) = o1;
+            u32x4 pu, pv;
+            pp_pair_exchange(o0, o1, pu, pv);
+            if (do_store) {
+                bf16* p = g.aux + (int64_t)(rowps + i * 16) * g.ldaux + n0ps;
+                if (rowp + i * 16 < g.M) *(u32x4*)p = pu;
+                if (rowp + i * 16 + 1 < g.M) *(u32x4*)(p + g.ldaux) = pv;
             }
         }
         if (flags & TNR_EPI_GELU) {
@@ -947,10 +988,12 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
             bf16x8 o0, o1;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { o0[e] = (bf16)v[e]; o1[e] = (bf16)v[8 + e]; }
-            if (live && do_store) {
-                bf16* c = (bf16*)g.C + (int64_t)(row0s + i * 16) * g.ldc + n0s;
-                *(bf16x8*)c = o0;
-                *(bf16x8*)(c + 32) = o1;
+            u32x4 pu, pv;
+            pp_pair_exchange(o0, o1, pu, pv);
+            if (do_store) {
+                bf16* c = (bf16*)g.C + (int64_t)(rowps + i * 16) * g.ldc + n0ps;
+                if (rowp + i * 16 < g.M) *(u32x4*)c = pu;
+                if (rowp + i * 16 + 1 < g.M) *(u32x4*)(c + g.ldc) = pv;
             }
             if ((flags & TNR_EPI_COLSUM) && live) {
 #pragma unroll
