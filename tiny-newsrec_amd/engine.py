@@ -978,8 +978,11 @@ class Engine:
             # two gradient buckets per layer, in completion order: the FFN block (names[10:16]) is final after the W1
             # weight gradient, the attention block (names[0:10]) at the end of the layer -- the last all-reduce of a step
             # (attention block of layer lo) is then a third of a layer instead of a whole one
-            rb = self.red.setdefault((l, acc, N, "ffn"), _ReduceBatch(self.dev)) if tr else None
-            rba = self.red.setdefault((l, acc, N, "att"), _ReduceBatch(self.dev)) if tr else None
+            # (without a bucket hook - one GPU - nothing waits for the FFN block's gradients before the end of the layer: one
+            # batched reduction per layer instead of two)
+            one = after_bucket is None
+            rba = self.red.setdefault((l, acc, N, "att+ffn" if one else "att"), _ReduceBatch(self.dev)) if tr else None
+            rb = (rba if one else self.red.setdefault((l, acc, N, "ffn"), _ReduceBatch(self.dev))) if tr else None
             nblk = T.query("tnr_ln_bwd_blocks", M)
             # with dropout behind the two output Linears the LayerNorm backward has two outputs: dx for the residual branch and
             # dx * mask / (1 - p) = the Linear's output gradient (its weight gradient, dgrad and -- through the partials -- bias)
@@ -1002,7 +1005,8 @@ class Engine:
                     self._c("tnr_colsum", self.du, I, T.BF16, M, I, self.cs_tmp[:I], self.cs_part, 0)
                     rb.add(self.cs_tmp, 1, I, I, gr[names[11]], acc, gi)
                 self._wgrad(self.du, a["h1"], gr[names[10]], M, acc)
-                rb.flush()
+                if not one:
+                    rb.flush()
                 if after_bucket:
                     after_bucket(bucket)
                     bucket += 1
