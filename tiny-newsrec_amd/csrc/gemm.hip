@@ -875,7 +875,9 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
     const int n0s = (g.probe & 32) ? wn * 64 + qd * 8 : n0, row0s = (g.probe & 32) ? wm * 16 * MI + m16 : row0;
     const int n0ps = (g.probe & 32) ? wn * 64 + qd * 8 + (odd ? 32 : 0) : n0p, rowps = (g.probe & 32) ? wm * 16 * MI + m16 - (m16 & 1) : rowp;
     const bool do_store = !(g.probe & 16);
+    const bool do_lut = !(g.probe & 2048), do_xload = !(g.probe & 4096);      // 2048: no table lookups ; 4096: no operand loads
 #else
+    constexpr bool do_lut = true, do_xload = true;
     const int n0s = n0, row0s = row0;
     const int n0ps = n0p, rowps = rowp;
     constexpr bool do_store = true;
@@ -905,6 +907,7 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
     const int64_t xld = pre_aux ? g.ldaux : g.ldres;
     bf16x8 x0 = {}, x1 = {};
     auto xload = [&](int i, bf16x8& a, bf16x8& b) {
+        if (!do_xload) return;
         int m = row0 + i * 16;
         m = m < g.M ? m : g.M - 1;
         const bf16* p = xsrc + (int64_t)m * xld + n0;
@@ -940,7 +943,7 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
         }
         if (flags & TNR_EPI_GELU) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = lut_eval<false>(lut, v[e]);
+            for (int e = 0; e < 16; ++e) v[e] = do_lut ? lut_eval<false>(lut, v[e]) : v[e] * 0.5f;
         }
         if (flags & TNR_EPI_TANH) {
 #pragma unroll
@@ -949,8 +952,8 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
         if (flags & TNR_EPI_MULDGELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                v[e] *= lut_eval<true>(lut, (float)y0[e]);
-                v[8 + e] *= lut_eval<true>(lut, (float)y1[e]);
+                v[e] *= do_lut ? lut_eval<true>(lut, (float)y0[e]) : (float)y0[e];
+                v[8 + e] *= do_lut ? lut_eval<true>(lut, (float)y1[e]) : (float)y1[e];
             }
         }
         if (flags & TNR_EPI_DROPOUT) {

@@ -16,6 +16,8 @@ LAUNCHES = [("qkv", 3 * H, H, B_, 4), ("attn_out", H, H, B_ | R_, 4), ("ffn_up_k
             ("ffn_down", H, I, B_ | R_, 4), ("pool_fc1", Q, H, B_ | TH | F32O, 1), ("dgrad_pool", H, Q, R_, 1),
             ("dgrad_w2_gelu'", I, H, MD | CS, 2), ("dgrad_w1", H, I, R_, 2), ("dgrad_o", H, H, 0, 2), ("dgrad_qkv", H, 3 * H, R_, 1)]
 PROBES = [(0, "full")] + ([] if os.environ.get("PRODUCT") else [(8, "no epilogue"), (16, "no stores"), (8 | 128, "no epilogue + 16 stores per wave spread over the K loop")])
+if os.environ.get("SPLIT"):               # what the arithmetic half of the epilogue is made of: table lookups / operand loads off
+    PROBES = [(8, "no epilogue"), (16, "no stores"), (16 | 2048, "no stores, no table"), (16 | 4096, "no stores, no operand loads"), (16 | 2048 | 4096, "neither")]
 if os.environ.get("AB"):                  # AB=pp:1:2 -> interleaved A/B of a library option instead of the probes (PRODUCT=1)
     key, va, vb = os.environ["AB"].split(":")
     PROBES = [(int(va), "%s=%s" % (key, va)), (int(vb), "%s=%s" % (key, vb))]
