@@ -45,6 +45,7 @@ struct TnrGemmOpts {
     int tnpp;        // weight gradient: 1 = ping-pong main loop, 0 = plain two-buffer loop
     int mix;         // ping-pong NT kernel: 1 = row panels of two heights so that the tiles fill whole rounds, 0 = one height
     int probe;       // timing probes of the ping-pong kernel (only in -DTNR_PROBES builds, tools/probe_build.sh)
+    int cus;         // 0 = plan and size the persistent GEMM grids for the device's CUs ; n = for n of them (two kernels side by side)
 };
 TnrGemmOpts* tnr_gemm_opts();
 

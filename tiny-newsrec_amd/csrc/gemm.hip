@@ -1735,6 +1735,7 @@ extern "C" int64_t TNR_NAME(tnr_gemm_colsum_rows)(int64_t M) { return ((M + 255)
 // through tnr_gemm_set_option -- the library never reads the environment).  tnr_gemm_nt_route() exposes the decision
 // so that the parity tests can pin every route.
 static int device_cus() {
+    if (tnr_gemm_opts()->cus > 0) return tnr_gemm_opts()->cus;
     static int cus[64] = {0};
     int devid = 0;
     if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return 256;
