@@ -22,6 +22,7 @@ M_BENCH = 52800                           # 32 impressions x 55 titles x 30 toke
 H, I, QPAD = 768, 3072, 256
 TD = {"bf16": torch.bfloat16, "fp16": torch.float16}
 EPS = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}      # one rounding of the 16-bit output
+PIN_ROUTES = [True]                                # False while a test sizes the grids for another CU count than the device's
 
 B_, G_, TH, R_, MD, F32O, AUX, CS = (T.EPI_BIAS, T.EPI_GELU, T.EPI_TANH, T.EPI_RES, T.EPI_MULDGELU, T.EPI_OUTF32, T.EPI_AUXOUT,
                                      T.EPI_COLSUM)
@@ -73,7 +74,7 @@ def test_gemm_nt_main_loop_bit_exact_at_bench_shape(dtype, name, N, K, flags):
     a, b = torch.from_numpy(A).to(DEV), torch.from_numpy(Bm).to(DEV)
     c = torch.full((M + 64, N), 7.0, device=DEV, dtype=torch.float32)
     route = T.query("tnr_gemm_nt_route" + _sfx(dtype), M, N, K, F32O)
-    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+    if PIN_ROUTES[0] and torch.cuda.get_device_properties(0).multi_processor_count == 256:
         assert route == _expected_route(M, N, F32O), (name, route)
     T.call("tnr_gemm_nt" + _sfx(dtype), a.to(TD[dtype]), K, b.to(TD[dtype]), K, c, N, M, N, K, None, None, 0, None, 0, F32O)
     full = a @ b.T                                    # fp32 GPU product: exact for these integers (|sum| < 2^24)
@@ -99,7 +100,7 @@ def test_gemm_nt_epilogues_at_bench_shape(dtype, name, N, K, flags):
     aux_in = aux.clone() if flags & MD else None
     c = torch.zeros((M, N), device=DEV, dtype=torch.float32 if flags & F32O else td)
     cs = torch.zeros((T.query("tnr_gemm_colsum_rows" + _sfx(dtype), M), N), device=DEV) if flags & CS else None
-    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+    if PIN_ROUTES[0] and torch.cuda.get_device_properties(0).multi_processor_count == 256:
         assert T.query("tnr_gemm_nt_route" + _sfx(dtype), M, N, K, flags) == _expected_route(M, N, flags), name
     T.call("tnr_gemm_nt_ex" + _sfx(dtype), a, K, b, K, c, N, M, N, K, bias, res, N if res is not None else 0, aux,
            N if aux is not None else 0, flags, cs)
@@ -141,6 +142,25 @@ def test_gemm_nt_plain_loop_variant_bit_exact():
         test_gemm_nt_epilogues_at_bench_shape("bf16", *NT_LAUNCHES[2])
     finally:
         L.tnr_gemm_set_option(b"pp", 1)
+
+
+@pytest.mark.parametrize("cus", [128, 100, 8])
+def test_gemm_grids_sized_for_fewer_cus_bit_exact(cus):
+    """tnr_gemm_set_option "cus": the persistent kernels' grids and the NT panel plan sized for n CUs instead of the device's
+    (two GEMMs side by side on disjoint shares) - other panel heights, more tiles / units per
+    workgroup, the same results on the step's launches."""
+    L = T.lib()
+    try:
+        assert L.tnr_gemm_set_option(b"cus", cus) == 0
+        PIN_ROUTES[0] = False
+        for name, N, K, flags in NT_LAUNCHES if cus == 128 else NT_LAUNCHES[1:3]:
+            test_gemm_nt_main_loop_bit_exact_at_bench_shape("fp16", name, N, K, flags)
+            test_gemm_nt_epilogues_at_bench_shape("fp16", name, N, K, flags)
+        for name, N, K in WGRAD_LAUNCHES if cus == 128 else WGRAD_LAUNCHES[:1]:
+            test_gemm_tn_wgrad_bit_exact_at_bench_shape("fp16", name, N, K)
+    finally:
+        L.tnr_gemm_set_option(b"cus", 0)
+        PIN_ROUTES[0] = True
 
 
 def test_gemm_nt_routes_cover_every_tile_variant():
