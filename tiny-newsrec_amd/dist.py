@@ -117,7 +117,10 @@ def broadcast_flat(tensors, src=0, force=False):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])     # this rank's GPU, not a guess from the rank number
+        else:
+            dist.barrier()
 
 
 def all_reduce_max(x):
