@@ -110,8 +110,10 @@ int64_t tnr_gemm_colsum_rows(int64_t M);
 /* Debug / test hooks.  tnr_gemm_nt_route: which kernel tnr_gemm_nt(_ex) launches for a shape on the current
  * device (the decision depends on (M, N, K, flags) and the CU count only) -- the parity tests assert it so that
  * every tile variant is pinned at the shapes the training step issues.  tnr_gemm_set_option: process-wide A/B
- * switches for tools/ ("ver", "gm", "fine_pct", "allow_fine", "bm", "nt", "pp", "tnpp", "mix"); the library never reads the
- * environment and the defaults are the shipped configuration. */
+ * switches for tools/ ("ver", "gm", "fine_pct", "allow_fine", "bm", "nt", "pp", "tnpp", "mix"; "cus" = n: plan and size the
+ * persistent GEMM grids for n compute units instead of the device's, 0 = the device's - same results, pinned by
+ * test_gemm_grids_sized_for_fewer_cus_bit_exact); the library never reads the environment and the defaults are the shipped
+ * configuration. */
 #define TNR_ROUTE_128x128 128    /* 128x128 tile, 4 waves, 2 workgroups per CU */
 #define TNR_ROUTE_256x128 2128   /* 256x128 tile (N % 256 != 0) */
 #define TNR_ROUTE_256x256 256    /* 256x256 tile, 8 waves */
