@@ -327,6 +327,42 @@ def test_news_vectors_do_not_depend_on_the_batch_they_are_in(dtype):
     assert torch.equal(got[:110], ref[perm])
 
 
+@pytest.mark.parametrize("B,tol", [(64, 5e-6), (96, 5e-4)])
+def test_big_batch_equals_its_pieces(B, tol):
+    """Batches beyond the B = 32 of demo.sh (288 GB of HBM hold B = 512 and more: token-row byte offsets past 2^31).  Scores of
+    one big batch == the scores of its B = 32 pieces bit for bit (rows are independent, whatever tiles they land in); its
+    gradient == the mean of theirs: the fp16 loss scale doubles with every doubling of the batch, so a power-of-two batch runs
+    its backward on the very 16-bit values the pieces saw (differences = fp32 summation order), any other on values within
+    one scale step of them."""
+    import hashinit
+    import synth
+    from schema import FULL, state_shapes
+    cfg = E.EngineConfig(n_layers=4, trainable_layers=(2, 3), num_teachers=4)
+    sd = hashinit.init_state_dict(1234, state_shapes(FULL, 4, cfg.D, 4))
+    n_news = 4000
+    comb = torch.from_numpy(synth.news_table(1234, n_news, cfg.L)).to(DEV)
+    tables = torch.from_numpy(synth.teacher_tables(1234, 4, n_news, cfg.D)).to(DEV)
+    hidx, mask, cidx, label = [torch.from_numpy(x).to(DEV) for x in synth.impressions(1235, B, n_news, cfg.U, cfg.C)]
+    small = E.Engine(cfg, DEV, max_batch=32, dtype="fp16")
+    small.load_state_dict(sd)
+    scores, g = [], torch.zeros_like(small.flat_g)
+    for i in range(B // 32):
+        s = slice(32 * i, 32 * i + 32)
+        _, sc = small.forward_indexed(comb, hidx[s], mask[s], cidx[s], label[s], tables)
+        scores.append(sc.clone())
+        small.backward()
+        g += small.flat_g
+    g /= B // 32
+    del small
+    big = E.Engine(cfg, DEV, max_batch=B, dtype="fp16")
+    big.load_state_dict(sd)
+    _, sc = big.forward_indexed(comb, hidx, mask, cidx, label, tables)
+    big.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(sc, torch.cat(scores))
+    assert float((big.flat_g - g).norm() / g.norm()) < tol
+
+
 @pytest.mark.parametrize("shape", [dict(B=3, U=13, C=3, L=17, D=64, Q=40, T=2, nl=2, tr=(1,), ulm=True),
                                    dict(B=1, U=5, C=2, L=32, D=128, Q=200, T=1, nl=1, tr=(0,), ulm=False),
                                    dict(B=5, U=50, C=5, L=9, D=256, Q=72, T=3, nl=2, tr=(0, 1), ulm=False),

@@ -419,6 +419,16 @@ class Engine:
         N = B * (cfg.U + cfg.C)
         Mp = _rup(N * L, 128)
         self.B_alloc, self.N_alloc, self.Mp = B, N, Mp
+        if self.f16:
+            # the losses are batch means, so activation gradients shrink as 1 / B: the scale grows with the batch in powers of two
+            # beyond the B = 32 it was set for (B = 512 at the fixed scale: parameter gradients 1.8e-3 off the mean of their
+            # B = 32 pieces; 1e-6 with it - a power-of-two batch then sees the very 16-bit values its pieces saw;
+            # tools/scratch/big_batch.py, test_big_batch_equals_its_pieces).  B <= 32: unchanged.
+            k = 0
+            while (32 << k) < B and k < 5:
+                k += 1
+            self.gscale = LOSS_SCALE * (1 << k)
+            self.ginv = 1.0 / self.gscale
         z = lambda *s, dt=bf: torch.zeros(s, device=dev, dtype=dt)
         f = lambda *s: torch.zeros(s, device=dev, dtype=torch.float32)
         Lr = _rup(L, 32)
