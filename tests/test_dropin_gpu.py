@@ -85,6 +85,7 @@ def test_bench_dp_path_under_torchrun_single_rank():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
+    assert d["larger_batch"]["batch_per_gpu"] == 128 and d["larger_batch"]["value"] > 0      # the informational 4 x batch leg
 
 
 def test_construction_time_init_and_pretrained_import(tmp_path):

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 key=$1; shift
 for v in "$@"; do
   out=gpurun_out/trace_${key}_$v; rm -rf $out; mkdir -p $out
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --dedup off --no-other-dtype --no-kernel-timing --gemm-opt $key=$v > $out/log.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --dedup off --no-other-dtype --no-larger-batch --no-kernel-timing --gemm-opt $key=$v > $out/log.txt 2>&1
   f=$(find $out -name "*kernel_stats.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, re
