@@ -338,3 +338,20 @@ def test_gemm_beside_held_cus_is_bit_identical():
         torch.cuda.synchronize()
         dws.append(dw)
     assert torch.equal(dws[0], dws[1])
+
+
+def test_queue_table_refuses_the_129th_stream_and_resets():
+    """include/tnr_hip.h (tnr_gemm_queue_reset): the persistent GEMM keeps nine counters per (device, stream) in a 128-slot table;
+    it never drains or switches a device - the 129th distinct stream is REFUSED (TNR_EUNSUPPORTED, message names the way out),
+    bound streams keep working launch after launch, a reset leaves a stream usable, and option "pp" = 0 serves the refused one.
+    Own process: the table stays full."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "workers", "queue_table.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] == 128 and d["refused_at"] == 128, d
+    assert "(-2)" in d["msg"] and "pp" in d["msg"], d["msg"]
+    assert d["again"] and d["rc_reset"] == 0 and d["after_reset"], d
+    assert d["rc_unbound"] == -2 and d["plain_on_refused"], d

@@ -1829,7 +1829,8 @@ static unsigned* pp_queue_of(hipStream_t st, bool reset = false) {
     const bool fresh = !set;
     if (!set) {
         if (nslot == PP_QUEUE_SETS) {
-            tnr_set_error("tnr_gemm_nt: more than %d (device, stream) pairs have launched the persistent GEMM in this process", PP_QUEUE_SETS);
+            tnr_set_error("tnr_gemm_nt: more than %d (device, stream) pairs have launched the persistent GEMM in this process "
+                          "(reuse streams, or tnr_gemm_set_option(\"pp\", 0) for the kernel without a tile queue)", PP_QUEUE_SETS);
             return nullptr;
         }
         slots[nslot] = Slot{dev, st};
