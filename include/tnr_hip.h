@@ -146,6 +146,21 @@ int tnr_gemm_tn_wgrad_ex(const void* dY, int64_t lddy, const void* X, int64_t ld
                          int64_t M, int64_t N, int64_t K, float* ws, int splits, int accumulate, float out_scale,
                          void* stream);
 int64_t tnr_gemm_tn_ws_elems(int64_t N, int64_t K, int splits);
+/* Up to four weight gradients - the Linears of one encoder layer that share a backward step (modeling.py:287, 305-306 and the
+ * q / k / v + output Linears of :205-231) - in ONE persistent launch + one slab-sum launch: the (split, tile) units of all of
+ * them are pulled from one queue, each computed exactly as in its own tnr_gemm_tn_wgrad_ex call (same unit partition, same slab
+ * order: bit-identical results).  Every problem has its own `ws`.  Problems off the 256 x 256 route (N or K not a multiple of
+ * 256) make the call fall back to one launch per problem. */
+typedef struct {
+    const void* dY; int64_t lddy;
+    const void* X; int64_t ldx;
+    float* dW; int64_t lddw;
+    int64_t M, N, K;
+    float* ws;               /* splits * N * K fp32, this problem's own */
+    int splits, accumulate;
+    float out_scale;
+} tnr_wgrad_problem_t;
+int tnr_gemm_tn_wgrad_group(const tnr_wgrad_problem_t* problems, int n, void* stream);
 
 /* LayerNorm over the last dim (H % 256 == 0), eps inside the sqrt (torch.nn.LayerNorm).
  * fwd: y = LN(x) ; stats (M,2) fp32 = (mean, rstd) kept for backward. */
@@ -398,6 +413,7 @@ int tnr_gemm_tn_wgrad_ex_f16(const void* dY, int64_t lddy, const void* X, int64_
                          int64_t M, int64_t N, int64_t K, float* ws, int splits, int accumulate, float out_scale,
                          void* stream);
 int64_t tnr_gemm_tn_ws_elems_f16(int64_t N, int64_t K, int splits);
+int tnr_gemm_tn_wgrad_group_f16(const tnr_wgrad_problem_t* problems, int n, void* stream);
 int tnr_ln_fwd_f16(const void* x, const float* gamma, const float* beta, float eps, void* y, float* stats,
                int64_t M, int H, void* stream);
 int tnr_ln_bwd_f16(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,

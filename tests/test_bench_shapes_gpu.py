@@ -355,3 +355,54 @@ def test_queue_table_refuses_the_129th_stream_and_resets():
     assert "(-2)" in d["msg"] and "pp" in d["msg"], d["msg"]
     assert d["again"] and d["rc_reset"] == 0 and d["after_reset"], d
     assert d["rc_unbound"] == -2 and d["plain_on_refused"], d
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_wgrad_group_equals_separate_launches_bit_for_bit(dtype):
+    """tnr_gemm_tn_wgrad_group: the four weight gradients of an encoder layer at the step's own size in ONE persistent launch
+    (units of all four pulled from one queue) + one slab-sum launch == four tnr_gemm_tn_wgrad_ex calls, bit for bit (random
+    operands; accumulate and out_scale mixed), and a group with a shape off the 256 x 256 route falls back to the same."""
+    import engine as E
+    M, td, sfx = M_BENCH, TD[dtype], _sfx(dtype)
+    Mp = (M + 127) // 128 * 128
+    g = torch.Generator(device=DEV).manual_seed(7)
+    shapes = [(3 * H, H), (H, H), (I, H), (H, I)]
+    probs, want = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy = torch.zeros((Mp, N), device=DEV, dtype=td)
+        x = torch.zeros((Mp, K), device=DEV, dtype=td)
+        dy[:M] = (torch.randn((M, N), device=DEV, generator=g) * 0.1).to(td)
+        x[:M] = torch.randn((M, K), device=DEV, generator=g).to(td)
+        splits, elems = E.Engine._wgrad_splits(N, K)
+        acc, scale = i & 1, (1.0, 1.0 / 1024, 0.5, 1.0)[i]
+        base = torch.randn((N, K), device=DEV, generator=g)
+        ref = base.clone()
+        ws = torch.zeros(elems, device=DEV)
+        T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy, N, x, K, ref, K, M, N, K, ws, splits, acc, scale)
+        want.append(ref)
+        probs.append(dict(dY=dy, lddy=N, X=x, ldx=K, dW=base.clone(), lddw=K, M=M, N=N, K=K, ws=torch.zeros(elems, device=DEV),
+                          splits=splits, accumulate=acc, out_scale=scale))
+    T.wgrad_group(probs, f16=dtype == "fp16")
+    torch.cuda.synchronize()
+    for q, ref, (N, K) in zip(probs, want, shapes):
+        assert torch.equal(q["dW"], ref), (N, K)
+    # two of them a second time (a group of two, as under a gradient-bucket hook), and a group that cannot take the persistent route
+    two = [dict(q, dW=torch.zeros_like(q["dW"]), accumulate=0) for q in probs[2:]]
+    T.wgrad_group(two, f16=dtype == "fp16")
+    N2, K2 = 384, 256
+    dy2 = torch.zeros((Mp, N2), device=DEV, dtype=td)
+    dy2[:M] = (torch.randn((M, N2), device=DEV, generator=g) * 0.1).to(td)
+    sp2, el2 = E.Engine._wgrad_splits(N2, K2)
+    odd = dict(dY=dy2, lddy=N2, X=probs[0]["X"], ldx=H, dW=torch.zeros((N2, K2), device=DEV), lddw=K2, M=M, N=N2, K=K2,
+               ws=torch.zeros(el2, device=DEV), splits=sp2, accumulate=0, out_scale=1.0)
+    ref2 = torch.zeros((N2, K2), device=DEV)
+    T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy2, N2, probs[0]["X"], H, ref2, K2, M, N2, K2, torch.zeros(el2, device=DEV), sp2, 0, 1.0)
+    T.wgrad_group([odd, dict(probs[1], dW=torch.zeros_like(probs[1]["dW"]), accumulate=0)], f16=dtype == "fp16")
+    torch.cuda.synchronize()
+    assert torch.equal(odd["dW"], ref2)
+    for q, (N, K) in zip(two, shapes[2:]):
+        sp, el = E.Engine._wgrad_splits(N, K)
+        ref = torch.zeros((N, K), device=DEV)
+        T.call("tnr_gemm_tn_wgrad_ex" + sfx, q["dY"], N, q["X"], K, ref, K, M, N, K, torch.zeros(el, device=DEV), sp, 0, q["out_scale"])
+        torch.cuda.synchronize()
+        assert torch.equal(q["dW"], ref), (N, K)

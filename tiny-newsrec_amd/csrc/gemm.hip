@@ -295,6 +295,44 @@ struct TNArgs {
     unsigned* queue;           // ping-pong kernel: the stream's tile-queue counters (8 per-XCD-label unit counters + a done counter)
 };
 
+// Up to four weight gradients in ONE persistent launch (tnr_gemm_tn_wgrad_group): the (split, tile) units of the problems are
+// numbered one after the other (ubase[i] = first unit of problem i; entries from n on hold the total) and pulled from the same
+// queue.  Each unit is computed exactly as in the problem's own launch.
+constexpr int TN_MAXP = 4;
+struct TNGroup {
+    TNArgs p[TN_MAXP];
+    int ubase[TN_MAXP + 1];
+    int xb[9];                 // unit range of XCD label x: [xb[x], xb[x + 1]) - equal shares of the WORK (units differ in length between problems)
+    unsigned* queue;
+};
+// the eight ranges: one problem -> equal unit counts (the old rule); several -> cut where the cumulated m steps (+ a fixed cost per
+// unit for its prologue and slab store) reach x / 8 of the total
+static void tn_group_ranges(TNGroup& g, int n) {
+    const int total = g.ubase[TN_MAXP];
+    if (n == 1) {
+        const int q8 = total >> 3, r8 = total & 7;
+        for (int x = 0; x <= 8; ++x) g.xb[x] = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
+        return;
+    }
+    int64_t w[TN_MAXP], cum[TN_MAXP + 1];
+    cum[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        w[i] = g.p[i].tiles_per_split + 8;
+        cum[i + 1] = cum[i] + w[i] * (g.ubase[i + 1] - g.ubase[i]);
+    }
+    g.xb[0] = 0;
+    g.xb[8] = total;
+    for (int x = 1; x < 8; ++x) {
+        const int64_t t = cum[n] * x / 8;
+        int i = 0;
+        while (i + 1 < n && cum[i + 1] <= t) ++i;
+        int u = g.ubase[i] + (int)((t - cum[i] + w[i] / 2) / w[i]);
+        if (u < g.xb[x - 1]) u = g.xb[x - 1];
+        if (u > total) u = total;
+        g.xb[x] = u;
+    }
+}
+
 __device__ __forceinline__ int tn_swz(int row) { return (((row & 3) | (((row >> 3) & 1) << 2)) << 1); }
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs g) {
@@ -1487,13 +1525,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
 // dY0(t+2), X0(t+2), X1(t+2) and waits vmcnt(6) (everything of step t+1 has landed).  Both operands stream from HBM here, so
 // the order is chosen for latency budget (8 intervals for three of the four sub-tiles, 6 for dY1): with the NT kernel's old
 // order (X1 two intervals before its wait) this kernel was 3-5 % slower.
-__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w >> 2, wk = w & 3;          // wave tile: 128 n x 64 k
-    const int nbk = g.K >> 8;
-    const int ntile = (g.N >> 8) * nbk;
     // Persistent: the work units (split z, output tile) -- one fp32 slab tile each, unit id = z * ntile + tile -- are PULLED from the
     // stream's queue counters exactly as the NT kernel pulls its tiles: the workgroups of an XCD label take consecutive units of
     // that label's contiguous run (units of one split read the same rows of dY / X: they share them through the XCD's L2), and a
@@ -1502,20 +1538,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
     // engine cuts the M range finer (Engine._wgrad_splits) so that a late workgroup costs a fraction of a unit, not a round.
     // The partition into units is fixed by (N, K, splits, M) alone and the slabs are summed in a fixed order: who computes a unit
     // never changes a bit of the result.
-    const int nunit = ntile * g.splits;
+    unsigned* const queue = grp.queue;
     const int xcd = blockIdx.x & 7;
-    const int q8 = nunit >> 3, r8 = nunit & 7;
-    const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
+    int c0 = grp.xb[0], c1 = grp.xb[1];
+#pragma unroll
+    for (int x = 1; x < 8; ++x)
+        if (xcd == x) { c0 = grp.xb[x]; c1 = grp.xb[x + 1]; }
     int* const qlds = (int*)(smem + RING3);
     unsigned q0;
-    pp_q_fetch(q0, g.queue + xcd * PP_Q_STRIDE, w == 0);
+    pp_q_fetch(q0, queue + xcd * PP_Q_STRIDE, w == 0);
     auto leave = [&]() {                                 // last workgroup out zeroes the counters for the next launch
         if (tid == 0) {
-            const unsigned d = __hip_atomic_fetch_add(g.queue + 8 * PP_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned d = __hip_atomic_fetch_add(queue + 8 * PP_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (d == gridDim.x - 1)
                 for (int i = 0; i < 9; ++i)
-                    __hip_atomic_store(g.queue + i * PP_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(queue + i * PP_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
@@ -1534,14 +1571,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
     int unit = qlds[0];
     if (unit >= c1) { leave(); return; }                 // whole workgroup, before any other barrier
   while (true) {
-    const int z = unit / ntile, tile = unit - z * ntile;
+    // the problem this unit belongs to (wave-uniform: scalar selects, the descriptor stays in SGPRs)
+    const int su = __builtin_amdgcn_readfirstlane(unit);
+    TNArgs g = grp.p[0];
+    int lu = su;
+    if (su >= grp.ubase[1]) { g = grp.p[1]; lu = su - grp.ubase[1]; }
+    if (su >= grp.ubase[2]) { g = grp.p[2]; lu = su - grp.ubase[2]; }
+    if (su >= grp.ubase[3]) { g = grp.p[3]; lu = su - grp.ubase[3]; }
+    const int nbk = g.K >> 8;
+    const int ntile = (g.N >> 8) * nbk;
+    const int z = lu / ntile, tile = lu - z * ntile;
     const int bn = tile / nbk, bk = tile - bn * nbk;
     const int mt0 = z * g.tiles_per_split;
     int mt1 = mt0 + g.tiles_per_split;
     if (mt1 > g.Mt) mt1 = g.Mt;
     const int nk = mt1 - mt0;
     unsigned qn;                                         // lane 0 of wave 0: the next unit, in flight during this one (oldest operation)
-    pp_q_fetch(qn, g.queue + xcd * PP_Q_STRIDE, w == 0);
+    pp_q_fetch(qn, queue + xcd * PP_Q_STRIDE, w == 0);
 
     // staging: every wave issues pieces 2w, 2w+1 (4 rows x 256 B each) of every sub-tile
     const bf16* srcY[2][2];
@@ -1704,6 +1750,32 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNArgs g) {
 
 __global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t NK, int K, float* out,
                                    int64_t ldo, int accumulate, float out_scale) {
+    int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= NK) return;
+    f32x4 s = *(const f32x4*)(ws + i4);
+    for (int z = 1; z < splits; ++z) s += *(const f32x4*)(ws + (int64_t)z * NK + i4);
+    int64_t n = i4 / K, k = i4 - n * K;
+    float* o = out + n * ldo + k;
+    s *= out_scale;
+    if (accumulate) s += *(const f32x4*)o;
+    *(f32x4*)o = s;
+}
+
+// the slab sums of up to four problems in one launch (blockIdx.y = problem): each element exactly as slab_reduce_kernel does it
+struct SlabGroup {
+    const float* ws[TN_MAXP]; float* out[TN_MAXP]; int64_t NK[TN_MAXP], ldo[TN_MAXP];
+    int splits[TN_MAXP], K[TN_MAXP], accumulate[TN_MAXP]; float out_scale[TN_MAXP];
+};
+__global__ void slab_reduce_group_kernel(SlabGroup g) {
+    const int pi = blockIdx.y;
+    const float* ws = g.ws[0]; float* out = g.out[0]; int64_t NK = g.NK[0], ldo = g.ldo[0];
+    int splits = g.splits[0], K = g.K[0], accumulate = g.accumulate[0]; float out_scale = g.out_scale[0];
+#pragma unroll
+    for (int k = 1; k < TN_MAXP; ++k)
+        if (pi == k) {
+            ws = g.ws[k]; out = g.out[k]; NK = g.NK[k]; ldo = g.ldo[k];
+            splits = g.splits[k]; K = g.K[k]; accumulate = g.accumulate[k]; out_scale = g.out_scale[k];
+        }
     int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= NK) return;
     f32x4 s = *(const f32x4*)(ws + i4);
@@ -1997,10 +2069,14 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
         dim3 grid((unsigned)((N / 256) * (K / 256) * splits));
         if (tnr_gemm_opts()->tnpp) {
             // persistent: at most one workgroup per CU (and at least one per XCD label) pulls the (split, tile) units
-            if (!(g.queue = pp_queue_of((hipStream_t)stream))) return TNR_EUNSUPPORTED;
+            TNGroup grp{};
+            grp.p[0] = g;
+            for (int i = 1; i <= TN_MAXP; ++i) grp.ubase[i] = (int)grid.x;
+            tn_group_ranges(grp, 1);
+            if (!(grp.queue = pp_queue_of((hipStream_t)stream))) return TNR_EUNSUPPORTED;
             const int n_cu = device_cus();
             dim3 pgrid((unsigned)std::min<int64_t>((int64_t)grid.x, std::max(n_cu, 8)));
-            hipLaunchKernelGGL(gemm_tn_pp_kernel, pgrid, dim3(512), RING3 + 64, (hipStream_t)stream, g);
+            hipLaunchKernelGGL(gemm_tn_pp_kernel, pgrid, dim3(512), RING3 + 64, (hipStream_t)stream, grp);
         }
         else hipLaunchKernelGGL(gemm_tn256x256_kernel, grid, dim3(512), RING3, (hipStream_t)stream, g);
     }
@@ -2009,6 +2085,55 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((NK / 4 + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)ws, splits, NK, (int)K, dW, lddw, accumulate, out_scale);
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad/reduce");
+    return TNR_OK;
+}
+
+extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_group)(const tnr_wgrad_problem_t* p, int n, void* stream) {
+    TNR_CHECK_ARG(p && n >= 1 && n <= TN_MAXP, "tnr_gemm_tn_wgrad_group: 1 .. %d problems", TN_MAXP);
+    bool pp = tnr_gemm_opts()->tnpp && tnr_gemm_opts()->ver == 3 && n > 1;
+    for (int i = 0; i < n; ++i) pp = pp && p[i].N >= 256 && p[i].K >= 256 && (p[i].N % 256) == 0 && (p[i].K % 256) == 0;
+    if (!pp) {                                 // a shape off the persistent kernel's route (or one problem): one launch each, the same results
+        for (int i = 0; i < n; ++i) {
+            int rc = TNR_NAME(tnr_gemm_tn_wgrad_ex)(p[i].dY, p[i].lddy, p[i].X, p[i].ldx, p[i].dW, p[i].lddw, p[i].M, p[i].N, p[i].K, p[i].ws,
+                                                     p[i].splits, p[i].accumulate, p[i].out_scale, stream);
+            if (rc != TNR_OK) return rc;
+        }
+        return TNR_OK;
+    }
+    TNGroup grp{};
+    SlabGroup sg{};
+    int64_t units = 0, maxblk = 0;
+    for (int i = 0; i < n; ++i) {
+        const tnr_wgrad_problem_t& q = p[i];
+        TNR_CHECK_ARG(q.dY && q.X && q.dW && q.ws, "tnr_gemm_tn_wgrad_group: null operand");
+        TNR_CHECK_ARG(q.M >= 1 && (q.lddy % 8) == 0 && (q.ldx % 8) == 0 && (q.lddw % 4) == 0 && q.lddy >= q.N && q.ldx >= q.K && q.lddw >= q.K,
+                      "tnr_gemm_tn_wgrad_group: bad shape / leading dimension (problem %d)", i);
+        TNR_CHECK_ARG(((uintptr_t)q.dY % 16) == 0 && ((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dW % 16) == 0 && ((uintptr_t)q.ws % 16) == 0,
+                      "tnr_gemm_tn_wgrad_group: operands must be 16-byte aligned");
+        TNR_CHECK_ARG(q.splits >= 1 && q.splits <= 64, "tnr_gemm_tn_wgrad_group: splits out of range");
+        int Mt = (int)((q.M + 63) / 64), splits = q.splits;                       // the split arithmetic of tnr_gemm_tn_wgrad_ex
+        if (splits > Mt) splits = Mt;
+        const int tps = (Mt + splits - 1) / splits;
+        splits = (Mt + tps - 1) / tps;
+        grp.p[i] = TNArgs{(const bf16*)q.dY, q.lddy, (const bf16*)q.X, q.ldx, q.ws, Mt, (int)q.N, (int)q.K, tps, splits, nullptr};
+        grp.ubase[i] = (int)units;
+        units += (q.N / 256) * (q.K / 256) * splits;
+        sg.ws[i] = q.ws; sg.out[i] = q.dW; sg.NK[i] = q.N * q.K; sg.ldo[i] = q.lddw;
+        sg.splits[i] = splits; sg.K[i] = (int)q.K; sg.accumulate[i] = q.accumulate; sg.out_scale[i] = q.out_scale;
+        maxblk = std::max<int64_t>(maxblk, (q.N * q.K / 4 + 255) / 256);
+    }
+    for (int i = n; i <= TN_MAXP; ++i) grp.ubase[i] = (int)units;
+    tn_group_ranges(grp, n);
+    TNR_ONCE_PER_DEVICE({
+        (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3 + 64);
+    });
+    if (!(grp.queue = pp_queue_of((hipStream_t)stream))) return TNR_EUNSUPPORTED;
+    const int n_cu = device_cus();
+    hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((unsigned)std::min<int64_t>(units, std::max(n_cu, 8))), dim3(512), RING3 + 64,
+                       (hipStream_t)stream, grp);
+    TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad_group");
+    hipLaunchKernelGGL(slab_reduce_group_kernel, dim3((unsigned)maxblk, (unsigned)n), dim3(256), 0, (hipStream_t)stream, sg);
+    TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad_group/reduce");
     return TNR_OK;
 }
 

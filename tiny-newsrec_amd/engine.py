@@ -505,13 +505,21 @@ class Engine:
         self.KS = 8                                                        # split-K of the long-K small GEMMs
         self.sg_part = f(self.KS * max(T_ * D * D, D * H, 3 * D * D, T_ * Rt * D, N * max(H, D), T_ * B * cfg.U * max(cfg.Qu, 3 * D)))
         self.sg_part2 = f(self.KS * max(cfg.Qu * D, 3 * D * D if cfg.nrms_heads else 1))       # second split problem of a grouped launch
-        self.ws = f(max(self._wgrad_splits(n_, k_)[1] for n_, k_ in ((3 * H, H), (H, H), (I, H), (H, I), (QPAD, H))))
+        # weight-gradient slabs: the four gradients of a layer are in flight together (_wgrad_flush), each with slabs of its own
+        self.ws = f(max(sum(_rup(self._wgrad_splits(n_, k_)[1], 64) for n_, k_ in ((3 * H, H), (H, H), (I, H), (H, I))),
+                        self._wgrad_splits(QPAD, H)[1]))
         self._rel_stale = True       # filled by the first encode() (no kernel launch at construction time)
 
     WGRAD_UNITS = 1     # work units (split, tile) per workgroup of the queue-fed weight-gradient kernel.  1 = one full round
                         # (fastest alone).  Beside CUs held by an overlapped all-reduce a late workgroup costs a whole unit:
                         # x1.65 at 1, x1.25 at 2, x1.1-1.15 at 4 -- but every doubling adds a round of fp32 slab traffic
                         # (alone: +10 % at 2, +24 % at 4 for the 3072 x 768 gradient; tools/cu_contention.py)
+
+    group_wgrad = False  # True: a layer's weight gradients in one persistent launch (tnr_gemm_tn_wgrad_group; the same bits).  Measured
+                         # on one GPU: step +6.4 %, the four gradients 848 -> 1 088 us - one launch each,
+                         # one unit per workgroup, all units equal and in lockstep, is the better schedule; kept as a switch for the
+                         # data-parallel case, where a workgroup held off its CU by a collective costs a quarter of what it costs now
+    _wg = None           # the collected weight gradients while a layer's backward runs
 
     @staticmethod
     def _wgrad_splits(N, K, units=None):
@@ -533,8 +541,29 @@ class Engine:
 
     def _wgrad(self, dy, x, dw, M, acc=0):
         N, K = dw.shape
+        if self._wg is not None:           # inside a layer's backward: collected, launched together by _wgrad_flush
+            self._wg.append((dy, x, dw, M, N, K, acc))
+            return
         self._c("tnr_gemm_tn_wgrad_ex", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws,
                self._wgrad_splits(N, K)[0], acc, self.ginv)
+
+    def _wgrad_flush(self):
+        """The weight gradients collected since the last flush in ONE persistent launch (+ one slab-sum launch): their (split, tile)
+        units share a queue, so the workgroups that finish one gradient's units go on with the next one's instead of idling to the
+        launch boundary, and a workgroup kept off its CU by another stream's kernel costs a unit of up to four rounds' worth
+        instead of a whole round.  Each gradient is computed exactly as by its own launch (slabs of its own in self.ws)."""
+        pend, self._wg = self._wg, []
+        if not pend:
+            return
+        probs, off = [], 0
+        for dy, x, dw, M, N, K, acc in pend:
+            splits, elems = self._wgrad_splits(N, K)
+            probs.append(dict(dY=dy, lddy=dy.stride(0), X=x, ldx=x.stride(0), dW=dw, lddw=dw.stride(0), M=M, N=N, K=K,
+                              ws=self.ws[off:off + elems], splits=splits, accumulate=acc, out_scale=self.ginv))
+            off += _rup(elems, 64)
+        assert off <= self.ws.numel()
+        for i in range(0, len(probs), 4):
+            T.wgrad_group(probs[i:i + 4], f16=self.f16)
 
     def _colsum(self, x, out, M, dtype=T.BF16):   # dtype BF16 = "the 16-bit type of the build"
         self._c("tnr_colsum", x, x.stride(0), dtype, M, x.shape[1], out, self.cs_part, 0)
@@ -949,6 +978,7 @@ class Engine:
         L, D, H, I = cfg.L, cfg.D, cfg.H, cfg.I
         M = N * L
         g, gr = self.p, self.grads
+        self._wg = None                    # nothing collected from an earlier, interrupted backward
         ds = self._dsite                   # sites of the forward call this backward belongs to (self.drop_cur)
         gi = self.ginv                     # parameter gradients below the pooling backward: 1 / loss scale on the way out
         rb = self.red.setdefault(("heads", acc, N), _ReduceBatch(self.dev))
@@ -991,6 +1021,7 @@ class Engine:
             # (without a bucket hook - one GPU - nothing waits for the FFN block's gradients before the end of the layer: one
             # batched reduction per layer instead of two)
             one = after_bucket is None
+            self._wg = [] if (tr and self.group_wgrad) else None
             rba = self.red.setdefault((l, acc, N, "att+ffn" if one else "att"), _ReduceBatch(self.dev)) if tr else None
             rb = (rba if one else self.red.setdefault((l, acc, N, "ffn"), _ReduceBatch(self.dev))) if tr else None
             nblk = T.query("tnr_ln_bwd_blocks", M)
@@ -1018,6 +1049,8 @@ class Engine:
                 if not one:
                     rb.flush()
                 if after_bucket:
+                    if self._wg is not None:
+                        self._wgrad_flush()            # the FFN block's two gradients: its bucket goes out now
                     after_bucket(bucket)
                     bucket += 1
             self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
@@ -1041,6 +1074,9 @@ class Engine:
                     rba.add(self.cs_tmp2, 1, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
             if tr:
                 self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M, acc)
+                if self._wg is not None:               # all four of the layer (two under a bucket hook), before the next layer overwrites their operands
+                    self._wgrad_flush()
+                    self._wg = None
                 rba.flush()
             if l > self.lo:
                 nxt = self.dy2 if dy is self.dy else self.dy

@@ -50,6 +50,25 @@ def sgemm_group(problems):
     if rc != 0:
         raise TnrError("tnr_sgemm_group failed (%d): %s" % (rc, lib().tnr_last_error().decode()))
 
+class WgradProblem(_c.Structure):
+    """tnr_wgrad_problem_t (include/tnr_hip.h): one member of a tnr_gemm_tn_wgrad_group launch."""
+    _fields_ = [("dY", _P), ("lddy", _L), ("X", _P), ("ldx", _L), ("dW", _P), ("lddw", _L), ("M", _L), ("N", _L), ("K", _L),
+                ("ws", _P), ("splits", _I), ("accumulate", _I), ("out_scale", _F)]
+
+
+def wgrad_group(problems, f16=False):
+    """problems: list of dicts with the field names of WgradProblem (tensors for the pointers); <= 4."""
+    arr = (WgradProblem * len(problems))()
+    for i, q in enumerate(problems):
+        for k, _ in WgradProblem._fields_:
+            v = q[k]
+            setattr(arr[i], k, _ptr(v) if isinstance(v, torch.Tensor) else v)
+    name = "tnr_gemm_tn_wgrad_group" + ("_f16" if f16 else "")
+    rc = getattr(lib(), name)(arr, len(problems), stream())
+    if rc != 0:
+        raise TnrError("%s failed (%d): %s" % (name, rc, lib().tnr_last_error().decode()))
+
+
 # name -> argument types (return type int unless listed in _RET)
 _SIG = {
     "tnr_version": [],
@@ -83,6 +102,7 @@ _SIG = {
     "tnr_attpool_bwd": [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _I, _I, _P],
     "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _I, _P, _P],
     "tnr_sgemm_group": [_c.POINTER(SgemmProblem), _I, _P],
+    "tnr_gemm_tn_wgrad_group": [_c.POINTER(WgradProblem), _I, _P],
     "tnr_gather_rows": [_P, _L, _P, _L, _I, _I, _P, _L, _L, _P],
     "tnr_segment_sum_rows": [_P, _P, _P, _L, _I, _P, _P],
     "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -108,7 +128,7 @@ _SIG = {
 }
 # entry points that exist twice: bf16 (plain name) and fp16 (suffix _f16)
 TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_colsum_rows", "tnr_gemm_nt_route",
-         "tnr_gemm_tn_wgrad", "tnr_gemm_tn_wgrad_ex", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd",
+         "tnr_gemm_tn_wgrad", "tnr_gemm_tn_wgrad_ex", "tnr_gemm_tn_wgrad_group", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd",
          "tnr_colsum", "tnr_colsum_batched", "tnr_attpool_fwd", "tnr_attpool_bwd", "tnr_refresh_shadows",
          "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32", "tnr_pool_fwd", "tnr_pool_bwd"]
 # *_do: the same with a tnr_dropout_t* in front of the stream (tnr_ln_bwd_do: the masked second output first)
