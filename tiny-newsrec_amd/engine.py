@@ -488,16 +488,16 @@ class Engine:
         self.dypre, self.dh1, self.dh1pre, self.dctx = z(Mp, H), z(Mp, H), z(Mp, H), z(Mp, H)
         self.du = z(Mp, I)
         self.dqkv = z(Mp, 3 * H)
-        self.ln_part = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
-        self.ln_part1 = f(T.query("tnr_ln_bwd_part_elems", Mp, H))
+        # partial sums of the bias / LayerNorm gradients: a set per trainable layer, so that ONE batched reduction at the end of the
+        # backward can sum them all (they are a few tens of MB per layer)
+        self.lpart = {l: dict(ln_part=f(T.query("tnr_ln_bwd_part_elems", Mp, H)), ln_part1=f(T.query("tnr_ln_bwd_part_elems", Mp, H)),
+                              gcs_part=f(T.query("tnr_gemm_colsum_rows", Mp), I), qkvb_part=f(N, 3 * H), cs_tmp=f(I), cs_tmp2=f(3 * H))
+                      for l in cfg.trainable_layers}
         self.red = {}                                                      # gradient bucket -> _ReduceBatch
         self.cs_part = f(max(T.query("tnr_colsum_part_elems", Mp, 3 * H if L > 32 else QPAD),
                              T.query("tnr_colsum_part_elems", 128, I),
                              T.query("tnr_colsum_part_elems", max(B * cfg.U, 1), 3 * D),
                              T_ * T.query("tnr_colsum_part_elems", Rt, D)))
-        self.cs_tmp, self.cs_tmp2 = f(I), f(3 * H)                        # column sums of the unfused fallbacks, before 1 / loss scale
-        self.gcs_part = f(T.query("tnr_gemm_colsum_rows", Mp), I)        # b1 gradient partials from the dgrad epilogue
-        self.qkvb_part = f(N, 3 * H)                                       # q/k/v bias gradient partials from attention bwd
         self.db1p = f(N, QPAD)
         self.epre_u = f(B * cfg.U, cfg.Qu)
         self.epad_buf = {1: f(1, cfg.Qu), T_: f(T_, cfg.Qu)}      # student / teachers (these run on different streams)
@@ -515,6 +515,7 @@ class Engine:
                         # x1.65 at 1, x1.25 at 2, x1.1-1.15 at 4 -- but every doubling adds a round of fp32 slab traffic
                         # (alone: +10 % at 2, +24 % at 4 for the 3072 x 768 gradient; tools/cu_contention.py)
 
+    merge_reductions = True   # False: the partial-sum reductions per gradient bucket even without a bucket hook (tools/step_ab.py)
     group_wgrad = False  # True: a layer's weight gradients in one persistent launch (tnr_gemm_tn_wgrad_group; the same bits).  Measured
                          # on one GPU: step +6.4 %, the four gradients 848 -> 1 088 us - one launch each,
                          # one unit per workgroup, all units equal and in lockstep, is the better schedule; kept as a switch for the
@@ -912,7 +913,8 @@ class Engine:
         g = self.p
         S, dS = self.S[:Rt], self.dS
         hidx, cidx = self._idx(B)
-        rbh = self.red.setdefault(("heads", 0, N if self.plan is None else self.plan.n_enc), _ReduceBatch(self.dev))
+        rbh = self.red.setdefault(("heads", 0, N if self.plan is None else self.plan.n_enc, after_bucket is None and self.merge_reductions),
+                                  _ReduceBatch(self.dev))   # backward_encoder's key
         pend = []                 # fp32 GEMMs that depend on nothing computed below: launched together with the user encoder's
         if T_ > 0:
             self._transform_grads(Rt, rbh, pend)
@@ -981,7 +983,9 @@ class Engine:
         self._wg = None                    # nothing collected from an earlier, interrupted backward
         ds = self._dsite                   # sites of the forward call this backward belongs to (self.drop_cur)
         gi = self.ginv                     # parameter gradients below the pooling backward: 1 / loss scale on the way out
-        rb = self.red.setdefault(("heads", acc, N), _ReduceBatch(self.dev))
+        # no bucket hook (one GPU): every partial sum of the backward in ONE batched reduction at its end
+        one = after_bucket is None and self.merge_reductions
+        rb = rb_heads = self.red.setdefault(("heads", acc, N, one), _ReduceBatch(self.dev))
         # dense + pooling of the news encoder
         wd = g(PFX + "dense.weight")
         self._sgemm_group([
@@ -996,7 +1000,8 @@ class Engine:
             rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], acc, gi)
             rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], acc, gi)
             rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), acc, gi)
-        rb.flush()
+        if not one or not cfg.trainable_layers:
+            rb.flush()
         if cfg.pooling == "att":
             self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M, acc)
         if after_bucket:
@@ -1018,33 +1023,33 @@ class Engine:
             # two gradient buckets per layer, in completion order: the FFN block (names[10:16]) is final after the W1
             # weight gradient, the attention block (names[0:10]) at the end of the layer -- the last all-reduce of a step
             # (attention block of layer lo) is then a third of a layer instead of a whole one
-            # (without a bucket hook - one GPU - nothing waits for the FFN block's gradients before the end of the layer: one
-            # batched reduction per layer instead of two)
-            one = after_bucket is None
+            # (without a bucket hook - one GPU - nothing waits for any bucket: the partial sums of all layers and of the heads go
+            # into one batched reduction at the end of the backward)
             self._wg = [] if (tr and self.group_wgrad) else None
-            rba = self.red.setdefault((l, acc, N, "att+ffn" if one else "att"), _ReduceBatch(self.dev)) if tr else None
-            rb = (rba if one else self.red.setdefault((l, acc, N, "ffn"), _ReduceBatch(self.dev))) if tr else None
+            rba = (rb_heads if one else self.red.setdefault((l, acc, N, "att"), _ReduceBatch(self.dev))) if tr else None
+            rb = (rb_heads if one else self.red.setdefault((l, acc, N, "ffn"), _ReduceBatch(self.dev))) if tr else None
+            P = self.lpart.get(l)
             nblk = T.query("tnr_ln_bwd_blocks", M)
             # with dropout behind the two output Linears the LayerNorm backward has two outputs: dx for the residual branch and
             # dx * mask / (1 - p) = the Linear's output gradient (its weight gradient, dgrad and -- through the partials -- bias)
             dF, dO, dPb = ds(T.DROP_FFN_OUT, l), ds(T.DROP_ATTN_OUT, l), ds(T.DROP_PROB, l)
             dypre_lin = self.dyprem if dF else self.dypre
             dh1pre_lin = self.dh1prem if dO else self.dh1pre
-            lnargs = (dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None, self.ln_part if tr else None, M, H)
+            lnargs = (dy, a["ypre"], a["st2"], g(names[14]), self.dypre, None, None, None, (P["ln_part"] if tr else None), M, H)
             self._c("tnr_ln_bwd_do", *lnargs, self.dyprem, dF) if dF else self._c("tnr_ln_bwd", *lnargs)
             if tr:
-                rb.add(self.ln_part, nblk, 3 * H, 2 * H, self._view(names[14], 2 * H, (2 * H,), grad=True), acc, gi)   # [dgamma | dbeta]
-                rb.add(self.ln_part[2 * H:], nblk, 3 * H, H, gr[names[13]], acc, gi)                                 # output.dense.bias
+                rb.add(P["ln_part"], nblk, 3 * H, 2 * H, self._view(names[14], 2 * H, (2 * H,), grad=True), acc, gi)   # [dgamma | dbeta]
+                rb.add(P["ln_part"][2 * H:], nblk, 3 * H, H, gr[names[13]], acc, gi)                                 # output.dense.bias
                 self._wgrad(dypre_lin, a["g"], gr[names[12]], M, acc)
             fused_cs = tr and M > 128            # the column-sum epilogue needs more than one 128-row strip
             self._gemm(dypre_lin, sh["w2T"], self.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if fused_cs else 0),
-                       colsum=self.gcs_part if fused_cs else None)
+                       colsum=P["gcs_part"] if fused_cs else None)
             if tr:
                 if fused_cs:
-                    rb.add(self.gcs_part, self._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], acc, gi)
+                    rb.add(P["gcs_part"], self._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], acc, gi)
                 else:
-                    self._c("tnr_colsum", self.du, I, T.BF16, M, I, self.cs_tmp[:I], self.cs_part, 0)
-                    rb.add(self.cs_tmp, 1, I, I, gr[names[11]], acc, gi)
+                    self._c("tnr_colsum", self.du, I, T.BF16, M, I, P["cs_tmp"][:I], self.cs_part, 0)
+                    rb.add(P["cs_tmp"], 1, I, I, gr[names[11]], acc, gi)
                 self._wgrad(self.du, a["h1"], gr[names[10]], M, acc)
                 if not one:
                     rb.flush()
@@ -1054,30 +1059,31 @@ class Engine:
                     after_bucket(bucket)
                     bucket += 1
             self._gemm(self.du, sh["w1T"], self.dh1, M, res=self.dypre, flags=T.EPI_RES)
-            lnargs = (self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, None, None, None, self.ln_part1 if tr else None, M, H)
+            lnargs = (self.dh1, a["h1pre"], a["st1"], g(names[8]), self.dh1pre, None, None, None, (P["ln_part1"] if tr else None), M, H)
             self._c("tnr_ln_bwd_do", *lnargs, self.dh1prem, dO) if dO else self._c("tnr_ln_bwd", *lnargs)
             if tr:
-                rba.add(self.ln_part1, nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True), acc, gi)
-                rba.add(self.ln_part1[2 * H:], nblk, 3 * H, H, gr[names[7]], acc, gi)                               # attention.output.dense.bias
+                rba.add(P["ln_part1"], nblk, 3 * H, 2 * H, self._view(names[8], 2 * H, (2 * H,), grad=True), acc, gi)
+                rba.add(P["ln_part1"][2 * H:], nblk, 3 * H, H, gr[names[7]], acc, gi)                               # attention.output.dense.bias
                 self._wgrad(dh1pre_lin, a["ctx"], gr[names[6]], M, acc)
             self._gemm(dh1pre_lin, sh["oT"], self.dctx, M)
             if L <= 32:
-                bargs = (a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv, self.qkvb_part if tr else None, N, L, cfg.A)
+                bargs = (a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv, (P["qkvb_part"] if tr else None), N, L, cfg.A)
                 self._c("tnr_attn_l32_bwd_do", *bargs, dPb) if dPb else self._c("tnr_attn_l32_bwd", *bargs)
                 if tr:
-                    rba.add(self.qkvb_part, N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
+                    rba.add(P["qkvb_part"], N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
             else:
                 bargs = (a["qkv"], self.mask_add, self.rel, a["ctx"], self.dctx, a["lse"], self.delta, self.dqkv, N, L, cfg.A)
                 self._c("tnr_attn_long_bwd_do", *bargs, dPb) if dPb else self._c("tnr_attn_long_bwd", *bargs)
                 if tr:
-                    self._c("tnr_colsum", self.dqkv, 3 * H, T.BF16, M, 3 * H, self.cs_tmp2[:3 * H], self.cs_part, 0)
-                    rba.add(self.cs_tmp2, 1, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
+                    self._c("tnr_colsum", self.dqkv, 3 * H, T.BF16, M, 3 * H, P["cs_tmp2"][:3 * H], self.cs_part, 0)
+                    rba.add(P["cs_tmp2"], 1, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
             if tr:
                 self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M, acc)
                 if self._wg is not None:               # all four of the layer (two under a bucket hook), before the next layer overwrites their operands
                     self._wgrad_flush()
                     self._wg = None
-                rba.flush()
+                if not one:
+                    rba.flush()
             if l > self.lo:
                 nxt = self.dy2 if dy is self.dy else self.dy
                 self._gemm(self.dqkv, sh["qkvT"], nxt, M, res=self.dh1pre, flags=T.EPI_RES)
@@ -1085,6 +1091,8 @@ class Engine:
             if tr and after_bucket:
                 after_bucket(bucket)
                 bucket += 1
+        if one:
+            rb_heads.flush()
 
     def grad(self, name):
         """Gradient of a trainable parameter (a view into flat_g; the fp16 loss scale never reaches it)."""

@@ -148,7 +148,7 @@ class Stage1Engine:
         C, D = self.cfg_t.C, self.cfg_t.D
         S, dS = t.S[:Rt], t.dS
         if self.cfg_t.T:
-            t._transform_grads(Rt, t.red.setdefault(("heads", 0, N), _ReduceBatch(t.dev)))
+            t._transform_grads(Rt, t.red.setdefault(("heads", 0, N, t.merge_reductions), _ReduceBatch(t.dev)))   # the title pass's batch (no bucket hook there)
         T.call("tnr_score_bwd", S, t.cidx, S[N:], t.dscore, dS, dS[N:], B, C, D)
         t.backward_encoder(dS[:N], N, acc=0)
         b.backward_encoder(dS[N:Rt], B, acc=1, after_bucket=after_bucket)

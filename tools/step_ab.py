@@ -30,6 +30,8 @@ for rnd in range(6):
             eng.teacher_stream = side if int(VALS[v]) else None
         elif KEY == "sg_kdiv":             # engine-level: K per split of the small fp32 GEMMs
             eng.sg_kdiv = int(VALS[v])
+        elif KEY == "merge_reductions":    # engine-level: one batched partial-sum reduction per backward (1) or one per gradient bucket (0)
+            eng.merge_reductions = bool(int(VALS[v]))
         elif KEY == "group_wgrad":         # engine-level: a layer's four weight gradients in one persistent launch (1) or one launch each (0)
             eng.group_wgrad = bool(int(VALS[v]))
         elif KEY == "group_sgemm":         # engine-level: independent fp32 GEMMs of the heads in one launch (1) or one launch each (0)
