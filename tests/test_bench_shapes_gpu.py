@@ -355,6 +355,8 @@ def test_queue_table_refuses_the_129th_stream_and_resets():
     assert "(-2)" in d["msg"] and "pp" in d["msg"], d["msg"]
     assert d["again"] and d["rc_reset"] == 0 and d["after_reset"], d
     assert d["rc_unbound"] == -2 and d["plain_on_refused"], d
+    # one table for the bf16 and the fp16 build, the NT and the weight-gradient kernel
+    assert d["both_builds"] and d["refused_f16"] and d["rc_reset2"] == 0 and d["after_reset2"], d
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
@@ -406,3 +408,28 @@ def test_wgrad_group_equals_separate_launches_bit_for_bit(dtype):
         T.call("tnr_gemm_tn_wgrad_ex" + sfx, q["dY"], N, q["X"], K, ref, K, M, N, K, torch.zeros(el, device=DEV), sp, 0, q["out_scale"])
         torch.cuda.synchronize()
         assert torch.equal(q["dW"], ref), (N, K)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_wgrad_group_with_fewer_units_than_xcd_labels(dtype):
+    """Two 256 x 256 gradients with one split each are two units: fewer than the eight XCD labels the grouped launch cuts its unit
+    range over (a grid of two workgroups would leave the label that owns unit 1 without a workgroup and the slab sum would read an
+    unwritten slab).  The entry point falls back to one launch per problem; results equal the single calls bit for bit."""
+    td, sfx = TD[dtype], _sfx(dtype)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    M, N, K = 700, 256, 256
+    Mp = (M + 127) // 128 * 128
+    probs, want = [], []
+    for i in range(2):
+        dy = torch.zeros((Mp, N), device=DEV, dtype=td); x = torch.zeros((Mp, K), device=DEV, dtype=td)
+        dy[:M] = (torch.randn((M, N), device=DEV, generator=g) * 0.1).to(td)
+        x[:M] = torch.randn((M, K), device=DEV, generator=g).to(td)
+        ref = torch.zeros((N, K), device=DEV)
+        T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy, N, x, K, ref, K, M, N, K, torch.zeros(N * K, device=DEV), 1, 0, 1.0)
+        want.append(ref)
+        probs.append(dict(dY=dy, lddy=N, X=x, ldx=K, dW=torch.full((N, K), float("nan"), device=DEV), lddw=K, M=M, N=N, K=K,
+                          ws=torch.full((N * K,), float("nan"), device=DEV), splits=1, accumulate=0, out_scale=1.0))
+    T.wgrad_group(probs, f16=dtype == "fp16")
+    torch.cuda.synchronize()
+    for q, ref in zip(probs, want):
+        assert torch.equal(q["dW"], ref)

@@ -419,3 +419,53 @@ def test_odd_shapes_against_oracle(shape):
         worst = max(worst, err)
         assert err < 2e-2, "%s: %.3e (norm %.2e)" % (k, err, rn)
     print("\n[odd shape %s] worst gradient rel. L2 error %.2e" % (s, worst))
+
+
+@pytest.mark.parametrize("D,kdiv", [(256, 256), (256, 128), (256, 64), (512, 256), (512, 128)])
+def test_grouped_small_gemms_equal_separate_launches_when_several_members_split(D, kdiv):
+    """The heads' independent fp32 GEMMs run as grouped launches (Engine._sgemm_group).  Members of a group run concurrently, so
+    every K-split member needs partial-sum storage of its own: with K slices of 128 (or news_dim 512) two or three members of a
+    group split at once, which the shipped configuration (D = 256, slices of 256) never does.  A whole training step with the
+    groups on must equal the step with one launch per GEMM bit for bit, and match the oracle."""
+    import hashinit
+    from helpers import FULL, state_shapes
+    B, U, C, L, T_, nl = 3, 7, 3, 12, 2, 2
+    P = hashinit.init_state_dict(78, state_shapes(dict(FULL), nl, D, T_))
+    cfg = dict(n_layers=nl, heads=12, trainable_layers=[1], user_log_mask=False, temperature=1.0, coef=0.2)
+    rs = np.random.RandomState(6)
+
+    def toks(n):
+        out = np.zeros((n, 2 * L), np.int64)
+        for r in range(n):
+            k = rs.randint(1, L + 1)
+            out[r, :k] = rs.randint(1, 30522, k)
+            out[r, L:L + k] = 1
+        return out
+    hist, cand = toks(B * U).reshape(B, U, 2 * L), toks(B * C).reshape(B, C, 2 * L)
+    mask = (rs.rand(B, U) > 0.3).astype(np.float32)
+    label = rs.randint(0, C, B)
+    th = [rs.randn(B, U, D).astype(np.float32) * 0.3 for _ in range(T_)]
+    tc = [rs.randn(B, C, D).astype(np.float32) * 0.3 for _ in range(T_)]
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    res = {}
+    for grouped in (True, False):
+        ec = E.EngineConfig(n_layers=nl, trainable_layers=(1,), num_teachers=T_, user_log_length=U, npratio=C - 1, num_words=L,
+                            news_dim=D, user_log_mask=False, temperature=1.0, coef=0.2)
+        eng = E.Engine(ec, DEV, max_batch=B, dtype="fp16")
+        eng.sg_kdiv, eng.group_sgemm = kdiv, grouped
+        eng.load_state_dict(P)
+        losses, score = eng.forward(t(hist), t(mask), t(cand), t(label), [t(x) for x in th], [t(x) for x in tc])
+        eng.backward()
+        torch.cuda.synchronize()
+        res[grouped] = (losses.clone(), score.clone(), eng.S.clone(), eng.flat_g.clone())
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    out = O.model_fwd(P, cfg, hist, mask, cand, label, th, tc)
+    ref_l = np.array([out["distill_loss"], out["target_loss"], out["emb_loss"]])
+    assert np.abs(res[True][0][:3].cpu().numpy() - ref_l).max() <= 2e-3 * max(1.0, np.abs(ref_l).max())
+    assert np.abs(res[True][1].cpu().numpy() - out["student_score"]).max() <= 2e-3 * max(1.0, np.abs(out["student_score"]).max())
+    G = O.model_bwd(P, cfg, out)
+    for k in ("student.news_encoder.dense.weight", "student.user_encoder.attn.att_fc1.weight", "transform_matrix.0.weight"):
+        got, ref = eng.grad(k).cpu().numpy(), G[k]
+        err = np.sqrt(((got - ref).astype(np.float64) ** 2).sum()) / np.sqrt((ref.astype(np.float64) ** 2).sum())
+        assert err < 2e-2, "%s: %.3e" % (k, err)

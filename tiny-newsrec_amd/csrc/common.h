@@ -48,6 +48,9 @@ struct TnrGemmOpts {
     int cus;         // 0 = plan and size the persistent GEMM grids for the device's CUs ; n = for n of them (two kernels side by side)
 };
 TnrGemmOpts* tnr_gemm_opts();
+// The tile-queue counter set of (current device, stream) for the persistent GEMM kernels of BOTH builds (defined once, in the
+// bf16 build of gemm.hip); reset = zero it again (stream-ordered).  NULL + tnr_last_error when the table is full.
+unsigned* tnr_pp_queue_of(void* stream, bool reset);
 
 // Runs `body` once per device of this process (function attributes such as the dynamic LDS limit are set per device); two
 // threads racing through it both run the idempotent body.

@@ -1114,7 +1114,8 @@ __device__ __forceinline__ int pp_bswz(int row) { return ((row >> 1) & 1) | (((r
 // wait would read the register before the data is there.
 // (a counter set: 8 tile counters + the count of workgroups that have left, each on a 256-byte line of its own - the workgroups
 // of one XCD label then update a line that stays in their L2 instead of passing it between the eight)
-constexpr int PP_Q_STRIDE = 64, PP_Q_SET = 9 * PP_Q_STRIDE;
+constexpr int PP_Q_STRIDE = 64;
+[[maybe_unused]] constexpr int PP_Q_SET = 9 * PP_Q_STRIDE;
 __device__ __forceinline__ void pp_q_fetch(unsigned& dst, unsigned* ctr, bool on) {
     const unsigned long long m = (unsigned)__builtin_amdgcn_readfirstlane(on ? 1 : 0);
     unsigned long long sv;
@@ -1880,9 +1881,18 @@ static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
 // by a hipMemsetAsync on its stream when the stream is first bound and again by tnr_gemm_queue_reset(); every launch leaves
 // it at zero (the last workgroup out resets it).  The table never drains a device and never changes the current device: when
 // it is full the launch is refused (TNR_EUNSUPPORTED) and the caller either reuses fewer streams or runs with option "pp" = 0.
-constexpr int PP_QUEUE_SETS = 128, PP_LDS = LDS3_BYTES + 64;
+// ONE table for both builds of this file (bf16 and -DTNR_BUILD_F16): it is defined in the bf16 translation unit and the fp16
+// one calls into it (tnr_pp_queue_of, declared in common.h), so a stream that launches kernels of both builds is bound once and
+// tnr_gemm_queue_reset reaches the counters whichever build's kernel was aborted.
+constexpr int PP_LDS = LDS3_BYTES + 64;
+[[maybe_unused]] constexpr int PP_QUEUE_SETS = 128;
+#ifdef TNR_BUILD_F16
+static unsigned* pp_queue_of(hipStream_t st, bool reset = false) { return tnr_pp_queue_of(st, reset); }
+#else
 __device__ unsigned g_pp_queue[PP_QUEUE_SETS * PP_Q_SET];
-static unsigned* pp_queue_of(hipStream_t st, bool reset = false) {
+static unsigned* pp_queue_of(hipStream_t st, bool reset = false) { return tnr_pp_queue_of(st, reset); }
+unsigned* tnr_pp_queue_of(void* stream, bool reset) {
+    hipStream_t st = (hipStream_t)stream;
     struct Slot { int dev; hipStream_t st; };
     static std::mutex mu;
     static Slot slots[PP_QUEUE_SETS];
@@ -1923,6 +1933,7 @@ static unsigned* pp_queue_of(hipStream_t st, bool reset = false) {
 #endif
     return set;
 }
+#endif
 
 #ifndef TNR_BUILD_F16
 // Zero the calling stream's tile-queue counters (stream-ordered).  Only needed after a launch on that stream was aborted (device
@@ -2121,6 +2132,16 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_group)(const tnr_wgrad_problem_t* p, i
         sg.ws[i] = q.ws; sg.out[i] = q.dW; sg.NK[i] = q.N * q.K; sg.ldo[i] = q.lddw;
         sg.splits[i] = splits; sg.K[i] = (int)q.K; sg.accumulate[i] = q.accumulate; sg.out_scale[i] = q.out_scale;
         maxblk = std::max<int64_t>(maxblk, (q.N * q.K / 4 + 255) / 256);
+    }
+    if (units < 8) {
+        // fewer units than XCD labels: the grid min(units, ...) would leave labels that tn_group_ranges gives work without a
+        // workgroup (their units never computed, the slab sum reading unwritten slabs) -> one launch per problem, the same results
+        for (int i = 0; i < n; ++i) {
+            int rc = TNR_NAME(tnr_gemm_tn_wgrad_ex)(p[i].dY, p[i].lddy, p[i].X, p[i].ldx, p[i].dW, p[i].lddw, p[i].M, p[i].N, p[i].K, p[i].ws,
+                                                     p[i].splits, p[i].accumulate, p[i].out_scale, stream);
+            if (rc != TNR_OK) return rc;
+        }
+        return TNR_OK;
     }
     for (int i = n; i <= TN_MAXP; ++i) grp.ubase[i] = (int)units;
     tn_group_ranges(grp, n);

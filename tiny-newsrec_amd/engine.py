@@ -503,7 +503,8 @@ class Engine:
         self.epad_buf = {1: f(1, cfg.Qu), T_: f(T_, cfg.Qu)}      # student / teachers (these run on different streams)
         self.epre_t = f(T_, B * cfg.U, cfg.Qu)
         self.KS = 8                                                        # split-K of the long-K small GEMMs
-        self.sg_part = f(self.KS * max(T_ * D * D, D * H, 3 * D * D, T_ * Rt * D, N * max(H, D), T_ * B * cfg.U * max(cfg.Qu, 3 * D)))
+        # x 2: the K-split members of a grouped launch get disjoint slices (_sgemm_group)
+        self.sg_part = f(2 * self.KS * max(T_ * D * D, D * H, 3 * D * D, T_ * Rt * D, N * max(H, D), T_ * B * cfg.U * max(cfg.Qu, 3 * D)))
         self.sg_part2 = f(self.KS * max(cfg.Qu * D, 3 * D * D if cfg.nrms_heads else 1))       # second split problem of a grouped launch
         # weight-gradient slabs: the four gradients of a layer are in flight together (_wgrad_flush), each with slabs of its own
         self.ws = f(max(sum(_rup(self._wgrad_splits(n_, k_)[1], 64) for n_, k_ in ((3 * H, H), (H, H), (I, H), (H, I))),
@@ -587,14 +588,24 @@ class Engine:
         computed exactly as its own tnr_sgemm call would).  A split problem needs a partial buffer of its own (`part`)."""
         if ksplit is None:
             ksplit = max(1, min(K // getattr(self, "sg_kdiv", 256), 8))
-        if ksplit > 1:
-            part = self.sg_part if part is None else part
+        if ksplit > 1 and part is not None:
             assert ksplit * batch * M * N <= part.numel(), "fp32 GEMM workspace too small for its K split"
         return dict(A=A, a_rs=a_rs, a_cs=a_cs, sA=sA, B=Bm, b_rs=b_rs, b_cs=b_cs, sB=sB, C=C, ldc=ldc, sC=sC, bias=bias, sBias=sBias,
                     M=M, N=N, K=K, batch=batch, alpha=alpha, beta=beta, ksplit=ksplit, part=part if ksplit > 1 else None)
 
     def _sgemm_group(self, problems):
-        """Independent fp32 GEMMs in one launch (Engine.group_sgemm = False: one tnr_sgemm each, the same bits; tools/step_ab.py)."""
+        """Independent fp32 GEMMs in one launch (Engine.group_sgemm = False: one tnr_sgemm each, the same bits; tools/step_ab.py).
+        The members run concurrently, so every K-split member gets a DISJOINT slice of the partial buffer (tnr_sgemm_group:
+        'not shared inside a group'); a member that brought its own buffer keeps it."""
+        off = 0
+        for q in problems:
+            if q["ksplit"] > 1 and q["part"] is None:
+                need = q["ksplit"] * q["batch"] * q["M"] * q["N"]
+                q["part"] = self.sg_part[off:off + need]
+                off += _rup(need, 64)
+        assert off <= self.sg_part.numel(), "fp32 GEMM workspace too small for the K splits of a grouped launch"
+        parts = [q["part"].data_ptr() for q in problems if q["part"] is not None]
+        assert len(parts) == len(set(parts)), "two members of a grouped fp32 GEMM share a partial buffer"
         if getattr(self, "group_sgemm", True):
             T.sgemm_group(problems)
             return
