@@ -379,6 +379,20 @@ int tnr_dropout_mask_probs(const tnr_dropout_t* drop, int64_t pairs, int L, int 
 int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step,
                      float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* Dynamic loss scaling of the fp16 build (the reference trains in fp32 and needs none, run.py:134,194-195; with 16-bit
+ * activation gradients one overflow would otherwise poison m / v / vmax for good).  guard = 4 uint32 words on the device,
+ * zero at start: [0] stamp of the last step that overflowed, [1] number of skipped steps, [2] scratch.
+ * tnr_grad_nonfinite: if any of g[0 .. n) is inf or nan, guard[0] = max(guard[0], stamp) and guard[1] += 1 (stamp >= 1, the
+ * caller's running count of optimiser steps).  tnr_amsgrad_step_guarded = tnr_amsgrad_step, except that (a) a launch whose
+ * stamp equals guard[0] touches nothing: the skipped step; (b) Adam's bias corrections use step - (guard[1] - known_skips):
+ * `step` is the caller's count of steps, known_skips how many skipped ones it has already taken out of that count (it learns of
+ * a skip with a lag of up to two steps).  Stream-ordered, no host synchronisation; the caller reads guard back whenever it
+ * likes (tiny-newsrec_amd/engine.py: LossScaler).  guard == NULL: unguarded. */
+int tnr_grad_nonfinite(const float* g, int64_t n, unsigned* guard, unsigned stamp, void* stream);
+int tnr_amsgrad_step_guarded(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step,
+                             float lr, float beta1, float beta2, float eps, float grad_scale, const unsigned* guard,
+                             unsigned stamp, unsigned known_skips, void* stream);
+
 /* refresh bf16 weight copies after an update: desc = n_desc * 8 int64 on DEVICE:
  * {src fp32 ptr, rows, cols, dst ptr (or 0), dst ld, dstT ptr (or 0), dstT ld, unused}
  * dst[r*ld + c] = bf16(src[r,c]) ; dstT[c*ldT + r] = bf16(src[r,c]). */

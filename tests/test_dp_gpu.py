@@ -98,8 +98,8 @@ def test_bucketwise_optimiser_step_is_bit_identical_to_one_launch(rates):
     P = hashinit.init_state_dict(3, state_shapes(FULL, 2, cfg.D, 2))
     outs = []
     for bucketed in (False, True):
-        eng = E.Engine(cfg, "cuda:0", max_batch=2, dtype="fp16")
-        eng.load_state_dict(P)
+        eng = E.Engine(cfg, "cuda:0", max_batch=2, dtype="bf16")      # the bucket-wise update is the bf16 path: under fp16's dynamic
+        eng.load_state_dict(P)                                          # loss scale the whole gradient is checked before any slice moves
         g = torch.Generator(device="cuda:0").manual_seed(5)
         for step in range(3):
             eng.flat_g.copy_(torch.randn(eng.n_train, device="cuda:0", generator=g) * 1e-3)

@@ -469,3 +469,62 @@ def test_grouped_small_gemms_equal_separate_launches_when_several_members_split(
         got, ref = eng.grad(k).cpu().numpy(), G[k]
         err = np.sqrt(((got - ref).astype(np.float64) ** 2).sum()) / np.sqrt((ref.astype(np.float64) ** 2).sum())
         assert err < 2e-2, "%s: %.3e" % (k, err)
+
+
+def test_fp16_overflow_skips_the_step_and_halves_the_scale():
+    """Dynamic loss scale of the fp16 build (the reference trains in fp32, run.py:134,194-195, and needs none).  A backward whose
+    16-bit activation gradients overflow leaves inf / nan in the flat gradient; the step must then touch NOTHING - parameters, m,
+    v, vmax bit-identical, the 16-bit weight copies too - the device decides without the host (tnr_grad_nonfinite +
+    tnr_amsgrad_step_guarded), the host learns it two steps later, halves the scale and takes the skipped step out of Adam's
+    count.  Clean steps are bit-identical to the unguarded optimiser's; enough of them in a row double the scale again."""
+    z, P, cfg, inp = load_case("full_model_1.npz")
+    T_ = len(inp[4])
+    eng, B = _engine_for(cfg, z, T_, "fp16")
+    ref, _ = _engine_for(cfg, z, T_, "fp16")
+    ref.scaler.enabled = False                   # the unguarded optimiser (static scale), as before this round
+    for e in (eng, ref):
+        e.load_state_dict(P)
+    args = _dev_inputs(inp)
+    sc = eng.scaler
+    assert sc.enabled and sc.mult == 1.0
+
+    def one(e):
+        e.forward(*args)
+        e.backward()
+        e.step(1e-3)
+    one(eng); one(ref)
+    torch.cuda.synchronize()
+    for a, b in ((eng.flat[True], ref.flat[True]), (eng.adam_m, ref.adam_m), (eng.adam_v, ref.adam_v), (eng.adam_vmax, ref.adam_vmax)):
+        assert torch.equal(a, b)                 # a clean guarded step == the unguarded step, bit for bit
+    snap = [x.clone() for x in (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax, eng.sh[eng.lo]["w1"], eng.sh[eng.lo]["qkvT"])]
+    # inject an overflow: a scale of 2^40 x the shipped one for ONE step
+    sc.mult = 2.0 ** 40
+    one(eng)
+    sc.mult = 1.0
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(eng.flat_g).all())           # the gradient did overflow ...
+    for a, b in zip(snap, (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax, eng.sh[eng.lo]["w1"], eng.sh[eng.lo]["qkvT"])):
+        assert torch.equal(a, b)                                # ... and the step touched nothing
+    assert int(sc.guard[0]) == 2 and sc.skipped == 0 and eng.step_count == 2      # the host does not know yet
+    one(eng)                                     # stamp 3: a clean step; poll() looked at stamp 1 only
+    assert sc.skipped == 0 and sc.mult == 1.0 and eng.step_count == 3
+    # ... yet it used Adam's bias corrections for step 2 (the device counts the skip itself): bit-identical to the reference
+    # engine's SECOND step on the same inputs
+    one(ref)
+    torch.cuda.synchronize()
+    for a, b in ((eng.flat[True], ref.flat[True]), (eng.adam_m, ref.adam_m), (eng.adam_v, ref.adam_v), (eng.adam_vmax, ref.adam_vmax)):
+        assert torch.equal(a, b)
+    one(eng)                                     # stamp 4: now stamp 2's answer is in
+    assert sc.skipped == 1 and sc.mult == 0.5 and eng.step_count == 3
+    one(ref)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.flat[True]).all()) and bool(torch.isfinite(eng.adam_vmax).all())
+    # half the scale: the same values one binade lower (exact but for what drops into fp16's subnormals)
+    d = float((eng.flat[True] - ref.flat[True]).abs().max())
+    assert d < 2e-6, d
+    # growth: `growth_interval` clean answers in a row double the multiplier
+    sc.growth_interval = 3
+    for _ in range(6):
+        one(eng)
+    sc.drain(eng)
+    assert sc.mult >= 1.0 and sc.skipped == 1

@@ -1,14 +1,32 @@
 // Fused AMSGrad over the flat trainable-parameter buffer + refresh of the bf16 weight copies
 // (row-major and transposed) the GEMMs read.  torch.optim.Adam(amsgrad=True) semantics (run.py:134).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+// guard (may be NULL): guard[0] = stamp of the last optimiser step whose gradient held a non-finite value, guard[1] = how many
+// steps have been skipped for that so far (tnr_grad_nonfinite).  A launch stamped guard[0] leaves parameters and state untouched:
+// the skipped step of dynamic loss scaling.  Adam's bias corrections depend on the number of steps actually TAKEN, which the host
+// knows only with a lag: it passes the factors for step, step - 1, step - 2 and how many skips it has accounted for, the kernel
+// picks by the skips it has not (all factors computed on the host, in double: the same bits as the unguarded launch).
+struct AdamFactors { float lr_c1[3], inv_sqrt_c2[3]; unsigned known_skips; };
 template <bool AMS>
 __global__ __launch_bounds__(256) void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
-                                                      float* __restrict__ vmax, int64_t n, float lr_c1, float inv_sqrt_c2,
-                                                      float b1, float b2, float eps, float gscale) {
+                                                      float* __restrict__ vmax, int64_t n, AdamFactors f,
+                                                      float b1, float b2, float eps, float gscale,
+                                                      const unsigned* __restrict__ guard, unsigned stamp) {
+    float lr_c1 = f.lr_c1[0], inv_sqrt_c2 = f.inv_sqrt_c2[0];
+    if (guard) {
+        if (guard[0] == stamp) return;
+        const unsigned k = guard[1] - f.known_skips;
+        if (k == 1) { lr_c1 = f.lr_c1[1]; inv_sqrt_c2 = f.inv_sqrt_c2[1]; }
+        else if (k >= 2) { lr_c1 = f.lr_c1[2]; inv_sqrt_c2 = f.inv_sqrt_c2[2]; }
+    }
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 4 <= n) {
@@ -36,6 +54,36 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(float* __restrict__ p, con
             m[i] = mv; v[i] = vv;
             if (AMS) vmax[i] = vm;
             p[i] -= lr_c1 * (mv / (sqrtf(vm) * inv_sqrt_c2 + eps));
+        }
+    }
+}
+
+// any inf / nan among g[0 .. n)?  -> guard[0] = max(guard[0], stamp), and the last workgroup to finish counts the skipped step in
+// guard[1] (guard[2]: arrival counter, back at zero afterwards).  16-byte reads, one atomic per offending workgroup.
+__global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* __restrict__ g, int64_t n, unsigned* guard, unsigned stamp) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    unsigned bad = 0;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const u32x4_t b = *(const u32x4_t*)(g + i);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bad |= ((b[r] & 0x7F800000u) == 0x7F800000u);
+        } else {
+            for (int64_t j = i; j < n; ++j) bad |= ((__float_as_uint(g[j]) & 0x7F800000u) == 0x7F800000u);
+        }
+    }
+    const int any = __syncthreads_or((int)bad);
+    if (threadIdx.x == 0) {
+        if (any) __hip_atomic_fetch_max(guard, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // agent-scope atomics on one address are totally ordered at the memory side: the last arriver's read of guard[0] (an
+        // atomic itself) sees every workgroup's max, each of which was issued before that workgroup's ticket
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned ticket = __hip_atomic_fetch_add(guard + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (__hip_atomic_fetch_max(guard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stamp)
+                __hip_atomic_fetch_add(guard + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(guard + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -78,20 +126,44 @@ __global__ __launch_bounds__(256) void refresh_kernel(const int64_t* __restrict_
 }  // namespace
 
 #ifndef TNR_BUILD_F16
+extern "C" int tnr_amsgrad_step_guarded(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step, float lr,
+                                        float beta1, float beta2, float eps, float grad_scale, const unsigned* guard,
+                                        unsigned stamp, unsigned known_skips, void* stream);
 extern "C" int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step, float lr,
                                 float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    return tnr_amsgrad_step_guarded(p, g, m, v, vmax, n, step, lr, beta1, beta2, eps, grad_scale, nullptr, 0u, 0u, stream);
+}
+
+extern "C" int tnr_grad_nonfinite(const float* g, int64_t n, unsigned* guard, unsigned stamp, void* stream) {
+    TNR_CHECK_ARG(g && guard && n >= 1 && stamp >= 1 && ((uintptr_t)g % 16) == 0, "tnr_grad_nonfinite: bad argument");
+    const int64_t nthr = (n + 3) / 4;
+    const unsigned grid = (unsigned)std::min<int64_t>((nthr + 255) / 256, 2048);
+    hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, guard, stamp);
+    TNR_CHECK_LAUNCH("tnr_grad_nonfinite");
+    return TNR_OK;
+}
+
+extern "C" int tnr_amsgrad_step_guarded(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step, float lr,
+                                        float beta1, float beta2, float eps, float grad_scale, const unsigned* guard,
+                                        unsigned stamp, unsigned known_skips, void* stream) {
     TNR_CHECK_ARG(p && g && m && v && n >= 1 && step >= 1, "tnr_amsgrad_step: bad argument");     // vmax NULL = plain Adam
     TNR_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                       ((uintptr_t)v % 16) == 0 && ((uintptr_t)vmax % 16) == 0, "tnr_amsgrad_step: 16-byte alignment");
-    double c1 = 1.0 - pow((double)beta1, step), c2 = 1.0 - pow((double)beta2, step);
-    float lr_c1 = (float)((double)lr / c1), inv_sqrt_c2 = (float)(1.0 / sqrt(c2));
+    AdamFactors f;
+    for (int k = 0; k < 3; ++k) {
+        const int t = step - k >= 1 ? step - k : 1;
+        const double c1 = 1.0 - pow((double)beta1, t), c2 = 1.0 - pow((double)beta2, t);
+        f.lr_c1[k] = (float)((double)lr / c1);
+        f.inv_sqrt_c2[k] = (float)(1.0 / sqrt(c2));
+    }
+    f.known_skips = known_skips;
     int64_t nthr = (n + 3) / 4;
     if (vmax)
         hipLaunchKernelGGL(amsgrad_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m,
-                           v, vmax, n, lr_c1, inv_sqrt_c2, beta1, beta2, eps, grad_scale);
+                           v, vmax, n, f, beta1, beta2, eps, grad_scale, guard, stamp);
     else      // plain Adam (Post-train_KD.ipynb cell 18: optim.Adam without amsgrad)
         hipLaunchKernelGGL(amsgrad_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m,
-                           v, vmax, n, lr_c1, inv_sqrt_c2, beta1, beta2, eps, grad_scale);
+                           v, vmax, n, f, beta1, beta2, eps, grad_scale, guard, stamp);
     TNR_CHECK_LAUNCH("tnr_amsgrad_step");
     return TNR_OK;
 }

@@ -195,6 +195,52 @@ LOSS_SCALE = 1024.0     # static scale of the 16-bit backward in fp16 mode (grad
                         # reduce, bias / LayerNorm partial reductions), so flat_g always holds the true gradients
 
 
+class LossScaler:
+    """Dynamic loss scale of the fp16 build (host side; the device side is tnr_grad_nonfinite + tnr_amsgrad_step_guarded).
+    The reference trains in fp32 (run.py:134,194-195) and has no such thing; with 16-bit activation gradients ONE overflow would
+    put inf / nan into m, v and - for good - vmax.  Every optimiser step gets a stamp; a kernel looks for non-finite values in
+    the (reduced) flat gradient and records the stamp in `guard`, and the update kernels of that stamp do nothing: the step is
+    skipped on the device without the host knowing.  The host reads guard back asynchronously and looks at the answer TWO steps
+    later (the GPU is never drained for it): an overflow halves the multiplier `mult` (the engine's scale is base x mult) and takes
+    the skipped step out of Adam's step count; `growth_interval` clean steps in a row double it again, up to `max_mult`.
+    bf16 has fp32's exponent range: scaler disabled, nothing launched."""
+
+    def __init__(self, dev, enabled, growth_interval=2000, max_mult=64.0, min_mult=2.0 ** -20):
+        self.enabled = bool(enabled) and torch.device(dev).type == "cuda"
+        self.mult, self.stamp, self.clean, self.skipped = 1.0, 0, 0, 0
+        self.growth_interval, self.max_mult, self.min_mult = growth_interval, max_mult, min_mult
+        self.guard = torch.zeros(4, dtype=torch.int32, device=dev) if self.enabled else None
+        self.pending = []                    # (stamp, pinned host word, event) in issue order
+
+    def poll(self, eng, lag=2):
+        """Answers of the steps at least `lag` stamps back.  Deterministic (which answers are used depends on the step number
+        only, never on timing: data-parallel ranks must change their scale and step count at the same step); the event of a step
+        two back has normally long completed - a host running further ahead than that waits here, with a full step still queued."""
+        while self.pending and self.pending[0][0] <= self.stamp - lag + 1:
+            stamp, host, ev = self.pending.pop(0)
+            ev.synchronize()
+            if int(host[0]) == stamp:        # that step found inf / nan: it was skipped on the device
+                self.skipped += 1
+                self.clean = 0
+                self.mult = max(self.mult * 0.5, self.min_mult)
+                eng.step_count = max(eng.step_count - 1, 0)
+            else:
+                self.clean += 1
+                if self.clean >= self.growth_interval and self.mult < self.max_mult:
+                    self.mult, self.clean = self.mult * 2.0, 0
+
+    def record(self):
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(self.guard[:1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((self.stamp, host, ev))
+
+    def drain(self, eng):
+        """Wait for every outstanding answer (end of an epoch / before a checkpoint / tests)."""
+        self.poll(eng, lag=0)
+
+
 class Engine:
     def __init__(self, cfg, device="cuda:0", max_batch=32, dtype="fp16", share=None):
         """dtype: 16-bit activation / weight-copy type, "fp16" (default: meets the 1e-3 logit / loss bound) or "bf16".
@@ -205,9 +251,10 @@ class Engine:
         self.f16 = dtype == "fp16"
         self.dtype = dtype
         self.tdt = torch.float16 if self.f16 else torch.bfloat16
-        self.gscale = LOSS_SCALE if self.f16 else 1.0
-        self.ginv = 1.0 / self.gscale
+        self._gbase = LOSS_SCALE if self.f16 else 1.0
         self.cfg, self.dev = cfg, torch.device(device)
+        # dynamic loss scale (fp16 only); engines that share parameters share it (stage 1: both passes of a step use one scale)
+        self.scaler = share.scaler if share is not None else LossScaler(self.dev, self.f16)
         self.step_count = 0
         self._n_alloc = 0
         if share is None:
@@ -224,6 +271,15 @@ class Engine:
         self.drop_calls = 0
         self._alloc_workspace(max_batch)
         self.comm = None             # set by dist.attach()
+
+    @property
+    def gscale(self):
+        """Loss scale of the 16-bit backward: LOSS_SCALE x (batch factor) x the dynamic multiplier (powers of two: exact)."""
+        return self._gbase * self.scaler.mult
+
+    @property
+    def ginv(self):
+        return 1.0 / self.gscale
 
     # ------------------------------------------------------------------ parameters
     def _groups(self):
@@ -427,8 +483,7 @@ class Engine:
             k = 0
             while (32 << k) < B and k < 5:
                 k += 1
-            self.gscale = LOSS_SCALE * (1 << k)
-            self.ginv = 1.0 / self.gscale
+            self._gbase = LOSS_SCALE * (1 << k)
         z = lambda *s, dt=bf: torch.zeros(s, device=dev, dtype=dt)
         f = lambda *s: torch.zeros(s, device=dev, dtype=torch.float32)
         Lr = _rup(L, 32)
@@ -1128,6 +1183,12 @@ class Engine:
         use 1e-6 for bert_model and 1e-5 for the rest).  amsgrad=False: plain Adam (Post-train_KD.ipynb cell 18).
         sync: a dist.GradSync with all-reduces in flight -- the update then runs bucket by bucket in completion order, each
         slice behind its own collective only (elementwise optimiser: the same bits as one launch over everything)."""
+        sc = self.scaler
+        guard, stamp = None, 0
+        if sc.enabled:
+            sc.poll(self)                    # overflows of steps two or more back: scale halved, Adam's count corrected
+            sc.stamp += 1
+            guard, stamp = sc.guard, sc.stamp
         self.step_count += 1
         head0 = self.off(PFX + ("attn.att_fc1.weight" if self.cfg.pooling == "att" else "dense.weight"))   # end of the BERT layers
         e = self.off(PFX + "dense.bias") + self.slot[PFX + "dense.bias"][2]
@@ -1137,11 +1198,24 @@ class Engine:
         ranges = [(0, self.n_train, lr)] if (lb == lr and lh == lr) else [(0, head0, lb), (head0, rest0, lh), (rest0, self.n_train, lr)]
         def launch(lo_, hi_, rate):
             if hi_ > lo_:
-                T.call("tnr_amsgrad_step", self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_],
-                       self.adam_v[lo_:hi_], self.adam_vmax[lo_:hi_] if amsgrad else None, hi_ - lo_, self.step_count, rate,
-                       beta1, beta2, eps, grad_scale)
+                args = (self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_], self.adam_v[lo_:hi_],
+                        self.adam_vmax[lo_:hi_] if amsgrad else None, hi_ - lo_, self.step_count, rate, beta1, beta2, eps, grad_scale)
+                if guard is None:
+                    T.call("tnr_amsgrad_step", *args)
+                else:
+                    T.call("tnr_amsgrad_step_guarded", *args, guard, stamp, sc.skipped)
 
-        if sync is not None and sync.pending:
+        if guard is not None:
+            # the WHOLE (reduced) gradient decides before any slice is updated - identically on every rank, since inf / nan
+            # survive the all-reduce; so under data parallelism every bucket is waited for first (the bucket-wise update below
+            # is the bf16 path)
+            if sync is not None:
+                sync.wait()
+            T.call("tnr_grad_nonfinite", self.flat_g, self.n_train, guard, stamp)
+            for lo_, hi_, rate in ranges:
+                launch(lo_, hi_, rate)
+            sc.record()
+        elif sync is not None and sync.pending:
             done = []
             for b, (s_, e_) in enumerate(sync.ranges):       # completion order of backward = launch order of the all-reduces
                 sync.wait_bucket(b)

@@ -150,9 +150,11 @@ def train(args):
             optimizer.step()
             if cnt % args.log_steps == 0:
                 d = max(cnt, 1)
-                logging.info("[{}] Ed: {}, train_loss: {:.5f}, acc: {:.5f}, {:.1f} impressions/s".format(
+                sc = eng.scaler          # fp16: steps whose 16-bit backward overflowed are skipped on the device (engine.LossScaler)
+                logging.info("[{}] Ed: {}, train_loss: {:.5f}, acc: {:.5f}, {:.1f} impressions/s{}".format(
                     rank, cnt * args.batch_size, loss_sum.item() / d, acc_sum.item() / d,
-                    size * cnt * args.batch_size / max(time.time() - t0, 1e-9)))
+                    size * cnt * args.batch_size / max(time.time() - t0, 1e-9),
+                    ", loss scale {:g}, {} steps skipped (fp16 overflow)".format(eng.gscale, sc.skipped) if sc.enabled and sc.skipped else ""))
         print(ep + 1)
         if rank == 0:                                                        # run.py:205-214
             os.makedirs(args.model_dir, exist_ok=True)
