@@ -91,24 +91,25 @@ def cpu_baseline(cfg_kw, seed):
         best = max(sweep, key=sweep.get)
         torch.set_num_threads(best)
         full = batch(B)
-        trn.step(*full)                                   # warm-up at the reported batch size
+        trn.step(*full)                                   # SURVEY 8-d / BASELINE.md section 3: 2 warm-up + 5 timed steps at the
+        trn.step(*full)                                   # reported batch size (fewer timed ones only if a slow host runs out of budget)
         n, t0 = 0, time.time()
-        while n < 3 and (n < 1 or time.time() - t_start < budget_s):
+        while n < 5 and (n < 1 or time.time() - t_start < budget_s):
             trn.step(*full)
             n += 1
         return B * n / (time.time() - t0), best, n, {str(k): round(x, 3) for k, x in sorted(sweep.items())}
 
     nl, tr, T_ = cfg_kw["n_layers"], cfg_kw["trainable_layers"], cfg_kw["num_teachers"]
-    v_head, th_head, n_head, sw_head = run(nl, tr, T_, 16, 75.0)
-    v_c0, th_c0, n_c0, sw_c0 = run(2, (0, 1), 0, 16, 45.0)
+    v_head, th_head, n_head, sw_head = run(nl, tr, T_, 16, 100.0)
+    v_c0, th_c0, n_c0, sw_c0 = run(2, (0, 1), 0, 16, 70.0)
     return {"value": round(v_head, 3), "unit": "impressions/s", "cores": int(th_head), "host_cores": int(cores), "cpu_model": model,
             "kind": "port", "threads_sweep": sw_head,
             "sample": "oracle/torch_port.py (torch-CPU port of the reference step: fwd + autograd bwd + Adam(amsgrad), fp32), same "
                       "%d-layer + %d-teacher model, B=16 impressions; threads swept over %s (1 warm-up + 1 timed step each at B=8), best = %d "
-                      "threads: 1 warm-up + %d timed steps at B=16" % (nl, T_, list(sw_head), th_head, n_head),
+                      "threads: 2 warm-up + %d timed steps at B=16 (SURVEY 8-d protocol)" % (nl, T_, list(sw_head), th_head, n_head),
             "configs0_plmnr_2layer_b16": {"value": round(v_c0, 3), "unit": "impressions/s", "cores": int(th_c0), "threads_sweep": sw_c0,
                                          "sample": "BASELINE configs[0]: PLM-NR 2-layer (train 0,1), B=16, fp32; same sweep, best = %d "
-                                                   "threads, 1 warm-up + %d timed steps" % (th_c0, n_c0)}}
+                                                   "threads, 2 warm-up + %d timed steps" % (th_c0, n_c0)}}
 
 
 def self_launch(a):
@@ -126,10 +127,6 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
-def lib_sha16():
-    import hashlib
-    with open(os.path.join(ROOT, "tiny-newsrec_amd", "csrc", "libtnr_hip.so"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def main():
@@ -146,6 +143,16 @@ def main():
                          "tolerance, bf16 does not -- DESIGN.md section 2)")
     ap.add_argument("--no-other-dtype", action="store_true", help="skip the extra timed loop in the other 16-bit type")
     ap.add_argument("--force-dp", action="store_true", help="run the RCCL broadcast / bucketed all-reduce path even at world size 1")
+    ap.add_argument("--wgrad-units", type=int, default=0,
+                    help="work units per workgroup of the weight-gradient kernel; 0 = 1 on one GPU, 2 under data parallelism (a "
+                         "workgroup kept off its CU by an overlapped collective then costs half a round, DESIGN.md: multi-GPU)")
+    ap.add_argument("--dp-buckets", type=int, choices=[5, 3], default=5,
+                    help="gradient collectives per step: 5 = heads + FFN / attention block of each trainable layer, 3 = heads + one per layer")
+    ap.add_argument("--dp-algo", choices=["allreduce", "rs_ag"], default="allreduce",
+                    help="one all-reduce per bucket, or reduce-scatter + all-gather (direct exchange on the xGMI mesh)")
+    ap.add_argument("--dp-sweep", action="store_true",
+                    help="data-parallel runs only: after the headline also time {wgrad units 1, 2} x {5, 3 buckets} x {allreduce, rs_ag} "
+                         "(30 steps each) and report them in the dp object")
     ap.add_argument("--dedup", choices=["off", "also", "only"], default="also",
                     help="in-batch news de-duplication (dedup.py): 'also' times it in a second loop and reports it beside "
                          "the headline (which stays un-deduplicated), 'only' makes it the headline")
@@ -155,6 +162,7 @@ def main():
     ap.add_argument("--gemm-opt", action="append", default=[], metavar="KEY=INT",
                     help="tools only: tnr_gemm_set_option(KEY, INT) before the run (A/B profiles; the default is the shipped configuration)")
     ap.add_argument("--no-larger-batch", action="store_true", help="skip the extra timed loop at 4 x the per-GPU batch")
+    ap.add_argument("--no-configs", action="store_true", help="skip the timed legs of the other BASELINE.json configurations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -186,6 +194,8 @@ def main():
     seed = 1234
     B, K, W = a.batch, a.steps, a.warmup
     use_dp = world > 1 or a.force_dp
+    wgrad_units = a.wgrad_units or (2 if use_dp else 1)
+    E.Engine.WGRAD_UNITS = wgrad_units           # before any engine is built: the slab workspace is sized by it
     comb = torch.from_numpy(synth.news_table(seed, N_NEWS, cfg.L)).to(dev)
     tables = torch.from_numpy(synth.teacher_tables(seed, max(a.teachers, 1), N_NEWS, cfg.D)).to(dev)
     hidx, mask, cidx, label = [torch.from_numpy(x).to(dev) for x in
@@ -205,7 +215,8 @@ def main():
         eng.load_state_dict(init_sd)
         D.broadcast_flat([eng.flat[True], eng.flat[False]], force=a.force_dp)
         eng.refresh_shadows(all_layers=True)
-        return eng, D.GradSync(eng.flat_g, eng.bucket_ranges(), world, force=a.force_dp, timing=use_dp)
+        return eng, D.GradSync(eng.flat_g, eng.bucket_ranges(), world, force=a.force_dp, timing=use_dp,
+                               merge_layers=a.dp_buckets == 3, algo=a.dp_algo)
 
     def reset(eng):
         eng.load_state_dict(init_sd)                 # same start; also drops the frozen-layer cache
@@ -269,13 +280,48 @@ def main():
         ex = gs.exposed_ms()
         per_bucket = [round(sum(ex.get(b, [0.0])) / max(len(ex.get(b, [])), 1), 4) for b in range(len(gs.ranges))]
         tot = torch.tensor([sum(per_bucket)], device=dev, dtype=torch.float64)
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
         dp_info = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                   "rccl_version": rccl, "algo": gs.algo, "wgrad_units_per_workgroup": wgrad_units,
+                   "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                          "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY")},
+                   "collectives_mb_in_launch_order": [round(x / 1e6, 2) for x in gs.collective_bytes()],
                    "bucket_mb_in_completion_order": [round(x / 1e6, 2) for x in gs.bucket_bytes()],
                    "exposed_allreduce_ms_per_step_by_bucket_rank0": per_bucket,
                    "exposed_allreduce_ms_per_step_max_over_ranks": round(float(D.all_reduce_max(tot).item()), 4),
                    "note": "all-reduce(sum) of fp32 gradients, 1/world folded into AMSGrad; every bucket but the last is launched "
                            "while backward still runs"}
     loss = float(eng.total_loss().item())
+    if use_dp and a.dp_sweep:
+        # the knobs the first multi-GPU run should weigh, each as its own 5 + 30 steps (max over ranks), headline configuration first
+        sweep = []
+        K_, W_ = K, W
+        for units in (1, 2):
+            for nb in (5, 3):
+                for algo in ("allreduce", "rs_ag"):
+                    try:
+                        eng = gs = None
+                        torch.cuda.empty_cache()
+                        E.Engine.WGRAD_UNITS = units
+                        e_ = E.Engine(cfg, dev, max_batch=B, dtype=a.dtype)
+                        e_.load_state_dict(init_sd)
+                        e_.refresh_shadows(all_layers=True)
+                        g_ = D.GradSync(e_.flat_g, e_.bucket_ranges(), world, force=a.force_dp, timing=True, merge_layers=nb == 3, algo=algo)
+                        K, W = min(30, K_), min(5, W_)
+                        d_ = timed_loop(e_, g_, False)
+                        ex_ = g_.exposed_ms()
+                        sweep.append({"wgrad_units": units, "buckets": nb, "algo": g_.algo, "ms_per_step": round(1e3 * d_ / K, 4),
+                                      "value": round(world * B * K / d_, 2),
+                                      "exposed_allreduce_ms_per_step_rank0": round(sum(sum(v) for v in ex_.values()) / K, 4)})
+                        del e_, g_
+                    except Exception as ex:
+                        sweep.append({"wgrad_units": units, "buckets": nb, "algo": algo, "error": repr(ex)[:200]})
+        K, W = K_, W_
+        E.Engine.WGRAD_UNITS = wgrad_units
+        dp_info["sweep"] = sweep
     routes = {}
     if rec:
         for _, _, w, shape in rec:
@@ -331,6 +377,91 @@ def main():
             T.TIMED.pop(TKEY, None)
             bigger = {"error": repr(ex)[:300]}
 
+    # The other BASELINE.json configurations, each on its own shapes (never `value`): configs[1] PLM-NR 12-layer fine-tune (train
+    # 10-11, bf16; PLM-NR/demo.sh:3-22), configs[2] 4-layer student + ONE teacher, configs[4] 2-layer student + 4 teachers in fp16
+    # (Tiny-NewsRec/demo.sh:3-36) and its stage-1 form, titles of 30 / bodies of 128 tokens, 1 + 4 titles per body
+    # (Post-train_KD.ipynb cell 4 with BASELINE's lengths).  B = 32 per GPU, 3 warm-up + 20 timed steps each, one GPU.
+    legs = None
+    if world == 1 and not a.no_configs and a.dedup != "only":
+        legs = {}
+        eng = gs = None
+        torch.cuda.empty_cache()
+
+        def stage2_leg(key, nl, tr, T_, dtype, what):
+            try:
+                c2 = E.EngineConfig(n_layers=nl, trainable_layers=tr, num_teachers=T_)
+                e2 = E.Engine(c2, dev, max_batch=B, dtype=dtype)
+                e2.load_state_dict(hashinit.init_state_dict(seed, state_shapes(FULL, nl, c2.D, T_)))
+                e2.refresh_shadows(all_layers=True)
+                W2, K2 = 3, 20
+
+                def st(i):
+                    s2 = slice(i * B, (i + 1) * B)
+                    e2.forward_indexed(comb, hidx[s2], mask[s2], cidx[s2], label[s2], tables[:T_] if T_ else None)
+                    e2.backward()
+                    e2.step(lr=1e-4)
+                for i in range(W2):
+                    st(i)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for i in range(W2, W2 + K2):
+                    st(i)
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t2
+                f2 = flops_per_impression(nl, len(tr))
+                legs[key] = {"workload": what, "dtype": dtype, "batch_per_gpu": B, "steps": K2, "value": round(B * K2 / d2, 2),
+                             "unit": "impressions/s", "ms_per_step": round(1e3 * d2 / K2, 4), "model_flops_per_impression": f2,
+                             "mfma_frac_whole_step": round(f2 * B * K2 / d2 / PEAK_BF16, 4), "final_loss": round(float(e2.total_loss().item()), 5)}
+                del e2
+            except Exception as ex:                  # an informational leg must never cost the headline line
+                legs[key] = {"workload": what, "error": repr(ex)[:300]}
+            torch.cuda.empty_cache()
+
+        stage2_leg("configs[1]", 12, (10, 11), 0, "bf16", "PLM-NR 12-layer UniLM teacher fine-tune (train [10, 11]), CE, two-rate AMSGrad path")
+        stage2_leg("configs[2]", 4, (2, 3), 1, a.dtype, "Tiny-NewsRec 4-layer student (train [2, 3]) + 1-teacher KD")
+        stage2_leg("configs[4]", 2, (0, 1), 4, "fp16", "Tiny-NewsRec 2-layer student (train [0, 1]) + 4-teacher KD")
+        try:
+            from stage1 import Stage1Engine
+            Lt, Lb, Kn, nd = 30, 128, 4, 20000
+            s1 = Stage1Engine(n_layers=2, trainable_layers=(0, 1), num_teachers=4, npratio=Kn, title_len=Lt, body_len=Lb, device=dev,
+                              batch=B, dtype="fp16")
+            s1.load_state_dict({k: torch.from_numpy(hashinit.init_tensor(seed, k, tuple(sh))) for k, sh in s1.shapes.items()})
+            s1.title.refresh_shadows(all_layers=True)
+            s1.body.refresh_rel()
+            d_title = torch.from_numpy(synth.news_table(11, nd - 1, Lt)).to(dev)
+            d_body = torch.from_numpy(synth.news_table(12, nd - 1, Lb, mean_len=0.6 * Lb, std_len=0.25 * Lb)).to(dev)
+            d_tt = torch.from_numpy(np.ascontiguousarray(synth.teacher_tables(13, 4, nd - 1, s1.cfg_t.D))).to(dev)
+            d_tb = torch.from_numpy(np.ascontiguousarray(synth.teacher_tables(14, 4, nd - 1, s1.cfg_t.D))).to(dev)
+            W2, K2 = 3, 20
+            rs = np.random.RandomState(seed)
+            pidx = torch.from_numpy(rs.randint(1, nd, ((W2 + K2) * B, 1 + Kn)).astype(np.int32)).to(dev)
+            lab1 = torch.zeros(B, dtype=torch.int64, device=dev)
+
+            def st1(i):
+                s1.forward_indexed(d_title, d_body, pidx[i * B:(i + 1) * B], lab1, d_tt, d_tb)
+                s1.backward()
+                s1.step(1e-5, lr_bert=1e-6, amsgrad=False)
+            for i in range(W2):
+                st1(i)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(W2, W2 + K2):
+                st1(i)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t2
+            H_ = 768
+            ftok = lambda L_: 24 * H_ * H_ + 4 * L_ * H_
+            f1 = (ftok(Lt) * (1 + Kn) * Lt + ftok(Lb) * Lb) * (2 + 2 * 2) + 0.2e9      # per (body, 1 + 4 titles) pair group, 2 layers both trainable
+            legs["configs[4] stage 1"] = {"workload": "Post-train_KD stage 1: 2-layer student + 4 teachers, 1 + 4 titles of 30 / body of 128 tokens, plain two-rate Adam",
+                                          "dtype": "fp16", "batch_per_gpu": B, "steps": K2, "value": round(B * K2 / d2, 2), "unit": "pairs/s",
+                                          "ms_per_step": round(1e3 * d2 / K2, 4), "model_flops_per_pair": f1,
+                                          "mfma_frac_whole_step": round(f1 * B * K2 / d2 / PEAK_BF16, 4),
+                                          "final_loss": round(float(s1.total_loss().item()), 5)}
+            del s1
+        except Exception as ex:
+            legs["configs[4] stage 1"] = {"error": repr(ex)[:300]}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         value = world * B * K / dt
         fpi = flops_per_impression(a.layers, len(trainable))
@@ -351,13 +482,13 @@ def main():
             ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
             fl = sum(w for _, _, w, _ in rec)
             ach = fl / (ms * 1e-3) / 1e12
-            # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (tools/pmc.sh); it is only quoted while
-            # the profiled library is byte-identical to the one running now
+            # HBM traffic per launch comes from a separate rocprofv3 --pmc pass (tools/make_profiles.sh); it is only quoted
+            # while the library's SOURCES are the ones that were profiled (tnr_hip.source_sha16: a rebuild does not break the link)
             traffic, busy = None, None
             import glob
             for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_nt_pmc.json")), reverse=True):
                 pm = json.load(open(pj))
-                if pm.get("lib_sha16") == lib_sha16() and pm.get("dtype") == a.dtype:
+                if pm.get("src_sha16") == T.source_sha16() and pm.get("dtype") == a.dtype:
                     traffic = pm.get("hbm_bytes_per_launch")
                     busy = pm.get("mfma_busy_frac")          # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE): SURVEY 8-d's "MFMA utilisation"
                     break
@@ -379,6 +510,8 @@ def main():
             out["other_dtype"] = other
         if bigger is not None:
             out["larger_batch"] = bigger
+        if legs:
+            out["configs"] = legs
         if a.dedup != "off":
             out["dedup"] = {"in_headline": a.dedup == "only", "frozen_layer_cache_in_headline": bool(a.dedup == "only" and a.frozen_cache), "distinct_news_frac": round(distinct, 4),
                             "encoded_frac": round(encoded, 4),

@@ -250,6 +250,10 @@ typedef struct tnr_sgemm_problem {
 } tnr_sgemm_problem_t;
 int tnr_sgemm_group(const tnr_sgemm_problem_t* problems, int n, void* stream);
 
+/* out = [a (na) | b (nb)]: the step's news indices as one array - history slots (B*U) then candidate slots (B*C), the row
+ * order of the encoder pass (dataloader.py:129-138 at index level; replaces a torch.cat inside the step) */
+int tnr_concat_i32(const int32_t* a, int64_t na, const int32_t* b, int64_t nb, int32_t* out, void* stream);
+
 /* out[z, out_row0 + r, :] = tbl[z, idx[r], :]  (dataloader.py:140-144 teacher-embedding gather, done on
  * device from resident tables instead of on the host) */
 int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, int64_t n_idx, int D, int n_model,

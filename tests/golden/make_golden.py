@@ -32,11 +32,14 @@ TINY_ARGS = dict(news_dim=32, news_query_vector_dim=16, user_query_vector_dim=16
                  npratio=2, num_words_title=10)
 
 
-def fill(model, seed):
+def fill(model, seed, stats=None):
     sd = model.state_dict()
+    W = {k: hashinit.init_tensor(seed, k, tuple(v.shape)) for k, v in sd.items()}
+    if stats == "pretrained_like":
+        hashinit.pretrained_like(W, seed)
     with torch.no_grad():
         for k, v in sd.items():
-            v.copy_(torch.from_numpy(hashinit.init_tensor(seed, k, tuple(v.shape))))
+            v.copy_(torch.from_numpy(W[k]))
     return {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
 
 
@@ -71,11 +74,11 @@ def grad_samples(seed, name, g, k=64):
     return idx, flat[idx]
 
 
-def run_model(R, cfg_json, args_over, trainable, seed, B, T, full_grads):
+def run_model(R, cfg_json, args_over, trainable, seed, B, T, full_grads, stats=None):
     a = ref_shim.make_args(config_name=ref_shim.write_config(cfg_json), num_teachers=T, batch_size=B,
                            **args_over)
     model = R.model_bert.Model(a)
-    P = fill(model, seed)
+    P = fill(model, seed, stats)
     # run.py:101-112 freeze policy
     for p in model.teachers.parameters():
         p.requires_grad = False
@@ -126,6 +129,9 @@ def run_model(R, cfg_json, args_over, trainable, seed, B, T, full_grads):
     rec["trainable"] = np.array(sorted(trainable))
     rec["flags"] = np.array([float(a.user_log_mask), a.temperature, a.coef])
     rec["variant"] = np.array([a.pooling, a.model, str(a.num_attention_heads if a.model == "NRMS" else 0)])
+    if stats:
+        rec["stats"] = np.array([stats])
+        rec["hidden_absmax"] = np.array([float(np.abs(h).max()) for h in hidden])
     return rec, P
 
 
@@ -242,6 +248,7 @@ def main():
     golden_plmnr()
     golden_stage0(R)
     golden_configs(R)
+    golden_pretrained_like(R)
 
 
 def golden_configs(R):
@@ -255,6 +262,17 @@ def golden_configs(R):
     np.savez_compressed(os.path.join(HERE, "full_model_5.npz"), **rec)
     print("full 5 (configs[4] stage 2)", rec["total"], rec["distill"], rec["emb"], rec["target"])
     golden_stage1(R, only=("cfg4",))
+
+
+def golden_pretrained_like(R):
+    """The headline model (4 layers, train 2-3, 4 teachers) on weights with a pretrained checkpoint's statistics
+    (hashinit.pretrained_like: LayerNorm gamma outliers x 12 ... 30, large embedding rows, |h| ~ 100): what the fp16 build's 16-bit
+    activations and loss-scaled backward have to hold up on."""
+    cfg = dict(ref_shim.BASE_CFG, num_hidden_layers=4)
+    rec, _ = run_model(R, cfg, dict(num_student_layers=4, user_log_mask=False, temperature=1.0, coef=0.2), (2, 3), seed=25,
+                       B=2, T=4, full_grads=False, stats="pretrained_like")
+    np.savez_compressed(os.path.join(HERE, "full_model_6.npz"), **rec)
+    print("full 6 (pretrained-like statistics)", rec["total"], rec["distill"], rec["emb"], rec["target"], "hidden |max|", rec["hidden_absmax"])
 
 
 def golden_variants(R):

@@ -27,6 +27,8 @@ def load_case(name):
     dims = TINY if name.startswith("tiny") else FULL
     pooling, model, nh = [str(x) for x in z["variant"]] if "variant" in z.files else ("att", "NAML", "0")
     P = hashinit.init_state_dict(seed, state_shapes(dims, nl, D, T, pooling, int(nh)))
+    if "stats" in z.files and str(z["stats"][0]) == "pretrained_like":
+        hashinit.pretrained_like(P, seed)
     ulm, tau, coef = [float(x) for x in z["flags"]]
     cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]],
                user_log_mask=bool(ulm), temperature=tau, coef=coef, pooling=pooling, nrms_heads=int(nh))

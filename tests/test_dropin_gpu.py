@@ -79,13 +79,22 @@ def test_bench_dp_path_under_torchrun_single_rank():
     process group, the flat broadcast and the overlapped bucketed all-reduce + scaled AMSGrad all execute."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--force-dp"]
+           "--no-cpu-baseline", "--force-dp", "--dp-sweep", "--no-configs"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
     assert d["larger_batch"]["batch_per_gpu"] == 128 and d["larger_batch"]["value"] > 0      # the informational 4 x batch leg
+    # the data-parallel leg explains itself (what the first multi-GPU run needs to be read): defaults under data parallelism,
+    # library version, the environment knobs RCCL reads, and the sweep over the knobs the build exposes
+    dp = d["dp"]
+    assert dp["backend"] == "nccl" and dp["wgrad_units_per_workgroup"] == 2 and dp["algo"] == "allreduce"
+    assert dp["rccl_version"] and set(dp["env"]) >= {"NCCL_ALGO", "NCCL_PROTO"}
+    assert len(dp["bucket_mb_in_completion_order"]) == 5 and len(dp["collectives_mb_in_launch_order"]) == 5
+    sw = dp["sweep"]
+    assert len(sw) == 8 and all("error" not in x and x["value"] > 0 for x in sw), sw
+    assert {(x["wgrad_units"], x["buckets"], x["algo"]) for x in sw} == {(u, b, g) for u in (1, 2) for b in (5, 3) for g in ("allreduce", "rs_ag")}
 
 
 def test_construction_time_init_and_pretrained_import(tmp_path):

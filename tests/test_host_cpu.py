@@ -144,6 +144,20 @@ def _sync_worker(rank, world, port, q):
     gs.wait_bucket(0)
     gs.wait()
     assert not gs.pending
+    # one collective per trainable layer (merge_layers): buckets [heads | FFN, attention of layer 1 | FFN, attention of layer 0];
+    # a layer's collective starts when BOTH its buckets have been handed over, and waiting for either waits for it
+    flat2 = torch.arange(1000, dtype=torch.float32) * (r + 1)
+    g2 = dist.GradSync(flat2, [(900, 1000), (700, 900), (500, 700), (250, 500), (0, 250)], w, merge_layers=True, algo="rs_ag")
+    assert g2.groups == [[0], [1, 2], [3, 4]] and g2.group_range == [(900, 1000), (500, 900), (0, 500)] and g2.algo == "allreduce"   # gloo: no rs_ag
+    g2.launch(0); g2.launch(1)
+    assert sorted(g2.pending) == [0]
+    g2.launch(2); g2.launch(3); g2.launch(4)
+    assert sorted(g2.pending) == [0, 1, 2]
+    g2.wait_bucket(2)
+    assert torch.equal(flat2[500:900], torch.arange(500, 900, dtype=torch.float32) * 3) and sorted(g2.pending) == [0, 2]
+    g2.wait_bucket(1)
+    g2.wait()
+    assert not g2.pending and torch.equal(flat2, torch.arange(1000, dtype=torch.float32) * 3)
     p = torch.full((10,), float(r))
     dist.broadcast_flat([p])
     dist.barrier()

@@ -1069,6 +1069,21 @@ extern "C" int tnr_sgemm_group(const tnr_sgemm_problem_t* p, int n, void* stream
     return TNR_OK;
 }
 
+// out = [a (na) | b (nb)] int32: the step's news indices, history slots then candidate slots (dataloader.py:129-138 at index level)
+__global__ __launch_bounds__(256) void concat_i32_kernel(const int32_t* __restrict__ a, int64_t na, const int32_t* __restrict__ b,
+                                                         int64_t nb, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) out[i] = a[i];
+    else if (i < na + nb) out[i] = b[i - na];
+}
+
+extern "C" int tnr_concat_i32(const int32_t* a, int64_t na, const int32_t* b, int64_t nb, int32_t* out, void* stream) {
+    TNR_CHECK_ARG(out && na >= 0 && nb >= 0 && na + nb >= 1 && (a || na == 0) && (b || nb == 0), "tnr_concat_i32: bad argument");
+    hipLaunchKernelGGL(concat_i32_kernel, dim3((unsigned)((na + nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, out);
+    TNR_CHECK_LAUNCH("tnr_concat_i32");
+    return TNR_OK;
+}
+
 extern "C" int tnr_gather_rows(const float* tbl, int64_t R, const int32_t* idx, int64_t n_idx, int D, int n_model,
                                float* out, int64_t out_rows, int64_t out_row0, void* stream) {
     TNR_CHECK_ARG(tbl && idx && out && n_idx >= 1 && (D % 4) == 0 && n_model >= 1, "tnr_gather_rows: bad argument");

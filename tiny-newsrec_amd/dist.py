@@ -40,25 +40,67 @@ class GradSync:
     timing = True: wait_bucket brackets its wait with events on the current stream; exposed_ms() = the time the compute stream
     actually stood still behind collectives (what overlap did not hide), per bucket, since the last call."""
 
-    def __init__(self, flat_g, ranges, world, force=False, timing=False):
+    def __init__(self, flat_g, ranges, world, force=False, timing=False, merge_layers=False, algo="allreduce"):
+        """merge_layers: one collective per trainable layer (its FFN and attention buckets together: 3 collectives of 2.8 / 28 /
+        28 MB instead of 5 for the headline model) - fewer, larger messages; the layer's collective then starts when its
+        attention block is complete.  algo: "allreduce" (one all-reduce per collective; RCCL picks ring / tree by NCCL_ALGO) or
+        "rs_ag" (reduce-scatter into this rank's 1 / world shard, then all-gather: on a fully connected xGMI mesh every rank
+        exchanges directly with every other; nccl backend only, falls back to all-reduce elsewhere).  Both are knobs for the
+        first multi-GPU run (bench.py --dp-sweep); results are the same sums."""
         self.flat_g, self.ranges, self.world = flat_g, list(ranges), world
         self.force = force and dist.is_initialized()      # exercise the collective path even with one rank
-        self.pending = {}                                 # bucket -> (work handle, pinned host mirror or None)
+        self.pending = {}                                 # collective -> (work handle, pinned host mirror or None)
         self.host_staged = dist.is_initialized() and dist.get_backend() == "gloo" and flat_g.is_cuda
         self._mirror = {}
         self.timing = timing and flat_g.is_cuda
         self._events = []                                 # (bucket, start event, end event)
+        # buckets (the engine's units of completion) -> collectives
+        n = len(self.ranges)
+        if merge_layers and n >= 3 and (n - 1) % 2 == 0:
+            self.groups = [[0]] + [[b, b + 1] for b in range(1, n, 2)]
+        else:
+            self.groups = [[b] for b in range(n)]
+        self.group_of = {b: g for g, mem in enumerate(self.groups) for b in mem}
+        self.group_range = []
+        for mem in self.groups:
+            s_, e_ = min(self.ranges[b][0] for b in mem), max(self.ranges[b][1] for b in mem)
+            assert sum(self.ranges[b][1] - self.ranges[b][0] for b in mem) == e_ - s_, "merged gradient buckets must be adjacent"
+            self.group_range.append((s_, e_))
+        self._arrived = {}
+        self.algo = algo if (dist.is_initialized() and dist.get_backend() == "nccl") else "allreduce"
+        self._shard = {}
 
     def bucket_bytes(self):
         return [4 * (e - s) for s, e in self.ranges]
 
+    def collective_bytes(self):
+        return [4 * (e - s) for s, e in self.group_range]
+
+    def _collective(self, t):
+        """sum over ranks of the flat slice t, in place, asynchronously -> work handle"""
+        if self.algo == "rs_ag" and t.numel() % max(self.world, 1) == 0:
+            w = max(self.world, 1)
+            k = t.numel() // w
+            shard = self._shard.get(k)
+            if shard is None:
+                shard = self._shard[k] = torch.empty(k, dtype=t.dtype, device=t.device)
+            dist.reduce_scatter_tensor(shard, t, op=dist.ReduceOp.SUM, async_op=True)
+            return dist.all_gather_into_tensor(t, shard, async_op=True)      # same communicator stream: ordered behind the scatter
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
     def launch(self, bucket):
         if self.world == 1 and not self.force:
             return
-        s, e = self.ranges[bucket]
+        g = self.group_of[bucket]
+        self._arrived[g] = self._arrived.get(g, 0) + 1
+        if self._arrived[g] < len(self.groups[g]):
+            return                                        # the layer's other bucket is still being written
+        self._arrived[g] = 0
+        bucket = g
+        s, e = self.group_range[g]
         if self.host_staged:
             h = self._mirror.get(bucket)
-            if h is None:
+            if h is None or h.numel() != e - s:
                 h = self._mirror[bucket] = torch.empty(e - s, dtype=self.flat_g.dtype, pin_memory=True)
             h.copy_(self.flat_g[s:e], non_blocking=True)  # stream-ordered behind the kernels that wrote the bucket
             ev = torch.cuda.Event()
@@ -66,10 +108,12 @@ class GradSync:
             ev.synchronize()
             self.pending[bucket] = (dist.all_reduce(h, op=dist.ReduceOp.SUM, async_op=True), h)
             return
-        self.pending[bucket] = (dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True), None)
+        self.pending[bucket] = (self._collective(self.flat_g[s:e]), None)
 
     def wait_bucket(self, bucket):
-        """Make the current stream wait for bucket's all-reduce (no-op when it was not launched)."""
+        """Make the current stream wait for the collective that carries `bucket` (no-op when it was not launched or has been
+        waited for already through another bucket of the same collective)."""
+        bucket = self.group_of[bucket]
         w = self.pending.pop(bucket, None)
         if w is None:
             return
@@ -79,15 +123,15 @@ class GradSync:
             e0.record()
         work.wait()
         if h is not None:
-            s, e = self.ranges[bucket]
+            s, e = self.group_range[bucket]
             self.flat_g[s:e].copy_(h, non_blocking=True)
         if self.timing:
             e1.record()
             self._events.append((bucket, e0, e1))
 
     def wait(self):
-        for b in list(self.pending):
-            self.wait_bucket(b)
+        for g in list(self.pending):
+            self.wait_bucket(self.groups[g][0])
 
     def exposed_ms(self):
         """-> {bucket: [ms, ...]} of the waits recorded since the last call (synchronises the device)."""

@@ -489,6 +489,7 @@ class Engine:
         Lr = _rup(L, 32)
         self.Lr = Lr
         self.tok = torch.zeros((N, 2 * L), device=dev, dtype=torch.int64)
+        self.nidx_buf = torch.zeros(N, device=dev, dtype=torch.int32)
         self.mask_add = f(N, Lr)
         self.rel = f(cfg.A, Lr, Lr)
         self.lse = f(N, cfg.A, Lr) if L > 32 else None        # long-sequence attention keeps the softmax statistics
@@ -848,7 +849,12 @@ class Engine:
         self.label = label.to(torch.int64).contiguous()
         idx = None
         if news_combined is not None or teacher_tables is not None:
-            idx = torch.cat([t_hidx.reshape(-1), t_cidx.reshape(-1)]).to(torch.int32)
+            if (t_hidx.dtype == torch.int32 and t_cidx.dtype == torch.int32 and t_hidx.is_contiguous() and t_cidx.is_contiguous()
+                    and t_hidx.device == self.dev):
+                idx = self.nidx_buf[:N]                  # no ATen kernel inside the step
+                T.call("tnr_concat_i32", t_hidx, B * U, t_cidx, B * C, idx)
+            else:
+                idx = torch.cat([t_hidx.reshape(-1), t_cidx.reshape(-1)]).to(device=self.dev, dtype=torch.int32)
         self.nidx = idx
         # teacher side (frozen user encoders over the teachers' rows, projection by the transform matrices): independent of
         # the student's encoder pass; issued first (optionally on a second stream, TNR_TEACHER_STREAM=1)

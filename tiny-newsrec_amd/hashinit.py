@@ -104,3 +104,28 @@ def init_tensor(seed, name, shape):
 def init_state_dict(seed, shapes):
     """shapes: {key: tuple} -> {key: fp32 ndarray}."""
     return {k: init_tensor(seed, k, tuple(s)) for k, s in shapes.items()}
+
+
+def pretrained_like(sd, seed):
+    """Give a hash-initialised state dict (in place, returned) the statistics a PRETRAINED UniLM / BERT checkpoint has and a
+    std-0.02 random init lacks - the ones that decide whether 16-bit activations and a loss-scaled 16-bit backward hold up on real
+    weights (unilm2-base-uncased.bin itself is not available offline): a few LayerNorm channels with gamma 12 ... 30 x the rest
+    (and one nearly switched off), shifted beta on the same channels, a handful of embedding rows 6 x larger than the others,
+    two FFN output-bias channels far off zero - hidden states reach |h| ~ 100 in the outlier channels, as in published
+    checkpoints.  Pure function of (seed, key): the golden harness (tests/golden/make_golden.py) applies it to the reference
+    model's weights, tests/helpers.py to the build's."""
+    for k in sorted(sd):
+        v = sd[k]
+        if k.endswith("LayerNorm.weight") or k.endswith("LayerNorm.bias"):
+            ch = hash_randint(seed, "outlier." + k.rsplit(".", 1)[0], (4,), 0, v.shape[0])
+            if k.endswith("weight"):
+                v[ch] = v[ch] * np.array([12.0, 20.0, 30.0, 0.05], np.float32)
+            else:
+                v[ch] = v[ch] + np.array([1.5, -2.0, 0.0, 0.0], np.float32)
+        elif k.endswith("word_embeddings.weight"):
+            rows = hash_randint(seed, "outlier." + k, (16,), 1, v.shape[0])
+            v[rows] = v[rows] * np.float32(6.0)
+        elif k.endswith("output.dense.bias") and ".attention." not in k:
+            ch = hash_randint(seed, "outlier." + k, (2,), 0, v.shape[0])
+            v[ch] = v[ch] + np.array([3.0, -3.0], np.float32)
+    return sd

@@ -168,6 +168,9 @@ def train(args):
         title_tab = token_table([t.lower() for t in titles], encode, args.max_title_len)
         body_tab = token_table([t.lower() for t in bodies], encode, args.max_body_len)
         tt, tb = load_teacher_tables(args, n_docs) if args.num_teachers else (np.zeros((1, 1, args.news_dim), np.float32),) * 2
+    if size > 1:
+        import engine as E
+        E.Engine.WGRAD_UNITS = 2             # see run.py: weight-gradient units beside an overlapped all-reduce
     eng = Stage1Engine(n_layers=args.num_hidden_layers, trainable_layers=[l for l in args.bert_trainable_layer if l < args.num_hidden_layers],
                        num_teachers=args.num_teachers, npratio=args.npratio, title_len=args.max_title_len,
                        body_len=args.max_body_len, device=dev, batch=args.batch_size, dtype=args.dtype, **_model_dims(args))

@@ -44,6 +44,11 @@ def train(args):
     # key names, and -- with --use_pretrain_model -- its two learning rates (PLM-NR/run.py:56-106).  Tiny-NewsRec's own
     # Model cannot be built without teachers, so the flag value is free for this.
     plmnr = args.num_teachers == 0
+    if size > 1:
+        # beside the CUs an overlapped gradient all-reduce holds, a late workgroup of the weight-gradient kernel costs one work
+        # unit: two units per workgroup halve that (engine.Engine.WGRAD_UNITS; set before the engine sizes its slab workspace)
+        import engine as E
+        E.Engine.WGRAD_UNITS = 2
     model = ModelBert(args) if plmnr else Model(args)
     eng = model.engine
     sd = model.state_dict()

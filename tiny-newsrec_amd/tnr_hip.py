@@ -69,6 +69,22 @@ def wgrad_group(problems, f16=False):
         raise TnrError("%s failed (%d): %s" % (name, rc, lib().tnr_last_error().decode()))
 
 
+def source_sha16():
+    """Hash of the library's SOURCES (csrc/*.hip, *.h, *.cpp, the Makefile, include/tnr_hip.h): what ties a committed rocprofv3 PMC
+    summary (profiles/*_pmc.json) to the library bench.py is running - a rebuild of unchanged sources gives another binary hash
+    (round 3 review) but the same kernels."""
+    import glob, hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h")) +
+                   glob.glob(os.path.join(here, "csrc", "*.cpp")) + [os.path.join(here, "csrc", "Makefile"),
+                                                                     os.path.join(os.path.dirname(here), "include", "tnr_hip.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 # name -> argument types (return type int unless listed in _RET)
 _SIG = {
     "tnr_version": [],
@@ -103,6 +119,7 @@ _SIG = {
     "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _I, _P, _P],
     "tnr_sgemm_group": [_c.POINTER(SgemmProblem), _I, _P],
     "tnr_gemm_tn_wgrad_group": [_c.POINTER(WgradProblem), _I, _P],
+    "tnr_concat_i32": [_P, _L, _P, _L, _P, _P],
     "tnr_gather_rows": [_P, _L, _P, _L, _I, _I, _P, _L, _L, _P],
     "tnr_segment_sum_rows": [_P, _P, _P, _L, _I, _P, _P],
     "tnr_user_score_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -4,8 +4,9 @@ import collections, csv, glob, json, os, re, sys
 raw, out = "gpurun_out/profiles_raw", "profiles"
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 dtype = sys.argv[2] if len(sys.argv) > 2 else "fp16"
-import hashlib
-lib_sha16 = hashlib.sha256(open("tiny-newsrec_amd/csrc/libtnr_hip.so", "rb").read()).hexdigest()[:16]
+sys.path.insert(0, "tiny-newsrec_amd")
+import tnr_hip
+src_sha16 = tnr_hip.source_sha16()         # ties the summary to the library SOURCES (a rebuild changes the binary hash, not this)
 def short(n):
     m = re.search(r"([A-Za-z_0-9]+_kernel)", n)
     return m.group(1) if m else n.split("(")[0][-50:]
@@ -31,7 +32,7 @@ c = {k: sum(v) / len(v) for k, v in agg[dom].items()}
 dom_rows = [r for r in rows if short(r["Name"]) == dom]      # the <MI=8> and <MI=7> instantiations of the one kernel
 dom_calls = sum(int(r["Calls"]) for r in dom_rows)
 dom_ns = sum(float(r["TotalDurationNs"]) for r in dom_rows)
-res = {"lib_sha16": lib_sha16, "dtype": dtype, "kernel": dom + " (all template instantiations; = every tnr_gemm_nt launch bench.py times)",
+res = {"src_sha16": src_sha16, "dtype": dtype, "kernel": dom + " (all template instantiations; = every tnr_gemm_nt launch bench.py times)",
        "avg_launch_us_trace": dom_ns / dom_calls / 1e3, "launches_in_trace": dom_calls,
        "counters_mean_per_launch": c,
        # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads exactly 1/2 of wide
@@ -70,7 +71,7 @@ for k in ("gemm_tn_pp_kernel", "slab_reduce_kernel", "attn_fwd_kernel", "attn_bw
                  "mfma_busy_frac": round(ck.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(ck.get("GRBM_GUI_ACTIVE", 1) / 8 * 1024, 1), 3),
                  "lds_bank_conflict_cycles": round(ck.get("SQ_LDS_BANK_CONFLICT", 0)),
                  "fetch_calibrated": k not in ("attn_fwd_kernel", "attn_bwd_kernel")}
-json.dump({"lib_sha16": lib_sha16, "dtype": dtype, "kernels": others}, open("%s/%s_other_kernels_pmc.json" % (out, tag), "w"), indent=1)
+json.dump({"src_sha16": src_sha16, "dtype": dtype, "kernels": others}, open("%s/%s_other_kernels_pmc.json" % (out, tag), "w"), indent=1)
 for k, v in others.items():
     print("%-24s %8.1f us x %4.1f  %7.1f MB  %5.2f TB/s  L2 hit %.2f  MFMA busy %.2f" % (k, v["avg_launch_us_trace"], v["launches_per_step"],
           v["fabric_bytes_per_launch"] / 1e6, v["tb_per_s"], v["l2_hit_rate"], v["mfma_busy_frac"]))
