@@ -111,6 +111,41 @@ def test_stream_covers_every_line_once_with_short_last_batch():
     assert sorted(n) == [4, 8]
 
 
+def test_decode_process_yields_the_same_batches_as_the_producer_thread():
+    """run.py --decode_process (resident mode): the epoch's sampler + decode + de-duplication plan run in a spawned child
+    process.  Same batches, same label draws (the child continues this process's global `random` stream and hands the state
+    back), same plans as the in-thread producer - here with the device hand-over replaced by a pass-through (no GPU)."""
+    import dataloader
+
+    def collect(use_process):
+        dl, _ = _loader(batch_size=5)                 # no shuffle buffer: its generator is seeded from the OS, as tf.data's is
+        dl.resident, dl.enable_gpu, dl.dedup, dl.decode_process = True, True, True, use_process
+        dl._to_device = lambda h, m, c, y, plan: (np.asarray(h).copy(), np.asarray(m).copy(), np.asarray(c).copy(), np.asarray(y).copy(),
+                                                  None if plan is None else (plan.uniq.copy(), plan.inv.copy(), plan.order.copy(),
+                                                                             plan.seg.copy(), plan.n_enc, plan.n_unique, plan.n_slots))
+        import torch as _t
+        _set = _t.cuda.set_device
+        _t.cuda.set_device = lambda *_: None          # the producer thread's set_device (dataloader.py:86-88) needs no GPU here
+        try:
+            random.seed(123)
+            out = [list(dl) for _ in range(2)]            # two epochs: the state handed back feeds the second one
+            dl.join()
+        finally:
+            _t.cuda.set_device = _set
+        return out, random.getstate()
+
+    (a, sa), (b, sb) = collect(False), collect(True)
+    assert sa == sb
+    for ea, eb in zip(a, b):
+        assert len(ea) == len(eb) == 3
+        for x, y in zip(ea, eb):
+            for u, v in zip(x[:4], y[:4]):
+                assert np.array_equal(u, v)
+            assert (x[4] is None) == (y[4] is None)
+            if x[4] is not None:
+                assert all(np.array_equal(u, v) for u, v in zip(x[4][:4], y[4][:4])) and x[4][4:] == y[4][4:]
+
+
 def test_news_table_layout_with_stub_tokenizer():
     import preprocess
     L = 6

@@ -22,6 +22,28 @@ from streaming import StreamSampler, _count_lines, shard_files
 _END = object()
 
 
+def _decode_process(cfg, rnd_state, q):
+    """Child process of DataLoaderTrain._produce_from_process: one epoch's lines -> index arrays (+ de-duplication plan)."""
+    try:
+        random.setstate(rnd_state)
+        dec = DataLoaderTrain.__new__(DataLoaderTrain)
+        dec.news_index, dec.user_log_length, dec.npratio = cfg["news_index"], cfg["user_log_length"], cfg["npratio"]
+        build_plan = None
+        if cfg["dedup"]:
+            from dedup import build_plan
+        for batch in StreamSampler(**cfg["sampler"]):
+            h, m, c, y = dec.decode(batch)
+            pl = None
+            if build_plan is not None:
+                p = build_plan(h, c)
+                pl = None if p is None else (p.uniq, p.inv, p.order, p.seg, p.n_enc, p.n_unique, p.n_slots)
+            q.put(("batch", (h.astype(np.int32), m, c.astype(np.int32), y, pl)))
+        q.put(("end", random.getstate()))
+    except BaseException as e:          # noqa: BLE001 - reported to the parent, which raises
+        import traceback
+        q.put(("error", "%r\n%s" % (e, traceback.format_exc())))
+
+
 class IndexBatch(tuple):
     """(hist_idx, log_mask, cand_idx, label[, dedup plan or None]) in resident mode."""
 
@@ -39,6 +61,7 @@ class DataLoaderTrain:
         self.teacher_embs, self.news_combined, self.news_index = teacher_embs, news_combined, news_index
         self.resident = enable_gpu if resident is None else resident
         self.dedup = bool(getattr(args, "dedup_news", False))
+        self.decode_process = bool(getattr(args, "decode_process", False)) and enable_prefetch
         self.epoch = -1
         self.sampler = None
         self.dev_tables = None
@@ -61,31 +84,53 @@ class DataLoaderTrain:
         return x[-fix_length:] + [padding_value] * (fix_length - n), [1] * min(fix_length, n) + [0] * (fix_length - n)
 
     def decode(self, batch):
-        """lines -> hist_idx (B,U), mask (B,U), cand_idx (B,C), label (B,)   dataloader.py:119-149"""
-        H, M, C, Y = [], [], [], []
-        for raw in batch:
+        """lines -> hist_idx (B,U), mask (B,U), cand_idx (B,C), label (B,)   dataloader.py:119-149
+        The same values as trans_to_nindex / pad_to_fix_len / the label draw of the reference, line by line and in its order (one
+        random.randint per line from Python's global generator), written into preallocated arrays: the producer thread shares the
+        GIL with the thread that launches the kernels, so its Python time per batch is what bounds a file-fed run."""
+        U, K = self.user_log_length, self.npratio
+        B = len(batch)
+        H, M = np.zeros((B, U), np.int64), np.zeros((B, U), np.float32)
+        C, Y = np.empty((B, K + 1), np.int64), np.empty(B, np.int64)
+        get, randint = self.news_index.get, random.randint
+        for r, raw in enumerate(batch):
             line = raw.decode("utf-8").split("\t")
-            click, mask = self.pad_to_fix_len(self.trans_to_nindex(line[3].split()), self.user_log_length)
-            pos = self.trans_to_nindex(line[4].split())
-            neg = self.trans_to_nindex(line[5].split())
-            label = random.randint(0, self.npratio)
-            H.append(click)
-            M.append(mask)
-            C.append(neg[:label] + pos + neg[label:])
-            Y.append(label)
-        return (np.asarray(H, np.int64), np.asarray(M, np.float32), np.asarray(C, np.int64), np.asarray(Y, np.int64))
+            click = [get(i, 0) for i in line[3].split()]           # unknown id -> index 0 (its mask stays 1)
+            n = len(click)
+            if n >= U:
+                H[r] = click[-U:]                                  # the LAST U clicks
+                M[r] = 1.0
+            elif n:
+                H[r, U - n:] = click                               # left-padded with 0
+                M[r, U - n:] = 1.0
+            pos = [get(i, 0) for i in line[4].split()]
+            neg = [get(i, 0) for i in line[5].split()]
+            label = randint(0, K)
+            C[r] = neg[:label] + pos + neg[label:]
+            Y[r] = label
+        return H, M, C, Y
+
+    def _staging(self, words):
+        """A pinned host buffer of >= `words` int32 from a small ring (the H2D copy of the batch that last used it has completed)."""
+        if not hasattr(self, "_pin"):
+            self._pin, self._pin_i = [None] * 16, 0
+        i = self._pin_i = (self._pin_i + 1) % len(self._pin)
+        slot = self._pin[i]
+        if slot is not None:
+            slot[1].synchronize()
+        if slot is None or slot[0].numel() < words:
+            slot = [torch.empty(max(words, 8192), dtype=torch.int32).pin_memory(), None]
+        self._pin[i] = slot
+        return slot
 
     def _process(self, batch):
         h, m, c, y = self.decode(batch)
         if self.resident and self.enable_gpu:
-            dev = self.dev_news.device
             plan = None
             if self.dedup:
                 from dedup import build_plan
                 plan = build_plan(h, c)
-                plan = plan.to(dev) if plan is not None else None
-            return IndexBatch((torch.from_numpy(h.astype(np.int32)).to(dev, non_blocking=True), torch.from_numpy(m).to(dev),
-                               torch.from_numpy(c.astype(np.int32)).to(dev), torch.from_numpy(y).to(dev), plan))
+            return self._to_device(h, m, c, y, plan)
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
         out = [t(self.news_combined[h].astype(np.int64)), t(m), t(self.news_combined[c].astype(np.int64)), t(y),
                [t(np.asarray(te)[h].astype(np.float32)) for te in self.teacher_embs[:self.num_teachers]],
@@ -94,7 +139,97 @@ class DataLoaderTrain:
             out = [x.cuda() if isinstance(x, torch.Tensor) else [v.cuda() for v in x] for x in out]
         return tuple(out)
 
+    def _to_device(self, h, m, c, y, plan):
+        """Resident mode: ONE pinned staging buffer and ONE asynchronous copy per batch on the producer's own stream (nine small
+        pageable copies cost the producer ~0.4 ms of a 2.8 ms step); the consumer's stream waits for the copy's event (__next__)."""
+        dev = self.dev_news.device
+        B, U, Cn = h.shape[0], h.shape[1], c.shape[1]
+        parts = [("h", np.ascontiguousarray(h, np.int32).reshape(-1)), ("c", np.ascontiguousarray(c, np.int32).reshape(-1)),
+                 ("m", np.ascontiguousarray(m, np.float32).reshape(-1).view(np.int32)),
+                 ("y", np.ascontiguousarray(y, np.int64).view(np.int32))]     # int64 labels as pairs of words (offsets kept even below)
+        if plan is not None:
+            parts += [(k, getattr(plan, k)) for k in ("uniq", "inv", "order", "seg")]
+        off, offs = 0, {}
+        for k, a in parts:
+            off += off & 1                                      # 8-byte alignment for every part
+            offs[k] = (off, a.size)
+            off += a.size
+        slot = self._staging(off)
+        host = slot[0].numpy()
+        for k, a in parts:
+            o, n = offs[k]
+            host[o:o + n] = a
+        if not hasattr(self, "_copy_stream"):
+            self._copy_stream = torch.cuda.Stream(dev)
+        with torch.cuda.stream(self._copy_stream):
+            d = slot[0][:off].to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        slot[1] = ev
+        part = lambda k: d[offs[k][0]:offs[k][0] + offs[k][1]]
+        dplan = None
+        if plan is not None:
+            from dedup import DedupPlan
+            dplan = DedupPlan()
+            for k in ("uniq", "inv", "order", "seg"):
+                setattr(dplan, k, part(k))
+            dplan.n_enc, dplan.n_unique, dplan.n_slots = plan.n_enc, plan.n_unique, plan.n_slots
+        out = IndexBatch((part("h").view(B, U), part("m").view(torch.float32).view(B, U), part("c").view(B, Cn),
+                          part("y").view(torch.int64), dplan))
+        out.ready, out.buf = ev, d
+        return out
+
     # -- streaming -----------------------------------------------------------------------------------
+    def _sampler_args(self):
+        return dict(data_dir=self.data_dir, filename_pat=self.filename_pat, batch_size=self.batch_size,
+                    worker_rank=self.worker_rank, world_size=self.world_size, enable_shuffle=self.enable_shuffle,
+                    shuffle_buffer_size=self.shuffle_buffer_size, shuffle_seed=self.epoch)
+
+    def _produce_from_process(self):
+        """Resident mode with --decode_process: the epoch's sampler + decode + de-duplication plan run in a CHILD process
+        (spawned: it never touches the GPU), this thread only stages its arrays and starts the H2D copy.  The decoder then no longer
+        shares the GIL with the thread that launches the kernels - what held run.py's default mode to 0.87 of bench.py's figure.
+        The label draws stay where the reference has them: the child continues Python's global `random` stream from this process's
+        state and hands the state back at the end of the epoch."""
+        import multiprocessing as mp
+        from dedup import DedupPlan
+        self.epoch += 1
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue(32)
+        cfg = dict(sampler=self._sampler_args(), news_index=self.news_index, user_log_length=self.user_log_length,
+                   npratio=self.npratio, dedup=self.dedup)
+        proc = ctx.Process(target=_decode_process, args=(cfg, random.getstate(), q), daemon=True)
+        proc.start()
+        self._proc = proc
+        try:
+            while True:
+                try:
+                    item = q.get(timeout=1.0)
+                except queue.Empty:
+                    if self.stopped:
+                        return
+                    if not proc.is_alive():
+                        raise RuntimeError("the decode process died (exit code %s)" % proc.exitcode)
+                    continue
+                if item[0] == "end":
+                    random.setstate(item[1])
+                    return
+                if item[0] == "error":
+                    raise RuntimeError("decode process: " + item[1])
+                if self.stopped:
+                    return
+                h, m, c, y, pl = item[1]
+                plan = None
+                if pl is not None:
+                    plan = DedupPlan()
+                    plan.uniq, plan.inv, plan.order, plan.seg, plan.n_enc, plan.n_unique, plan.n_slots = pl
+                self.outputs.put(self._to_device(h, m, c, y, plan))
+        finally:
+            if proc.is_alive():
+                proc.terminate()
+            proc.join(5)
+            self._proc = None
+
     def _new_sampler(self):
         self.epoch += 1
         self.sampler = StreamSampler(data_dir=self.data_dir, filename_pat=self.filename_pat, batch_size=self.batch_size,
@@ -118,10 +253,13 @@ class DataLoaderTrain:
         try:
             if self.enable_gpu:
                 torch.cuda.set_device(self.cuda_device_idx)      # dataloader.py:86-88
-            for batch in self._new_sampler():
-                if self.stopped:
-                    break
-                self.outputs.put(self._process(batch))
+            if self.decode_process and self.resident and self.enable_gpu:
+                self._produce_from_process()
+            else:
+                for batch in self._new_sampler():
+                    if self.stopped:
+                        break
+                    self.outputs.put(self._process(batch))
         except BaseException as e:      # surface producer failures instead of hanging the consumer
             logging.exception("producer failed")
             self.outputs.put(e)
@@ -146,8 +284,14 @@ class DataLoaderTrain:
                 raise StopIteration
             if isinstance(item, BaseException):
                 raise item
-            return item
-        return self._process(next(self._sync_it))
+        else:
+            item = self._process(next(self._sync_it))
+        ev = getattr(item, "ready", None)
+        if ev is not None:                       # resident mode: the batch's one H2D copy runs on the producer's stream
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            item.buf.record_stream(cur)          # allocated on the copy stream, read by this one
+        return item
 
     def join(self):
         self.stopped = True

@@ -35,6 +35,7 @@ def _flag_table():
           ("resident_tables", _B, True, dict(help="keep news_combined / teacher tables in HBM and ship indices only")),
           ("cache_frozen_layers", _B, True, dict(help="resident mode: compute the frozen lower encoder layers once per news instead of every step (identical results)")),
           ("dedup_news", _B, True, dict(help="encode each distinct news of a batch once (resident mode; identical results)")),
+          ("decode_process", _B, True, dict(help="resident mode: TSV decode + de-duplication plan in a child process, so that the decoder does not share the GIL with the thread that launches the kernels (identical batches)")),
           ("dtype", str, "fp16", dict(choices=["bf16", "fp16"], help="16-bit activation type of the HIP kernels (fp16 meets the 1e-3 logit / loss tolerance, bf16 does not: DESIGN.md section 2)")),
           ("allow_random_init", _B, False, dict(help="start from the construction-time initialisation when --model_name does not exist (the reference's from_pretrained raises; so does this build unless this flag or --synthetic is set)")),
           ("synthetic", _B, False, dict(help="random-init weights + synthetic MIND-shaped data (no files needed)"))]

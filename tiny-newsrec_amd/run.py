@@ -4,6 +4,7 @@ epoch-end checkpoint dict and file name, max_steps_per_epoch break), on the HIP 
 horovod.  --mode test / get_teacher_emb are the forward-only paths of SURVEY.md section 8-f N2."""
 import logging
 import os
+import sys
 import pickle
 import time
 
@@ -39,6 +40,9 @@ def train(args):
     from streaming import get_stat, get_worker_files
     size, rank, local = utils.init_hvd_cuda(args.enable_hvd, args.enable_gpu)
     assert args.enable_gpu, "the HIP path needs a GPU (there is no CPU fallback)"
+    # the loader's producer thread (TSV decode) and this thread (kernel launches) share the GIL: with the default 5 ms switch
+    # interval the launching thread can sit out a whole 3 ms step behind the decoder and the GPU queue runs dry
+    sys.setswitchinterval(2e-4)
     news_index, news_combined, teacher_embs, category_dict, subcategory_dict = _load_inputs(args)
     # --num_teachers 0 is PLM-NR/run.py's train(): the same encoders with plain CE (ModelBert), checkpoints with PLM-NR's
     # key names, and -- with --use_pretrain_model -- its two learning rates (PLM-NR/run.py:56-106).  Tiny-NewsRec's own

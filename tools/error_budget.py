@@ -30,7 +30,8 @@ SITES = ["W", "x0", "qkv", "P", "ctx", "h1pre", "h1", "g", "ypre", "y"]
 
 def forward(round_sites):
     r = lambda name, t: t.to(DT).float() if name in round_sites else t
-    w = lambda k: r("W", P[k])
+    # "W": every 16-bit weight copy ; "W:<key>": that one matrix only ; "Wfp32:<key>": every copy EXCEPT that one
+    w = lambda k: P[k].to(DT).float() if (("W" in round_sites and "Wfp32:" + k not in round_sites) or "W:" + k in round_sites) else P[k]
     ids, m = tok[:, :L], tok[:, L:].float()
     N = ids.shape[0]
     e = P[O.BERT + "embeddings.word_embeddings.weight"][ids] + P[O.BERT + "embeddings.position_embeddings.weight"][:L][None] \
@@ -85,3 +86,24 @@ with torch.no_grad():
             ss += rms * rms
         print("%-58s max %.2e  rms %.2e" % (name, mx, rms), flush=True)
     print("root-sum-square of the single-site r.m.s. errors: %.2e" % ss ** 0.5)
+    if os.environ.get("PER_GEMM"):
+        # which weight matrix carries the weight-rounding error?  One 16-bit copy at a time (everything else fp32), then what a
+        # compensated weight (W = W_hi + W_lo, two MFMAs: that GEMM launch at twice the MFMA time) on the top contributors would buy
+        keys = []
+        for l in range(NL):
+            p = O.BERT + "encoder.layer.%d." % l
+            keys += [p + "attention.self.query.weight", p + "attention.self.key.weight", p + "attention.self.value.weight",
+                     p + "attention.output.dense.weight", p + "intermediate.dense.weight", p + "output.dense.weight"]
+        keys.append(O.PFX + "attn.att_fc1.weight")
+        per = []
+        for k in keys:
+            mx, rms = err(forward({"W:" + k}), ref)
+            per.append((rms, mx, k))
+            print("only W %-62s max %.2e  rms %.2e" % (k[len(O.BERT):] if k.startswith(O.BERT) else k, mx, rms), flush=True)
+        print("root-sum-square over the matrices: %.2e" % sum(r_ * r_ for r_, _, _ in per) ** 0.5)
+        per.sort(reverse=True)
+        for n in (1, 2, 4, 8):
+            keep = {"Wfp32:" + k for _, _, k in per[:n]}
+            mx, rms = err(forward(set(SITES) | keep), ref)
+            print("the engine with the top %d matrices compensated (exact weights): max %.2e  rms %.2e   [%s]" % (
+                n, mx, rms, ", ".join(k.split("encoder.")[-1] for _, _, k in per[:n])), flush=True)
