@@ -200,7 +200,14 @@ def _conv(a):
     return _ptr(a) if (isinstance(a, torch.Tensor) or a is None) else a
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """torch's current stream on the current device as a raw hipStream_t (~0.2 us through the C entry point, ~1.5 us through the
+    Stream object; a step makes ~85 calls)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -28,16 +28,15 @@ def make_corpus(d, n_news, n_lines, seed=5):
         for i in range(n_news):
             t = " ".join(words[j] for j in rs.randint(0, 5000, lens[i]))
             f.write("N%d\tcat%d\tsub%d\t%s\tabs\turl\t[]\t[]\n" % (i + 1, i % 17, i % 250, t))
-    # raw MIND behaviors: Zipf-like popularity, histories of geometric length (mean ~32, the loader keeps the last 50), 3 clicked
-    # and 12 skipped candidates per impression -> 3 training lines each after split_file.py
-    pop = rs.zipf(1.1, 4 * n_lines) % n_news + 1
-    n_imp, k = (n_lines + 2) // 3, 0
+    # raw MIND behaviors with EXACTLY the statistics of bench.py's synthetic impressions (synth.impressions: history lengths,
+    # popularity law, uniform candidates), so that the two figures compare like with like - the share of distinct news per batch
+    # decides what the de-duplicated modes cost; one clicked + four skipped candidates per impression = one training line each
+    import synth
+    hidx, hmask, cidx, label = synth.impressions(1235, n_lines, n_news, 50, 5)
     with open(os.path.join(d, "behaviors.tsv"), "w") as f:
-        for i in range(n_imp):
-            hl = min(int(rs.geometric(1 / 32.0)), 80)
-            hist = " ".join("N%d" % x for x in pop[k:k + hl]); k = (k + hl) % (len(pop) - 200)
-            cand = rs.randint(1, n_news + 1, 15)
-            imp = " ".join("N%d-%d" % (c, 1 if j < 3 else 0) for j, c in enumerate(cand))
+        for i in range(n_lines):
+            hist = " ".join("N%d" % x for x in hidx[i][hmask[i] > 0])
+            imp = " ".join("N%d-%d" % (c, 1 if j == label[i] else 0) for j, c in enumerate(cidx[i]))
             f.write("%d\tU%d\t11/15/2019 8:55:22 AM\t%s\t%s\n" % (i, i % 50000, hist, imp))
     import split_file
     paths, n = split_file.split(os.path.join(d, "behaviors.tsv"), 1, 4, seed=7)
