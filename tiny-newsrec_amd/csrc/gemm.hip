@@ -1403,6 +1403,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         if (acc[0][0][0] == 12345.678f) *(f32x4*)g.C = acc[1][1];
     } else
 #endif
+#ifdef TNR_NOEPI   // tools only (make BUILD=../../tools/_noepi EXTRA=-DTNR_NOEPI): the product's code minus the epilogue, no probe code
+#pragma unroll     // in the K loop - the probe build's runtime switches slow its K loop by ~15 %, which misled one A/B (EXPERIMENTS.md)
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+    if (false)
+#endif
     nt_epilogue_cols<MI, CF>(g, acc, lut, bias_lds + par * 256, bm, bn, rs, tall ? MI : MI - 1, wm, wn, lane);
     par ^= 1;
 #ifdef TNR_PROBES

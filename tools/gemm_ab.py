@@ -1,10 +1,16 @@
 """Interleaved same-process A/B of a library GEMM option (tnr_gemm_set_option) over the encoder's NT shapes; GPU box.
 Box-to-box variance on this pool is up to 15 %, so only interleaved same-box comparisons are meaningful.
-    AB=pp:0:1 python tools/gemm_ab.py        (two-phase main loop vs ping-pong)      DTYPE=fp16|bf16"""
+    AB=pp:0:1 python tools/gemm_ab.py        (two-phase main loop vs ping-pong)      DTYPE=fp16|bf16
+    PROBE=8 ... : the same A/B in the probe build (tools/_probe, -DTNR_PROBES=2) with that probe set, e.g. 8 = K loops without epilogues"""
 import collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
 import torch, tnr_hip as T
+if os.environ.get("LIB"):                 # another build of the library (e.g. tools/_noepi: make BUILD=../../tools/_noepi EXTRA=-DTNR_NOEPI)
+    T.LIB_PATH = os.path.join(ROOT, os.environ["LIB"], "libtnr_hip.so")
+if os.environ.get("PROBE"):
+    T.LIB_PATH = os.path.join(ROOT, "tools", "_probe", "libtnr_hip.so")
+    T.lib().tnr_gemm_set_option(b"probe", int(os.environ["PROBE"]))
 dev = "cuda:0"
 M = int(os.environ.get("M", 52800))
 KEY, *VALS = os.environ.get("AB", "pp:0:1").split(":")

@@ -1,35 +1,22 @@
-"""Assemble (tools/w4_proto/gen_w4_asm.py) and time the hand-scheduled four-wave NT GEMM tile kernel against the shipped eight-wave
-kernel (tools only).  python tools/w4_proto/run_w4_asm.py [N K] [knobs]     e.g.  768 3072 dma_step=4,bar_at=32"""
-import ctypes, os, struct, subprocess, sys
+"""Check and time the hand-scheduled four-wave NT GEMM tile kernel (tools/w4_proto/gen_w4_hip.py -> libw4asm.so) against the shipped
+eight-wave kernel (tools only).
+    python tools/w4_proto/gen_w4_hip.py [knobs] > /tmp/w4.hip && hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o tools/w4_proto/libw4asm.so /tmp/w4.hip
+    python tools/w4_proto/run_w4_asm.py [N K]           (LIB=<path> for another build of the prototype)"""
+import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
 import torch, tnr_hip as T
 HERE = os.path.dirname(os.path.abspath(__file__))
-LLVM = "/opt/rocm/lib/llvm/bin"
-hip = ctypes.CDLL("libamdhip64.so")
+L = ctypes.CDLL(os.environ.get("LIB", os.path.join(HERE, "libw4asm.so")))
+L.w4_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p]
 dev = "cuda:0"
+VAR = {"full": 0, "mfma": 1, "noread": 2, "nodma": 3, "noepi": 1}
+VARIANTS = os.environ.get("VARIANTS", "full,mfma,nodma,noread").split(",")
 
 
-def build(variant, knobs=""):
-    tag = variant + ("_" + knobs.replace("=", "").replace(",", "_") if knobs else "")
-    s, o, h = ["/tmp/w4_%s.%s" % (tag, e) for e in ("s", "o", "hsaco")]
-    src = subprocess.run([sys.executable, os.path.join(HERE, "gen_w4_asm.py"), variant] + ([knobs] if knobs else []), capture_output=True, text=True, check=True).stdout
-    open(s, "w").write(src)
-    subprocess.run([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s, "-o", o], check=True)
-    subprocess.run([LLVM + "/ld.lld", "-shared", o, "-o", h], check=True)
-    mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
-    assert hip.hipModuleLoad(ctypes.byref(mod), h.encode()) == 0
-    assert hip.hipModuleGetFunction(ctypes.byref(fn), mod, ("w4_gemm_" + variant).encode()) == 0
-    return fn
-
-
-def launch(fn, a, b, c, M, N, K):
-    args = struct.pack("<QQQiiiiii", a.data_ptr(), b.data_ptr(), c.data_ptr(), a.stride(0) * 2, b.stride(0) * 2, c.stride(0) * 2, M, K // 64, N // 256)
-    buf = ctypes.create_string_buffer(args, len(args))
-    size = ctypes.c_size_t(len(args))
-    extra = (ctypes.c_void_p * 5)(1, ctypes.cast(buf, ctypes.c_void_p), 2, ctypes.cast(ctypes.byref(size), ctypes.c_void_p), 3)
-    grid = ((M + 255) // 256) * (N // 256)
-    rc = hip.hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None, extra)
+def launch(v, a, b, c, M, N, K):
+    rc = L.w4_launch(VAR[v], a.data_ptr(), b.data_ptr(), c.data_ptr(), a.stride(0) * 2, b.stride(0) * 2, c.stride(0) * 2, M, N, K,
+                     torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
 
 
@@ -42,32 +29,59 @@ def timeit(f, n=20):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-def main():
-    N, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (768, 3072)
-    knobs = sys.argv[3] if len(sys.argv) > 3 else ""
-    M = int(os.environ.get("M", 52800))
+def check(M, N, K):
     torch.manual_seed(0)
     a = (torch.randn((M, K), device=dev) * 0.5).to(torch.float16)
     b = (torch.randn((N, K), device=dev) * 0.05).to(torch.float16)
-    c = torch.zeros((M, N), device=dev, dtype=torch.float16)
-    full = build("full", knobs)
-    launch(full, a, b, c, M, N, K)
+    c = torch.full((M, N), 7.0, device=dev, dtype=torch.float16)
+    guard = torch.full((1 << 20,), 3.0, device=dev, dtype=torch.float16)        # allocated right behind C: a stray store shows up here
+    launch("full", a, b, c, M, N, K)
     torch.cuda.synchronize()
-    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M), torch.randint(0, M, (400,))]).to(dev)
-    ref = (a[rows].float() @ b.float().t())
-    err = (c[rows].float() - ref).abs().max().item()
     c2 = torch.zeros_like(c)
     T.call("tnr_gemm_nt_ex_f16", a, K, b, K, c2, N, M, N, K, None, None, 0, None, 0, 0, None)
     torch.cuda.synchronize()
-    same = torch.equal(c, c2)
-    print("N=%d K=%d M=%d: max |err| vs fp32 on %d rows %.3e ; bit-identical to the shipped kernel: %s" % (N, K, M, rows.numel(), err, same), flush=True)
+    ref = a.float() @ b.float().t() if M <= 4096 else None
+    err = float((c.float() - ref).abs().max()) if ref is not None else float("nan")
+    same = bool(torch.equal(c, c2))
+    print("M=%d N=%d K=%d: max |err| vs fp32 %.3e ; bit-identical to the shipped kernel: %s ; guard intact: %s" % (
+        M, N, K, err, same, bool((guard == 3.0).all())), flush=True)
+    if not same:
+        bad = (c != c2)
+        print("   differing: %d of %d ; rows %s ; cols %s" % (int(bad.sum()), c.numel(), bad.any(1).nonzero().flatten()[:12].tolist(),
+                                                              bad.any(0).nonzero().flatten()[:12].tolist()), flush=True)
+    return same, a, b, c, c2
+
+
+def main():
+    N, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (768, 3072)
+    ok, *_ = check(512, N, 256)                      # small first: nothing large runs on a kernel that is wrong at 6 tiles
+    if not ok:
+        sys.exit(1)
+    ok, *_ = check(700, N, K)                        # rows that are not a multiple of the tile height
+    if not ok:
+        sys.exit(1)
+    M = int(os.environ.get("M", 52800))
+    ok, a, b, c, c2 = check(M, N, K)
+    if not ok:
+        sys.exit(1)
     tiles = ((M + 255) // 256) * (N // 256)
     rounds = -(-tiles // 256)
     res = {}
-    for v in ("full", "mfma", "nodma", "noread"):
-        fn = full if v == "full" else build(v, knobs)
-        res[v] = timeit(lambda: launch(fn, a, b, c, M, N, K))
-    res["shipped 8-wave (plain store)"] = timeit(lambda: T.call("tnr_gemm_nt_ex_f16", a, K, b, K, c2, N, M, N, K, None, None, 0, None, 0, 0, None))
+    for rep in range(3):                                      # interleaved: prototype variants and the shipped kernel in turn
+        for v in VARIANTS:
+            res.setdefault(v, []).append(timeit(lambda: launch(v, a, b, c, M, N, K)))
+        res.setdefault("shipped 8-wave (plain store)", []).append(
+            timeit(lambda: T.call("tnr_gemm_nt_ex_f16", a, K, b, K, c2, N, M, N, K, None, None, 0, None, 0, 0, None)))
+        if os.environ.get("PROBE_LIB"):                       # the shipped kernel without its epilogue (probe 8 of a -DTNR_PROBES=2 build)
+            if rep == 0:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("tnr_probe", os.path.join(ROOT, "tiny-newsrec_amd", "tnr_hip.py"))
+                TP = importlib.util.module_from_spec(spec); spec.loader.exec_module(TP)
+                TP.LIB_PATH = os.path.join(ROOT, os.environ["PROBE_LIB"])
+                TP.lib().tnr_gemm_set_option(b"probe", 8)
+            res.setdefault("shipped 8-wave, no epilogue (probe 8)", []).append(
+                timeit(lambda: TP.call("tnr_gemm_nt_ex_f16", a, K, b, K, c2, N, M, N, K, None, None, 0, None, 0, 0, None)))
+    res = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
     for k, us in res.items():
         print("   %-32s %8.1f us   %6.0f TF   per K step (%.2f rounds of tiles) %.2f us" % (k, us, 2.0 * M * N * K / us / 1e6, tiles / 256.0, us / rounds / (K // 64)), flush=True)
 
