@@ -489,6 +489,33 @@ def test_amsgrad_matches_reference_golden(golden_dir):
             np.testing.assert_allclose(p.cpu().numpy(), z["p%d_%d" % (s + 1, i)].reshape(-1), rtol=1e-5, atol=1e-6)
 
 
+def test_grad_nonfinite_finds_a_single_bad_value_anywhere():
+    """tnr_grad_nonfinite (PLM-NR/run.py:158-160 scaler.step: the step is skipped when any gradient is inf / nan): a lone inf,
+    -inf or nan at the first, last or any other position of a buffer of any length (whole 4 KB trips, a tail, fewer than four
+    elements) raises guard[0] to the stamp and counts the skip in guard[1]; finite buffers - large values, denormals, zeros -
+    leave both alone; guard[2] (the arrival counter) is back at zero either way."""
+    rs = np.random.RandomState(5)
+    stamp = 1
+    for n in (1, 3, 4, 5, 1023, 4095, 4096, 4097, 8192, 12289, (1 << 20) + 3, 9 * (1 << 20) + 1029):
+        base = (rs.standard_normal(n) * 1e3).astype(np.float32)
+        base[rs.randint(0, n, 4)] = (3.0e38, -3.0e38, 1e-42, 0.0)
+        g = torch.zeros(n + 8, device=DEV)[4:4 + n]                      # 16-byte aligned, not the start of an allocation
+        guard = torch.zeros(4, dtype=torch.int32, device=DEV)
+        skips = 0
+        for pos, val in [(None, 0.0), (0, np.inf), (n - 1, np.nan), (int(rs.randint(0, n)), -np.inf), (n // 2, np.nan), (None, 0.0)]:
+            a = base.copy()
+            if pos is not None:
+                a[pos] = val
+            g.copy_(torch.from_numpy(a))
+            T.call("tnr_grad_nonfinite", g, n, guard, stamp)
+            torch.cuda.synchronize()
+            got = guard.cpu().numpy()
+            skips += pos is not None
+            assert (got[0] == stamp) if pos is not None else (got[0] < stamp), (n, pos, got)     # stamps only grow
+            assert got[1] == skips and got[2] == 0, (n, pos, got)
+            stamp += 1
+
+
 def test_refresh_shadows():
     w1, w2 = rnd((200, 768), 1), rnd((768, 96), 2)
     s1, s2 = dev(w1), dev(w2)
