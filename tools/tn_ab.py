@@ -1,10 +1,14 @@
 """Interleaved same-process A/B of a library option on the weight-gradient GEMMs of the headline step (engine's split counts);
-GPU box.     AB=tnpp:0:1 DTYPE=fp16 python tools/tn_ab.py"""
+GPU box.     AB=tnpp:0:1 DTYPE=fp16 python tools/tn_ab.py
+LIB=tools/_tnp2 ... : another build of the library (make BUILD=../../tools/_tnp2 EXTRA=-DTNR_TN_PROBE=2: the kernel without its
+fragment reads; 1 = without LDS-DMA after the first two m steps, 4 = without MFMAs, sums combine)"""
 import collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
 import torch, tnr_hip as T
 import engine as E
+if os.environ.get("LIB"):
+    T.LIB_PATH = os.path.join(ROOT, os.environ["LIB"], "libtnr_hip.so")
 dev, M = "cuda:0", int(os.environ.get("M", 52800))
 Mp = (M + 127) // 128 * 128
 KEY, *VALS = os.environ.get("AB", "tnpp:0:1").split(":")
