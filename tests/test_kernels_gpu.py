@@ -490,7 +490,8 @@ def test_amsgrad_matches_reference_golden(golden_dir):
 
 
 def test_grad_nonfinite_finds_a_single_bad_value_anywhere():
-    """tnr_grad_nonfinite (PLM-NR/run.py:158-160 scaler.step: the step is skipped when any gradient is inf / nan): a lone inf,
+    """tnr_grad_nonfinite (no reference counterpart: the reference steps its optimiser in fp32, run.py:194-195; this build's fp16
+    backward carries a loss scale, and a step whose gradient holds inf / nan must be skipped): a lone inf,
     -inf or nan at the first, last or any other position of a buffer of any length (whole 4 KB trips, a tail, fewer than four
     elements) raises guard[0] to the stamp and counts the skip in guard[1]; finite buffers - large values, denormals, zeros -
     leave both alone; guard[2] (the arrival counter) is back at zero either way."""
