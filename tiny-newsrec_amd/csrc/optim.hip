@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(float* __restrict__ p, con
     }
 }
 
-// any inf / nan among g[0 .. n)?  -> guard[0] = max(guard[0], stamp), and the last workgroup to finish counts the skipped step in
-// guard[1] (guard[2]: arrival counter, back at zero afterwards).  16-byte reads, one atomic per offending workgroup.
+// any inf / nan among g[0 .. n)?  -> guard[0] = max(guard[0], stamp): one atomic per OFFENDING workgroup, none on a clean gradient
+// (an arrival counter on one address cost more than the scan: 2 048 same-address atomics = 30-70 us).  The skipped step is counted
+// in guard[1] by the one-thread kernel behind it.  16-byte reads, four in flight per lane.
 __global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* __restrict__ g, int64_t n, unsigned* guard, unsigned stamp) {
-    // a workgroup takes 4 x 4 KB per trip: four independent 16-byte loads per lane in flight (one load per trip ran at 1.3 TB/s)
     const int64_t stride = (int64_t)gridDim.x * 4096;
     unsigned bad = 0;
     for (int64_t base = (int64_t)blockIdx.x * 4096; base < n; base += stride) {
@@ -81,19 +81,11 @@ __global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* __rest
         }
     }
     const int any = __syncthreads_or((int)bad);
-    if (threadIdx.x == 0) {
-        if (any) __hip_atomic_fetch_max(guard, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // agent-scope atomics on one address are totally ordered at the memory side: the last arriver's read of guard[0] (an
-        // atomic itself) sees every workgroup's max, each of which was issued before that workgroup's ticket
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned ticket = __hip_atomic_fetch_add(guard + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == gridDim.x - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (__hip_atomic_fetch_max(guard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stamp)
-                __hip_atomic_fetch_add(guard + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(guard + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (any && threadIdx.x == 0) __hip_atomic_fetch_max(guard, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void grad_nonfinite_count_kernel(unsigned* guard, unsigned stamp) {      // <<<1, 1>>>, stream-ordered behind the scan
+    if (guard[0] == stamp) guard[1] += 1;
 }
 
 // one workgroup per 32x32 tile of some weight matrix (descriptor table on device)
@@ -146,6 +138,7 @@ extern "C" int tnr_grad_nonfinite(const float* g, int64_t n, unsigned* guard, un
     TNR_CHECK_ARG(g && guard && n >= 1 && stamp >= 1 && ((uintptr_t)g % 16) == 0, "tnr_grad_nonfinite: bad argument");
     const unsigned grid = (unsigned)std::min<int64_t>((n + 4095) / 4096, 2048);
     hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, guard, stamp);
+    hipLaunchKernelGGL(grad_nonfinite_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, guard, stamp);
     TNR_CHECK_LAUNCH("tnr_grad_nonfinite");
     return TNR_OK;
 }
