@@ -17,31 +17,10 @@ import threading
 import numpy as np
 import torch
 
+from decode_worker import decode_lines, decode_process
 from streaming import StreamSampler, _count_lines, shard_files
 
 _END = object()
-
-
-def _decode_process(cfg, rnd_state, q):
-    """Child process of DataLoaderTrain._produce_from_process: one epoch's lines -> index arrays (+ de-duplication plan)."""
-    try:
-        random.setstate(rnd_state)
-        dec = DataLoaderTrain.__new__(DataLoaderTrain)
-        dec.news_index, dec.user_log_length, dec.npratio = cfg["news_index"], cfg["user_log_length"], cfg["npratio"]
-        build_plan = None
-        if cfg["dedup"]:
-            from dedup import build_plan
-        for batch in StreamSampler(**cfg["sampler"]):
-            h, m, c, y = dec.decode(batch)
-            pl = None
-            if build_plan is not None:
-                p = build_plan(h, c)
-                pl = None if p is None else (p.uniq, p.inv, p.order, p.seg, p.n_enc, p.n_unique, p.n_slots)
-            q.put(("batch", (h.astype(np.int32), m, c.astype(np.int32), y, pl)))
-        q.put(("end", random.getstate()))
-    except BaseException as e:          # noqa: BLE001 - reported to the parent, which raises
-        import traceback
-        q.put(("error", "%r\n%s" % (e, traceback.format_exc())))
 
 
 class IndexBatch(tuple):
@@ -84,31 +63,8 @@ class DataLoaderTrain:
         return x[-fix_length:] + [padding_value] * (fix_length - n), [1] * min(fix_length, n) + [0] * (fix_length - n)
 
     def decode(self, batch):
-        """lines -> hist_idx (B,U), mask (B,U), cand_idx (B,C), label (B,)   dataloader.py:119-149
-        The same values as trans_to_nindex / pad_to_fix_len / the label draw of the reference, line by line and in its order (one
-        random.randint per line from Python's global generator), written into preallocated arrays: the producer thread shares the
-        GIL with the thread that launches the kernels, so its Python time per batch is what bounds a file-fed run."""
-        U, K = self.user_log_length, self.npratio
-        B = len(batch)
-        H, M = np.zeros((B, U), np.int64), np.zeros((B, U), np.float32)
-        C, Y = np.empty((B, K + 1), np.int64), np.empty(B, np.int64)
-        get, randint = self.news_index.get, random.randint
-        for r, raw in enumerate(batch):
-            line = raw.decode("utf-8").split("\t")
-            click = [get(i, 0) for i in line[3].split()]           # unknown id -> index 0 (its mask stays 1)
-            n = len(click)
-            if n >= U:
-                H[r] = click[-U:]                                  # the LAST U clicks
-                M[r] = 1.0
-            elif n:
-                H[r, U - n:] = click                               # left-padded with 0
-                M[r, U - n:] = 1.0
-            pos = [get(i, 0) for i in line[4].split()]
-            neg = [get(i, 0) for i in line[5].split()]
-            label = randint(0, K)
-            C[r] = neg[:label] + pos + neg[label:]
-            Y[r] = label
-        return H, M, C, Y
+        """lines -> hist_idx (B,U), mask (B,U), cand_idx (B,C), label (B,)   dataloader.py:119-149 (decode_worker.decode_lines)"""
+        return decode_lines(batch, self.news_index, self.user_log_length, self.npratio)
 
     def _staging(self, words):
         """A pinned host buffer of >= `words` int32 from a small ring (the H2D copy of the batch that last used it has completed)."""
@@ -187,7 +143,8 @@ class DataLoaderTrain:
 
     def _produce_from_process(self):
         """Resident mode with --decode_process: the epoch's sampler + decode + de-duplication plan run in a CHILD process
-        (spawned: it never touches the GPU), this thread only stages its arrays and starts the H2D copy.  The decoder then no longer
+        (spawned from decode_worker.py, which imports neither torch nor this module: it never touches the GPU and is up in a
+        fraction of a second), this thread only stages its arrays and starts the H2D copy.  The decoder then no longer
         shares the GIL with the thread that launches the kernels - what held run.py's default mode to 0.87 of bench.py's figure.
         The label draws stay where the reference has them: the child continues Python's global `random` stream from this process's
         state and hands the state back at the end of the epoch."""
@@ -198,7 +155,7 @@ class DataLoaderTrain:
         q = ctx.Queue(32)
         cfg = dict(sampler=self._sampler_args(), news_index=self.news_index, user_log_length=self.user_log_length,
                    npratio=self.npratio, dedup=self.dedup)
-        proc = ctx.Process(target=_decode_process, args=(cfg, random.getstate(), q), daemon=True)
+        proc = ctx.Process(target=decode_process, args=(cfg, random.getstate(), q), daemon=True)
         proc.start()
         self._proc = proc
         try:

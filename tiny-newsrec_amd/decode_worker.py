@@ -1,0 +1,56 @@
+"""The line decode of the training loader (Tiny-NewsRec/dataloader.py:119-149) as a free function, and the child process that
+runs it for DataLoaderTrain's resident mode.  Imports numpy and the standard library only: the spawned child must not pay for
+(or touch) torch."""
+import random
+
+import numpy as np
+
+
+def decode_lines(batch, news_index, U, K):
+    """lines -> hist_idx (B,U), mask (B,U), cand_idx (B,K+1), label (B,)
+    The same values as trans_to_nindex / pad_to_fix_len / the label draw of the reference (dataloader.py:73-83, 131-137), line by
+    line and in its order (one random.randint per line from Python's global generator), written into preallocated arrays: in
+    the producer THREAD this code shares the GIL with the thread that launches the kernels, so its Python time per batch is what
+    bounds a file-fed run."""
+    B = len(batch)
+    H, M = np.zeros((B, U), np.int64), np.zeros((B, U), np.float32)
+    C, Y = np.empty((B, K + 1), np.int64), np.empty(B, np.int64)
+    get, randint = news_index.get, random.randint
+    for r, raw in enumerate(batch):
+        line = raw.decode("utf-8").split("\t")
+        click = [get(i, 0) for i in line[3].split()]           # unknown id -> index 0 (its mask stays 1)
+        n = len(click)
+        if n >= U:
+            H[r] = click[-U:]                                  # the LAST U clicks
+            M[r] = 1.0
+        elif n:
+            H[r, U - n:] = click                               # left-padded with 0
+            M[r, U - n:] = 1.0
+        pos = [get(i, 0) for i in line[4].split()]
+        neg = [get(i, 0) for i in line[5].split()]
+        label = randint(0, K)
+        C[r] = neg[:label] + pos + neg[label:]
+        Y[r] = label
+    return H, M, C, Y
+
+
+def decode_process(cfg, rnd_state, q):
+    """Child process of DataLoaderTrain._produce_from_process: one epoch's lines -> index arrays (+ de-duplication plan).
+    Continues Python's global `random` stream from the parent's state and hands the state back with the end marker."""
+    try:
+        from streaming import StreamSampler
+        random.setstate(rnd_state)
+        build_plan = None
+        if cfg["dedup"]:
+            from dedup import build_plan
+        for batch in StreamSampler(**cfg["sampler"]):
+            h, m, c, y = decode_lines(batch, cfg["news_index"], cfg["user_log_length"], cfg["npratio"])
+            pl = None
+            if build_plan is not None:
+                p = build_plan(h, c)
+                pl = None if p is None else (p.uniq, p.inv, p.order, p.seg, p.n_enc, p.n_unique, p.n_slots)
+            q.put(("batch", (h.astype(np.int32), m, c.astype(np.int32), y, pl)))
+        q.put(("end", random.getstate()))
+    except BaseException as e:          # noqa: BLE001 - reported to the parent, which raises
+        import traceback
+        q.put(("error", "%r\n%s" % (e, traceback.format_exc())))
