@@ -10,6 +10,7 @@ frozen) whose slices ARE the nn.Parameters of model_bert.py, gradients and AMSGr
 buffers of the trainable size, bf16 (and transposed bf16) weight copies are refreshed by one
 kernel after each update, activations of the trainable layers stay resident for backward.
 """
+import logging
 import math
 import struct
 
@@ -207,7 +208,7 @@ class LossScaler:
 
     def __init__(self, dev, enabled, growth_interval=2000, max_mult=64.0, min_mult=2.0 ** -20):
         self.enabled = bool(enabled) and torch.device(dev).type == "cuda"
-        self.mult, self.stamp, self.clean, self.skipped = 1.0, 0, 0, 0
+        self.mult, self.stamp, self.clean, self.skipped, self.run_of_skips = 1.0, 0, 0, 0, 0
         self.growth_interval, self.max_mult, self.min_mult = growth_interval, max_mult, min_mult
         self.guard = torch.zeros(4, dtype=torch.int32, device=dev) if self.enabled else None
         self.pending = []                    # (stamp, pinned host word, event) in issue order
@@ -222,9 +223,14 @@ class LossScaler:
             if int(host[0]) == stamp:        # that step found inf / nan: it was skipped on the device
                 self.skipped += 1
                 self.clean = 0
+                self.run_of_skips += 1
                 self.mult = max(self.mult * 0.5, self.min_mult)
                 eng.step_count = max(eng.step_count - 1, 0)
+                if self.run_of_skips == 16:  # a smaller scale cures a backward overflow within a few steps, never a forward one
+                    logging.warning("16 optimiser steps in a row skipped for inf / nan gradients although the loss scale went down "
+                                    "to %g: the fp16 FORWARD overflows (or the data holds inf / nan) - use --dtype bf16", eng.gscale)
             else:
+                self.run_of_skips = 0
                 self.clean += 1
                 if self.clean >= self.growth_interval and self.mult < self.max_mult:
                     self.mult, self.clean = self.mult * 2.0, 0
