@@ -385,9 +385,10 @@ int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, 
 
 /* Dynamic loss scaling of the fp16 build (the reference trains in fp32 and needs none, run.py:134,194-195; with 16-bit
  * activation gradients one overflow would otherwise poison m / v / vmax for good).  guard = 4 uint32 words on the device,
- * zero at start: [0] stamp of the last step that overflowed, [1] number of skipped steps, [2] scratch.
+ * zero at start: [0] stamp of the last step that overflowed, [1] number of skipped steps, [2], [3] unused.
  * tnr_grad_nonfinite: if any of g[0 .. n) is inf or nan, guard[0] = max(guard[0], stamp) and guard[1] += 1 (stamp >= 1, the
- * caller's running count of optimiser steps).  tnr_amsgrad_step_guarded = tnr_amsgrad_step, except that (a) a launch whose
+ * caller's running count of optimiser steps; two launches: the scan, in which only a workgroup that found something touches
+ * guard, and a one-thread kernel that counts the skip).  tnr_amsgrad_step_guarded = tnr_amsgrad_step, except that (a) a launch whose
  * stamp equals guard[0] touches nothing: the skipped step; (b) Adam's bias corrections use step - (guard[1] - known_skips):
  * `step` is the caller's count of steps, known_skips how many skipped ones it has already taken out of that count (it learns of
  * a skip with a lag of up to two steps).  Stream-ordered, no host synchronisation; the caller reads guard back whenever it
