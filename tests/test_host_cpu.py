@@ -439,3 +439,62 @@ def test_step_cap_follows_the_per_epoch_resharding_gloo(tmp_path):
         assert [m0, m1] == [-(-sum(sizes[os.path.basename(f)] for f in fs) // 8) for fs in files]
         caps_seen.add((m0, m1))
     assert len(caps_seen) > 1                                # the file sets really changed between epochs
+
+
+def test_decode_worker_never_imports_torch():
+    """The spawned decoder of the resident feed must come up without torch (and must not touch a GPU): importing its module, and
+    decoding a batch in it, works in an interpreter where torch cannot be imported."""
+    import subprocess, sys
+    code = ("import sys; sys.modules['torch'] = None; sys.path.insert(0, %r)\n"
+            "import decode_worker as d\n"
+            "h, m, c, y = d.decode_lines([b'0\\tu\\tt\\tN1 N2 N9\\tN3\\tN4 N5'], {'N1': 1, 'N2': 2, 'N3': 3, 'N4': 4, 'N5': 5}, 4, 2)\n"
+            "assert h.tolist() == [[0, 1, 2, 0]] and m.tolist() == [[0.0, 1.0, 1.0, 1.0]], (h, m)\n"
+            "assert sorted(c[0].tolist()) == [3, 4, 5] and c[0, y[0]] == 3, (c, y)\n"
+            "assert 'torch' not in [k for k, v in sys.modules.items() if v is not None]\n") % os.path.join(os.path.dirname(GOLDEN), "..", "tiny-newsrec_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+
+
+def test_loss_scaler_host_logic():
+    """engine.LossScaler.poll (host half of the fp16 loss scale; the reference trains in fp32, run.py:134,194-195): an answer is
+    used exactly two steps after its step, an overflow halves the multiplier and takes the skipped step out of Adam's count,
+    `growth_interval` clean answers in a row double it (up to max_mult), 16 skips in a row warn once about a forward overflow."""
+    import logging
+    import engine as E
+
+    class Ev:
+        def synchronize(self):
+            pass
+    sc = E.LossScaler("cpu", True, growth_interval=3, max_mult=4.0)
+    assert not sc.enabled                      # no device: nothing is launched, poll is pure host logic
+    eng = types.SimpleNamespace(step_count=0, gscale=1024.0)
+    overflow_at = {4, 5, 12}
+    seen = []
+    for step in range(1, 16):
+        sc.poll(eng)                           # Engine.step: poll, then stamp += 1, launches, record
+        sc.stamp += 1
+        eng.step_count += 1
+        sc.pending.append((sc.stamp, [sc.stamp if sc.stamp in overflow_at else 0], Ev()))
+        seen.append((sc.mult, sc.skipped, eng.step_count))
+    # the answer of step s is read at the start of step s + 2
+    assert [m for m, _, _ in seen] == [1, 1, 1, 1, 2, 1, 0.5, 0.5, 0.5, 1, 1, 1, 2, 1, 1], seen
+    assert [k for _, k, _ in seen] == [0, 0, 0, 0, 0, 1, 2, 2, 2, 2, 2, 2, 2, 3, 3]
+    assert seen[-1][2] == 15 - 3               # three skipped steps taken out of Adam's count
+    sc.drain(eng)
+    assert not sc.pending
+    # sixteen skips in a row: one warning
+    sc2 = E.LossScaler("cpu", True)
+    eng2 = types.SimpleNamespace(step_count=100, gscale=1.0)
+    records = []
+    h = logging.Handler()
+    h.emit = records.append
+    logging.getLogger().addHandler(h)
+    try:
+        for s in range(1, 40):
+            sc2.stamp = s
+            sc2.pending.append((s, [s], Ev()))
+        sc2.drain(eng2)
+    finally:
+        logging.getLogger().removeHandler(h)
+    assert sc2.skipped == 39 and sc2.mult == 2.0 ** -20 and eng2.step_count == 100 - 39       # the multiplier stops at min_mult
+    assert sum("bf16" in r.getMessage() for r in records) == 1
