@@ -147,7 +147,7 @@ def test_gemm_nt_plain_loop_variant_bit_exact():
 @pytest.mark.parametrize("cus", [128, 100, 8])
 def test_gemm_grids_sized_for_fewer_cus_bit_exact(cus):
     """tnr_gemm_set_option "cus": the persistent kernels' grids and the NT panel plan sized for n CUs instead of the device's
-    (two GEMMs side by side on disjoint shares) - other panel heights, more tiles / units per
+    (two GEMMs side by side on disjoint shares, EXPERIMENTS.md section 4 item 20) - other panel heights, more tiles / units per
     workgroup, the same results on the step's launches."""
     L = T.lib()
     try:

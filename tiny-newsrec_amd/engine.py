@@ -580,7 +580,7 @@ class Engine:
 
     merge_reductions = True   # False: the partial-sum reductions per gradient bucket even without a bucket hook (tools/step_ab.py)
     group_wgrad = False  # True: a layer's weight gradients in one persistent launch (tnr_gemm_tn_wgrad_group; the same bits).  Measured
-                         # on one GPU: step +6.4 %, the four gradients 848 -> 1 088 us - one launch each,
+                         # on one GPU: step +6.4 %, the four gradients 848 -> 1 088 us (EXPERIMENTS.md section 4 item 22) - one launch each,
                          # one unit per workgroup, all units equal and in lockstep, is the better schedule; kept as a switch for the
                          # data-parallel case, where a workgroup held off its CU by a collective costs a quarter of what it costs now
     _wg = None           # the collected weight gradients while a layer's backward runs

@@ -1,4 +1,4 @@
-// Microbenchmark of a CU's store path: 256 workgroups (one per CU) x 8 waves, every wave issues
+// Microbenchmark of a CU's store path (EXPERIMENTS.md section 4 item 15): 256 workgroups (one per CU) x 8 waves, every wave issues
 // NST 16-byte-per-lane stores of registers it already holds, in one of several address patterns, into a buffer that stays in L2 /
 // into a large one; reports shader cycles per store instruction and per CU.   hipcc --offload-arch=gfx950 -O3 store_path.hip -o store_path
 #include <hip/hip_runtime.h>

@@ -1,6 +1,6 @@
 // PROTOTYPE (tools only, never linked into libtnr_hip.so): the 256 x 256 x 64 NT GEMM tile with FOUR waves of 128 x 128
 // (one per SIMD, 256 accumulator registers) and a software-pipelined K loop - the layout whose LDS traffic per K tile is
-// 128 KB of fragment reads instead of the eight-wave kernel's 192 KB.  Round 1's
+// 128 KB of fragment reads instead of the eight-wave kernel's 192 KB (EXPERIMENTS.md section 4, items 5 / 6).  Round 1's
 // version of this layout ("v7", tools/retired/) read all 16 fragments of a k half and then issued its 64 MFMAs, leaving
 // the interleave to the compiler: 20-40 % slower than eight waves.  Here the fragment reads of k half s+1 are placed
 // between the MFMA rows of half s at source level and pinned with sched_barrier.  fp16 only, plain store, M % 256 == 0.
