@@ -1,21 +1,23 @@
 """Check and time the hand-scheduled four-wave NT GEMM tile kernel (tools/w4_proto/gen_w4_hip.py -> libw4asm.so) against the shipped
 eight-wave kernel (tools only).
     python tools/w4_proto/gen_w4_hip.py [knobs] > /tmp/w4.hip && hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o tools/w4_proto/libw4asm.so /tmp/w4.hip
-    python tools/w4_proto/run_w4_asm.py [N K]           (LIB=<path> for another build of the prototype)"""
+    python tools/w4_proto/run_w4_asm.py [N K]           (LIB=<path> for another build of the prototype; SYM=w4r_launch for
+    gen_w4r_hip.py's register-staged form; PROBE_LIB=tools/_noepi/libtnr_hip.so adds the shipped kernel without its epilogue)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
 import torch, tnr_hip as T
 HERE = os.path.dirname(os.path.abspath(__file__))
 L = ctypes.CDLL(os.environ.get("LIB", os.path.join(HERE, "libw4asm.so")))
-L.w4_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+SYM = os.environ.get("SYM", "w4_launch")             # gen_w4r_hip.py: SYM=w4r_launch
+getattr(L, SYM).argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p]
 dev = "cuda:0"
-VAR = {"full": 0, "mfma": 1, "noread": 2, "nodma": 3, "noepi": 1}
+VAR = {"full": 0, "mfma": 1, "noread": 2, "nodma": 3, "noepi": 4 if SYM == "w4r_launch" else 1}
 VARIANTS = os.environ.get("VARIANTS", "full,mfma,nodma,noread").split(",")
 
 
 def launch(v, a, b, c, M, N, K):
-    rc = L.w4_launch(VAR[v], a.data_ptr(), b.data_ptr(), c.data_ptr(), a.stride(0) * 2, b.stride(0) * 2, c.stride(0) * 2, M, N, K,
+    rc = getattr(L, SYM)(VAR[v], a.data_ptr(), b.data_ptr(), c.data_ptr(), a.stride(0) * 2, b.stride(0) * 2, c.stride(0) * 2, M, N, K,
                      torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
 
@@ -78,8 +80,9 @@ def main():
                 spec = importlib.util.spec_from_file_location("tnr_probe", os.path.join(ROOT, "tiny-newsrec_amd", "tnr_hip.py"))
                 TP = importlib.util.module_from_spec(spec); spec.loader.exec_module(TP)
                 TP.LIB_PATH = os.path.join(ROOT, os.environ["PROBE_LIB"])
-                TP.lib().tnr_gemm_set_option(b"probe", 8)
-            res.setdefault("shipped 8-wave, no epilogue (probe 8)", []).append(
+                if "_noepi" not in TP.LIB_PATH:               # tools/_noepi (-DTNR_NOEPI) has no epilogue at all: the clean K loop
+                    TP.lib().tnr_gemm_set_option(b"probe", 8)
+            res.setdefault("shipped 8-wave, no epilogue", []).append(
                 timeit(lambda: TP.call("tnr_gemm_nt_ex_f16", a, K, b, K, c2, N, M, N, K, None, None, 0, None, 0, 0, None)))
     res = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
     for k, us in res.items():
