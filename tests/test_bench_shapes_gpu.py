@@ -22,6 +22,7 @@ M_BENCH = 52800                           # 32 impressions x 55 titles x 30 toke
 H, I, QPAD = 768, 3072, 256
 TD = {"bf16": torch.bfloat16, "fp16": torch.float16}
 EPS = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}      # one rounding of the 16-bit output
+TNPP_DEFAULT = 2                          # the library's default weight-gradient main loop (tnr_gemm_set_option "tnpp")
 PIN_ROUTES = [True]                                # False while a test sizes the grids for another CU count than the device's
 
 B_, G_, TH, R_, MD, F32O, AUX, CS = (T.EPI_BIAS, T.EPI_GELU, T.EPI_TANH, T.EPI_RES, T.EPI_MULDGELU, T.EPI_OUTF32, T.EPI_AUXOUT,
@@ -209,7 +210,41 @@ def test_gemm_tn_wgrad_plain_loop_variant_bit_exact():
         for name, N, K in WGRAD_LAUNCHES:
             test_gemm_tn_wgrad_bit_exact_at_bench_shape("fp16", name, N, K)
     finally:
-        L.tnr_gemm_set_option(b"tnpp", 1)
+        L.tnr_gemm_set_option(b"tnpp", TNPP_DEFAULT)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_gemm_tn_wgrad_register_staged_variant_bit_identical(dtype):
+    """The weight-gradient kernel's two ping-pong main loops (tnr_gemm_set_option "tnpp": 1 = operands by LDS-DMA + transposing
+    fragment reads, 2 = operands through registers, transposed there, fragment-ready LDS image) feed every MFMA the same operand
+    registers in the same order: integer-exact on the step's launches, and the SAME BITS on random operands."""
+    L = T.lib()
+    M, Mp = M_BENCH, (M_BENCH + 127) // 128 * 128
+    try:
+        for tnpp in (1, 2):
+            assert L.tnr_gemm_set_option(b"tnpp", tnpp) == 0
+            for name, N, K in WGRAD_LAUNCHES:
+                test_gemm_tn_wgrad_bit_exact_at_bench_shape(dtype, name, N, K)
+        import engine as E
+        g = torch.Generator(device=DEV); g.manual_seed(7)
+        for name, N, K in WGRAD_LAUNCHES:
+            dy = torch.zeros((Mp, N), device=DEV, dtype=TD[dtype]); x = torch.zeros((Mp, K), device=DEV, dtype=TD[dtype])
+            dy[:M] = (torch.randn((M, N), device=DEV, generator=g) * 0.1).to(TD[dtype])
+            x[:M] = torch.randn((M, K), device=DEV, generator=g).to(TD[dtype])
+            splits = E.Engine._wgrad_splits(N, K)[0]
+            ws = torch.zeros(T.query("tnr_gemm_tn_ws_elems" + _sfx(dtype), N, K, splits), device=DEV)
+            outs = []
+            for tnpp in (1, 2):
+                L.tnr_gemm_set_option(b"tnpp", tnpp)
+                dW = torch.zeros((N, K), device=DEV)
+                T.call("tnr_gemm_tn_wgrad" + _sfx(dtype), dy, N, x, K, dW, K, M, N, K, ws, splits, 0)
+                torch.cuda.synchronize()
+                outs.append(dW)
+            assert torch.equal(outs[0], outs[1]), name
+            ref = dy[:M].float().T @ x[:M].float()
+            assert (outs[1] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), name
+    finally:
+        L.tnr_gemm_set_option(b"tnpp", TNPP_DEFAULT)
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])

@@ -18,7 +18,7 @@ void tnr_set_error(const char* fmt, ...) {
 extern "C" const char* tnr_last_error(void) { return g_err; }
 extern "C" int tnr_version(void) { return 1; }
 
-static TnrGemmOpts g_gemm_opts = {3, 8, 60, 1, 0, 0, 1, 1, 1, 0, 0};
+static TnrGemmOpts g_gemm_opts = {3, 8, 60, 1, 0, 0, 1, 2, 1, 0, 0};
 TnrGemmOpts* tnr_gemm_opts() { return &g_gemm_opts; }
 
 extern "C" int tnr_gemm_set_option(const char* key, int value) {

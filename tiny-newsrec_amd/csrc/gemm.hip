@@ -75,6 +75,7 @@ __device__ __forceinline__ void tile_coords(int wg, int nbm, int nbn, int GM, in
 constexpr int LUT_N = 2048;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // node i holds {f(x_i), f(x_i+1) - f(x_i)}: ONE 8-byte gather per element on the 64-bank ds_read_b64 path
 __device__ __forceinline__ void lut_build(f32x2* lut, bool grad) {
     for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) {
@@ -1756,6 +1757,276 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNGroup grp) {
     leave();
 }
 
+// wgrad v5 "register-staged": the v4 tile, (split, tile) units, queue and ping-pong of two wave groups, with a different path from
+// memory to the MFMA operands and a different cut of the m step into phases.  Every MFMA gets the operand registers v4 gives it
+// and every accumulator sees half 0 of an m step before half 1, so the slabs are bit-identical to v4's.
+// What the round-5 barrier-arrival stamps showed (tools/tn_stamps.py, EXPERIMENTS item 32) and what follows from it:
+//   * beside the other group's MFMAs a vector instruction of a load segment -- LDS read, vector-memory, plain VALU alike -- gets
+//     one issue slot per MFMA, ~16 clk; in the wave's OWN MFMA segment it costs its 4-13 clk, nothing is free.  v4's load
+//     segments carry 48 ds_read_b64_tr_b16 + 8 LDS-DMA issues (~100 clk each) + address arithmetic per wave and step;
+//   * a CU accepts vector-memory instructions at ~30 B / clk: all the loads of a step issued by four waves in one segment (v4's
+//     phase 3: 24 KB; the first register-staged form: 32 KB) hold that segment for 1 000-1 200 clk;
+//   * every barrier-to-barrier interval costs ~100 clk on top of its MFMAs.
+// Hence:
+//   * operands through registers: a lane loads, one m step ahead, the 16-byte rows of an 8-column strip -- 4 rows of each 32-row
+//     half of the step ("set A", "set B", 4 buffer_load_dwordx4 each) --, transposes a set with 16 v_perm_b32 into its 8 bytes of
+//     8 fragments "one column, eight rows" of the 16x16x32 operand and stores them with 8 ds_write_b64 into a FRAGMENT-READY
+//     image: fragment (operand, 16-column block, 32-row half) = 1 KB, lane-linear for the reading lane (g = lane >> 4: row
+//     octet, r = lane & 15: column): 24 ds_read_b128 per wave and step instead of 48 transposing reads, no LDS-DMA, and every
+//     LDS address a register + immediate.  16-byte slot of (g, r) in a fragment:  16 g + 8 (r >> 3) + ((r & 7) ^ key),
+//     key = (block & 3) | ((r >> 3) << 2): the 16 lanes of a ds_write_b64 cycle (8 column strips = 8 keys, x the two 4-row
+//     halves of a row octet) cover the 128-byte bank row once, the 16 lanes of a ds_read_b128 cycle the 256-byte one
+//     (tools/scratch/tn_rs_image_check.py walks both maps);
+//   * the transposition and the stores ride in the wave's own MFMA segments (one v_perm_b32 behind each of 16 MFMAs), the address
+//     updates too; a load segment is fragment reads + 4 loads and nothing else;
+//   * two phases per m step instead of four: phase S = 12 fragment reads of 32-row half S (X 4, dY 8) + the 4 loads of the set
+//     the MFMA segment before has stored | 32 MFMAs (8 dY blocks x 4 X blocks) + the staging of set S of step t + 1.  A load has
+//     two intervals (~0.9 us) to land; 16 KB of loads per interval.
+// Hazards.  Stage (t + 1) & 1 receives half 0 of step t + 1 in the MFMA segments A of step t and half 1 in the segments B; group 1
+// runs one interval behind group 0 (intervals of a step: group 0 L_A 0, M_A 1, L_B 2, M_B 3; group 1 L_A 1, M_A 2, L_B 3,
+// M_B 4 = 0 of the next step); a load segment ends with lgkmcnt(0) BEFORE its barrier, so a wave's LDS operations of an interval
+// are complete when the next but one begins at the latest (stores of an MFMA segment: by the end of the wave's next load segment).
+//   RAW  half 0 of step t + 1: stored in intervals 1-2 of step t, complete by the end of interval 3, first read in interval 0 of
+//        step t + 1.  half 1: stored in intervals 3-4, complete by the end of interval 1 of step t + 1, first read in its interval 2.
+//   WAR  half 0 of step t - 1 (same stage): last read in interval 1 of step t - 1 ... overwritten from interval 1 of step t;
+//        half 1: last read in interval 3 of step t - 1, overwritten from interval 3 of step t.
+constexpr int RS_OP = 2 * TILE_BYTES;        // dY image | X image, 32 KB each per stage
+// LDS accesses by 32-bit LDS address (the address of `smem` folded into the per-lane base once): `smem + offset` costs a v_add per
+// access otherwise, and a vector instruction in a load segment waits ~16 clk for its issue slot
+#define TNR_LDS(T, ADDR) (*(__attribute__((address_space(3))) T*)(size_t)(ADDR))
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
+#ifdef TNR_TN_STAMPS
+// probe build only (make BUILD=../../tools/_tnst EXTRA=-DTNR_TN_STAMPS, tools/tn_stamps.py): every wave records s_memtime at its
+// ARRIVAL at each of the 4 barriers of m steps 32-95 (the stamp rides in front of the barrier, its latency under the barrier wait)
+// into LDS; copied out after the workgroup's first unit: [wg][wave][0..3] = memtime / memrealtime at the unit's start and end,
+// [4] = its m steps, [8 + 4 (t - 32) + k] = arrival at barrier k of step t.  The product library has none of this.
+constexpr int TN_STAMP_WORDS = 264, TN_STAMP_T0 = 32, TN_STAMP_NT = 64, TN_STAMP_NB = 4;     // per wave: 8 header words + 64 steps x 4 barriers
+__device__ unsigned tnr_tn_stamp_buf[256][8][TN_STAMP_WORDS];
+constexpr int RS_LDS = RING3 + 64 + 8 * TN_STAMP_WORDS * 4;
+#define TNR_RS_BARRIER(K)                                                                                      \
+    do {                                                                                                       \
+        unsigned long long ts_;                                                                                \
+        asm volatile("s_memtime %0\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");              \
+        if (lane == 0 && t >= TN_STAMP_T0 && t < TN_STAMP_T0 + TN_STAMP_NT) stamps[w * TN_STAMP_WORDS + 8 + TN_STAMP_NB * (t - TN_STAMP_T0) + (K)] = (unsigned)ts_; \
+    } while (0)
+#else
+constexpr int RS_LDS = RING3 + 64;
+#define TNR_RS_BARRIER(K) __builtin_amdgcn_s_barrier()
+#endif
+__global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w >> 2, wk = w & 3;          // wave tile: 128 n x 64 k
+    unsigned* const queue = grp.queue;
+    const int xcd = blockIdx.x & 7;
+    int c0 = grp.xb[0], c1 = grp.xb[1];
+#pragma unroll
+    for (int x = 1; x < 8; ++x)
+        if (xcd == x) { c0 = grp.xb[x]; c1 = grp.xb[x + 1]; }
+    int* const qlds = (int*)(smem + RING3);
+#ifdef TNR_TN_STAMPS
+    unsigned* const stamps = (unsigned*)(smem + RING3 + 64);
+    bool stamped = false;
+#endif
+    unsigned q0;
+    pp_q_fetch(q0, queue + xcd * PP_Q_STRIDE, w == 0);
+    auto leave = [&]() {                                 // last workgroup out zeroes the counters for the next launch
+        if (tid == 0) {
+            const unsigned d = __hip_atomic_fetch_add(queue + 8 * PP_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == gridDim.x - 1)
+                for (int i = 0; i < 9; ++i)
+                    __hip_atomic_store(queue + i * PP_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // reader side: slot of this lane in a fragment, for the four values of block & 3
+    int raddr[4];
+    {
+        const int r16 = lane & 15, g4 = lane >> 4, rhi = r16 >> 3, rl = (r16 & 7) ^ (rhi << 2);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) raddr[v] = (g4 * 16 + rhi * 8 + (rl ^ v)) * 16;
+    }
+    // staging side: waves 0-3 carry dY, 4-7 X; wave q of the four owns m octet q of BOTH 32-row halves; a lane owns rows 4 sh ..
+    // 4 sh + 3 of the octet (sh = lane bit 3) and column octet sc (of the tile's 32): 8 consecutive lanes load one 128-byte line
+    // and the 16 lanes of a ds_write_b64 cycle cover 8 slots x 2 halves = the whole 128-byte bank row
+    const int sop = w >> 2, sq = w & 3, sh = (lane >> 3) & 1, sc = ((lane >> 4) << 3) | (lane & 7);
+    const int waddr = ((sop * RS_OP + (((sc >> 1) * 2) * 64 + sq * 16 + (sc & 1) * 8) * 16) ^
+                       (((((sc >> 1) & 3) | ((sc & 1) << 2))) << 4)) + 8 * sh;     // half 0; half 1 = + 1024
+    pp_q_wait(q0);
+    if (tid == 0) qlds[0] = c0 + (int)q0;
+    __syncthreads();
+    int unit = qlds[0];
+    if (unit >= c1) { leave(); return; }                 // whole workgroup, before any other barrier
+  while (true) {
+    const int su = __builtin_amdgcn_readfirstlane(unit);
+    TNArgs g = grp.p[0];
+    int lu = su;
+    if (su >= grp.ubase[1]) { g = grp.p[1]; lu = su - grp.ubase[1]; }
+    if (su >= grp.ubase[2]) { g = grp.p[2]; lu = su - grp.ubase[2]; }
+    if (su >= grp.ubase[3]) { g = grp.p[3]; lu = su - grp.ubase[3]; }
+    const int nbk = g.K >> 8;
+    const int ntile = (g.N >> 8) * nbk;
+    const int z = lu / ntile, tile = lu - z * ntile;
+    const int bn = tile / nbk, bk = tile - bn * nbk;
+    const int mt0 = z * g.tiles_per_split;
+    int mt1 = mt0 + g.tiles_per_split;
+    if (mt1 > g.Mt) mt1 = g.Mt;
+    const int nk = mt1 - mt0;
+    unsigned qn;                                         // lane 0 of wave 0: the next unit, in flight during this one (oldest operation)
+    pp_q_fetch(qn, queue + xcd * PP_Q_STRIDE, w == 0);
+
+    // this wave's operand as a raw buffer that starts at (first row of the unit, first column of the tile) and ends with the unit's
+    // last row: the loads the pipeline issues for the two steps past the end return zeros without touching memory
+    const int ld = sop ? (int)g.ldx : (int)g.lddy;
+    const bf16* const opnd = sop ? g.X + ((int64_t)mt0 * 64 * g.ldx + bk * 256) : g.dY + ((int64_t)mt0 * 64 * g.lddy + bn * 256);
+    const int64_t extent = ((int64_t)nk * 64 * ld - (sop ? bk : bn) * 256) * 2;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)opnd, 0, (int)(extent > 0x7fffffff ? 0x7fffffff : extent), 0x00020000);
+    const int voff = ((sq * 8 + sh * 4) * ld + sc * 8) * 2;
+    const int row_b = ld * 2, step_b = 64 * ld * 2;
+    u32x4 in[8];                                // set A = the lane's 4 rows in half 0 of an m step, set B = in half 1
+    auto fetch = [&](int t, int half) {         // 4 rows of half `half` of m step t -> registers
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            in[4 * half + e] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, t * step_b + (32 * half + e) * row_b, 0);
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#ifdef TNR_TN_STAMPS
+    if (lane == 0) {
+        stamps[w * TN_STAMP_WORDS + 0] = (unsigned)__builtin_amdgcn_s_memtime();
+        stamps[w * TN_STAMP_WORDS + 1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+        stamps[w * TN_STAMP_WORDS + 4] = (unsigned)nk;
+    }
+#endif
+    if (nk > 0) {
+// end of a load segment: the wave's LDS operations complete BEFORE the barrier (the other group reads this wave's stores of the MFMA
+// segment before, and overwrites what it has just read, right behind barriers; see Hazards)
+#define TNR_PP_SEG_END(K)                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    TNR_RS_BARRIER(K);                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    __builtin_amdgcn_s_setprio(1)
+#define TNR_PP_MFMA_END(K)                                          \
+    __builtin_amdgcn_s_setprio(0);                                  \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    TNR_RS_BARRIER(K);                                              \
+    __builtin_amdgcn_sched_barrier(0)
+// the segment's 32 MFMAs (8 dY blocks x 4 X blocks over 32-row half S); behind each of the first 16 one v_perm_b32 of the
+// transposition of register set S (step t + 1's rows of half S -> the lane's 8 bytes of 8 fragments), after every fourth the two
+// ds_write_b64 of a dword column; with S == 1 the 16 LDS addresses move to the other stage behind the last 16 MFMAs
+#define TNR_RS_MFMAS(S)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                  \
+        u32x2 lo, hi;                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+            acc[i][j] = TNR_MFMA_16x16x32(xf[j], yf[i], acc[i][j], 0, 0, 0);                                         \
+            if (i < 4) {                                  /* MFMA row i carries dword column i of the block */       \
+                const int e = 4 * (S) + 2 * (j & 1);                                                                 \
+                if (j < 2) lo[j & 1] = __builtin_amdgcn_perm(in[e + 1][i], in[e][i], 0x05040100u);                   \
+                else hi[j & 1] = __builtin_amdgcn_perm(in[e + 1][i], in[e][i], 0x07060302u);                         \
+            } else if ((S) == 1 && i < 6) {                                                                          \
+                if (j < 2) ray[2 * (i - 4) + j] += dlt; else rax[2 * (i - 4) + j - 2] += dlt;                        \
+            } else if ((S) == 1) {                                                                                   \
+                wa[4 * (i - 6) + j] -= dlt;                                                                          \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        if (i < 4) {                                                                                                 \
+            TNR_LDS(u32x2, wa[2 * i] + 1024 * (S)) = lo;                                                             \
+            TNR_LDS(u32x2, wa[2 * i + 1] + 1024 * (S)) = hi;                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+    }
+#define TNR_RS_READS(S)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[j] = TNR_LDS(const bf16x8, rax[j] + (j * 2 + (S)) * 1024);      \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) yf[i] = TNR_LDS(const bf16x8, ray[i & 3] + (i * 2 + (S)) * 1024);  \
+    __builtin_amdgcn_sched_barrier(0)
+        bf16x8 yf[8], xf[4];
+        unsigned ray[4], rax[4], wa[8];                     // LDS addresses: fragment reads (dY / X, by block & 3), the 8 stores
+        const unsigned lds0 = lds_addr_of(smem);
+        unsigned dlt = STAGE3;                              // reads move stage 0 -> 1 -> 0 ..., the stores of step t + 1 the other way
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { ray[v] = lds0 + raddr[v] + wn * (8 * 2048); rax[v] = lds0 + raddr[v] + RS_OP + wk * (4 * 2048); }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) wa[f] = lds0 + (waddr ^ (f << 4));
+        {                                                   // step 0 -> stage 0 through registers the loop does not hold yet, so that
+            u32x4 p0[8];                                    // set A of step 1 is in flight beside it (a unit of 30 steps notices)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p0[e] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (32 * (e >> 2) + (e & 3)) * row_b, 0);
+            fetch(1, 0);                                    // (set B of step 1 is loaded in the first load segment)
+#pragma unroll
+            for (int S = 0; S < 2; ++S)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u32x2 lo, hi;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        lo[q] = __builtin_amdgcn_perm(p0[4 * S + 2 * q + 1][i], p0[4 * S + 2 * q][i], 0x05040100u);
+                        hi[q] = __builtin_amdgcn_perm(p0[4 * S + 2 * q + 1][i], p0[4 * S + 2 * q][i], 0x07060302u);
+                    }
+                    TNR_LDS(u32x2, wa[2 * i] + 1024 * S) = lo;
+                    TNR_LDS(u32x2, wa[2 * i + 1] + 1024 * S) = hi;
+                }
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) wa[f] += STAGE3;        // the loop's stores of step t go to stage (t + 1) & 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // m step 0 is in LDS
+        if (wn == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 runs one interval behind
+        for (int t = 0; t < nk; ++t) {
+            TNR_RS_READS(0);
+            fetch(t + 1, 1);                                // set B went to LDS in the MFMA segment before
+            TNR_PP_SEG_END(0);
+            TNR_RS_MFMAS(0);                                // + set A (half 0 of step t + 1) -> LDS
+            TNR_PP_MFMA_END(1);
+            TNR_RS_READS(1);
+            fetch(t + 2, 0);
+            TNR_PP_SEG_END(2);
+            TNR_RS_MFMAS(1);                                // + set B (half 1 of step t + 1) -> LDS, addresses to the other stage
+            dlt = 0u - dlt;
+            TNR_PP_MFMA_END(3);
+        }
+        if (wn == 0) __builtin_amdgcn_s_barrier();          // all waves execute the same number of barriers
+#undef TNR_RS_READS
+#undef TNR_RS_MFMAS
+#undef TNR_PP_SEG_END
+#undef TNR_PP_MFMA_END
+    }
+#ifdef TNR_TN_STAMPS
+    if (lane == 0) {
+        stamps[w * TN_STAMP_WORDS + 2] = (unsigned)__builtin_amdgcn_s_memtime();
+        stamps[w * TN_STAMP_WORDS + 3] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    }
+    __syncthreads();
+    if (!stamped && blockIdx.x < 256)
+        for (int i = tid; i < 8 * TN_STAMP_WORDS; i += 512) (&tnr_tn_stamp_buf[blockIdx.x][0][0])[i] = stamps[i];
+    stamped = true;
+#endif
+    pp_q_wait(qn);
+    if (tid == 0) qlds[1] = c0 + (int)qn;
+    float* slab = g.ws + (int64_t)z * g.N * g.K;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int n = bn * 256 + wn * 128 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k = bk * 256 + wk * 64 + j * 16 + (lane >> 4) * 4;
+            *(f32x4*)(slab + (int64_t)n * g.K + k) = acc[i][j];
+        }
+    }
+    __syncthreads();                                     // qlds[1] visible ; every fragment read of this unit is long complete
+    const int next = qlds[1];
+    if (next >= c1) break;
+    unit = next;
+    __syncthreads();                                     // qlds[1] is rewritten only after everybody has read it
+  }
+    leave();
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t NK, int K, float* out,
                                    int64_t ldo, int accumulate, float out_scale) {
     int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -2076,6 +2347,7 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
         (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_tn256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3 + 64);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_rs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
     });
     if (ver == 1 || (N % 256) != 0) {
         dim3 grid((unsigned)((N / 128) * (K / 128) * splits));
@@ -2094,7 +2366,8 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
             if (!(grp.queue = pp_queue_of((hipStream_t)stream))) return TNR_EUNSUPPORTED;
             const int n_cu = device_cus();
             dim3 pgrid((unsigned)std::min<int64_t>((int64_t)grid.x, std::max(n_cu, 8)));
-            hipLaunchKernelGGL(gemm_tn_pp_kernel, pgrid, dim3(512), RING3 + 64, (hipStream_t)stream, grp);
+            if (tnr_gemm_opts()->tnpp == 2) hipLaunchKernelGGL(gemm_tn_rs_kernel, pgrid, dim3(512), RS_LDS, (hipStream_t)stream, grp);
+            else hipLaunchKernelGGL(gemm_tn_pp_kernel, pgrid, dim3(512), RING3 + 64, (hipStream_t)stream, grp);
         }
         else hipLaunchKernelGGL(gemm_tn256x256_kernel, grid, dim3(512), RING3, (hipStream_t)stream, g);
     }
@@ -2154,16 +2427,24 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_group)(const tnr_wgrad_problem_t* p, i
     tn_group_ranges(grp, n);
     TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3 + 64);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_rs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
     });
     if (!(grp.queue = pp_queue_of((hipStream_t)stream))) return TNR_EUNSUPPORTED;
     const int n_cu = device_cus();
-    hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((unsigned)std::min<int64_t>(units, std::max(n_cu, 8))), dim3(512), RING3 + 64,
-                       (hipStream_t)stream, grp);
+    const dim3 ggrid((unsigned)std::min<int64_t>(units, std::max(n_cu, 8)));
+    if (tnr_gemm_opts()->tnpp == 2) hipLaunchKernelGGL(gemm_tn_rs_kernel, ggrid, dim3(512), RS_LDS, (hipStream_t)stream, grp);
+    else hipLaunchKernelGGL(gemm_tn_pp_kernel, ggrid, dim3(512), RING3 + 64, (hipStream_t)stream, grp);
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad_group");
     hipLaunchKernelGGL(slab_reduce_group_kernel, dim3((unsigned)maxblk, (unsigned)n), dim3(256), 0, (hipStream_t)stream, sg);
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad_group/reduce");
     return TNR_OK;
 }
+
+#ifdef TNR_TN_STAMPS
+extern "C" int TNR_NAME(tnr_debug_tn_stamps)(void* host_dst, int64_t bytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(tnr_tn_stamp_buf), (size_t)bytes) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int TNR_NAME(tnr_gemm_tn_wgrad)(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
                                  int64_t lddw, int64_t M, int64_t N, int64_t K, float* ws, int splits,

@@ -32,8 +32,13 @@ for (N, K) in ((3072, 768), (768, 3072), (2304, 768), (768, 768), (256, 768)):
             for _ in range(10): run()
             e1.record(); torch.cuda.synchronize()
             acc[v].append(e0.elapsed_time(e1) * 100)
+    outs = []
+    for v in (0, 1):                                  # the two variants' results on the same random operands, bit for bit
+        T.lib().tnr_gemm_set_option(KEY.encode(), int(VALS[v]))
+        dw.zero_(); run(); torch.cuda.synchronize(); outs.append(dw.clone())
+    same = torch.equal(outs[0], outs[1])
     m0, m1 = sorted(acc[0])[4], sorted(acc[1])[4]
     tot[0] += m0; tot[1] += m1
-    print("dW %4d x %4d splits %2d: %s=%s %.1f us (%.0f TF)   %s=%s %.1f us (%.0f TF)   (%+.1f %%)  [incl. slab reduce]" % (
-        N, K, sp, KEY, VALS[0], m0, 2.0 * M * N * K / m0 / 1e6, KEY, VALS[1], m1, 2.0 * M * N * K / m1 / 1e6, 100 * (m1 - m0) / m0), flush=True)
+    print("dW %4d x %4d splits %2d: %s=%s %.1f us (%.0f TF)   %s=%s %.1f us (%.0f TF)   (%+.1f %%)  [incl. slab reduce]  bit-identical: %s" % (
+        N, K, sp, KEY, VALS[0], m0, 2.0 * M * N * K / m0 / 1e6, KEY, VALS[1], m1, 2.0 * M * N * K / m1 / 1e6, 100 * (m1 - m0) / m0, same), flush=True)
 print("sum: %.1f us vs %.1f us (%+.1f %%)" % (tot[0], tot[1], 100 * (tot[1] - tot[0]) / tot[0]))
