@@ -165,7 +165,15 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the timed legs of the other BASELINE.json configurations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--concat-batches", action="store_true",
+                    help="tests only: the ranks' batches of a step are consecutive slices of ONE batch of world x B impressions drawn from "
+                         "a common seed (so that a one-rank run with --batch world x B sees the concatenation); default: per-rank seeds")
     a = ap.parse_args()
+    # tests only (tests/test_dropin_gpu.py): TNR_BENCH_BACKEND=gloo runs the world > 1 path - self_launch, per-rank batches, bucketed
+    # all-reduce with its waits, max over ranks, the dp object, --dp-sweep - as N processes over gloo, TNR_BENCH_SHARE_GPU=1 puts them
+    # all on GPU 0, TNR_BENCH_DUMP_PARAMS=<file.npy> saves a sample of the trained parameters.  No throughput claim comes from it.
+    backend = os.environ.get("TNR_BENCH_BACKEND") or None
+    share_gpu = os.environ.get("TNR_BENCH_SHARE_GPU") == "1"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
 
@@ -183,9 +191,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=0, world_size=1)
-    world, rank, local = D.init()
+    world, rank, local = D.init(backend)
     if world != a.gpus:
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (a.gpus, world))
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     trainable = tuple(a.trainable) if a.trainable else (a.layers - 2, a.layers - 1)
@@ -198,8 +208,12 @@ def main():
     E.Engine.WGRAD_UNITS = wgrad_units           # before any engine is built: the slab workspace is sized by it
     comb = torch.from_numpy(synth.news_table(seed, N_NEWS, cfg.L)).to(dev)
     tables = torch.from_numpy(synth.teacher_tables(seed, max(a.teachers, 1), N_NEWS, cfg.D)).to(dev)
-    hidx, mask, cidx, label = [torch.from_numpy(x).to(dev) for x in
-                               synth.impressions(seed + 1 + rank, (K + W) * B, N_NEWS, cfg.U, cfg.C)]
+    if a.concat_batches:
+        imp = [x.reshape((K + W, world, B) + x.shape[1:])[:, rank].reshape(((K + W) * B,) + x.shape[1:])
+               for x in synth.impressions(seed + 1, (K + W) * B * world, N_NEWS, cfg.U, cfg.C)]
+    else:
+        imp = synth.impressions(seed + 1 + rank, (K + W) * B, N_NEWS, cfg.U, cfg.C)
+    hidx, mask, cidx, label = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in imp]
     plans = None
     if a.dedup != "off":
         from dedup import build_plan
@@ -272,25 +286,49 @@ def main():
     TKEY = "tnr_gemm_nt_ex_f16" if a.dtype == "fp16" else "tnr_gemm_nt_ex"
     dt = timed_loop(eng, gs, a.dedup == "only", None if a.no_kernel_timing else TKEY)
     rec = timed_rec or None
+    if rank == 0 and os.environ.get("TNR_BENCH_DUMP_PARAMS"):
+        np.save(os.environ["TNR_BENCH_DUMP_PARAMS"], eng.flat[True][::97].float().cpu().numpy())
     dp_info = None
     if use_dp:
         # the data-parallel leg explains itself: bucket sizes in completion order and, per bucket, how long the compute stream
         # stood still behind its all-reduce (events around GradSync.wait_bucket on the stream Engine.step runs on) -- what the
         # overlap with backward did NOT hide.  Max over ranks of the per-step sum.
         ex = gs.exposed_ms()
-        per_bucket = [round(sum(ex.get(b, [0.0])) / max(len(ex.get(b, [])), 1), 4) for b in range(len(gs.ranges))]
+        per_bucket = [round(sum(ex.get(g, [0.0])) / max(len(ex.get(g, [])), 1), 4) for g in range(len(gs.groups))]
         tot = torch.tensor([sum(per_bucket)], device=dev, dtype=torch.float64)
         try:
             rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception:
             rccl = None
+        # what stays serial behind the LAST collective on the fp16 path (the per-bucket scans of the earlier buckets hide under
+        # the collectives still in flight): 8 more steps with the guard kernels and the update bracketed by events
+        tail = None
+        if eng.scaler.enabled:
+            names = ("tnr_grad_nonfinite_scan", "tnr_grad_nonfinite_commit", "tnr_amsgrad_step_guarded")
+            recs = {n_: [] for n_ in names}
+            T.TIMED.update(recs)
+            n_tail = min(8, K)
+            for i in range(W, W + n_tail):
+                one_step(eng, gs, i, False)
+            torch.cuda.synchronize()
+            for n_ in names:
+                T.TIMED.pop(n_, None)
+            ms_of = lambda n_: sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs[n_]) / n_tail
+            nb = max(len(gs.ranges), 1)
+            last = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs[names[0]][nb - 1::nb]) / n_tail if recs[names[0]] else 0.0
+            tail = {"scans": round(ms_of(names[0]), 4), "last_scan": round(last, 4), "commit": round(ms_of(names[1]), 4),
+                    "amsgrad": round(ms_of(names[2]), 4),
+                    "note": "fp16: every bucket is scanned for inf / nan behind its own all-reduce; only the last scan, the commit and the "
+                            "guarded update are serial behind the last collective (bf16: no guard, the update runs bucket by bucket)"}
+            gs._events = []
         dp_info = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                   "fp16_tail_ms_per_step": tail,
                    "rccl_version": rccl, "algo": gs.algo, "wgrad_units_per_workgroup": wgrad_units,
                    "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                           "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY")},
                    "collectives_mb_in_launch_order": [round(x / 1e6, 2) for x in gs.collective_bytes()],
                    "bucket_mb_in_completion_order": [round(x / 1e6, 2) for x in gs.bucket_bytes()],
-                   "exposed_allreduce_ms_per_step_by_bucket_rank0": per_bucket,
+                   "exposed_allreduce_ms_per_step_by_collective_rank0": per_bucket,
                    "exposed_allreduce_ms_per_step_max_over_ranks": round(float(D.all_reduce_max(tot).item()), 4),
                    "note": "all-reduce(sum) of fp32 gradients, 1/world folded into AMSGrad; every bucket but the last is launched "
                            "while backward still runs"}

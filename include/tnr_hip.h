@@ -394,6 +394,12 @@ int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, 
  * a skip with a lag of up to two steps).  Stream-ordered, no host synchronisation; the caller reads guard back whenever it
  * likes (tiny-newsrec_amd/engine.py: LossScaler).  guard == NULL: unguarded. */
 int tnr_grad_nonfinite(const float* g, int64_t n, unsigned* guard, unsigned stamp, void* stream);
+/* the same in pieces, for a gradient that arrives bucket by bucket (data parallelism: each bucket is scanned as soon as its
+ * all-reduce has landed, beside the collectives still in flight): any number of _scan launches over disjoint slices with one
+ * stamp (they only ever raise guard[0] to it), then ONE _commit that counts the skipped step.  scan(all) + commit ==
+ * tnr_grad_nonfinite. */
+int tnr_grad_nonfinite_scan(const float* g, int64_t n, unsigned* guard, unsigned stamp, void* stream);
+int tnr_grad_nonfinite_commit(unsigned* guard, unsigned stamp, void* stream);
 int tnr_amsgrad_step_guarded(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, int step,
                              float lr, float beta1, float beta2, float eps, float grad_scale, const unsigned* guard,
                              unsigned stamp, unsigned known_skips, void* stream);

@@ -249,6 +249,7 @@ def main():
     golden_stage0(R)
     golden_configs(R)
     golden_pretrained_like(R)
+    golden_trajectory(R)
 
 
 def golden_configs(R):
@@ -262,6 +263,64 @@ def golden_configs(R):
     np.savez_compressed(os.path.join(HERE, "full_model_5.npz"), **rec)
     print("full 5 (configs[4] stage 2)", rec["total"], rec["distill"], rec["emb"], rec["target"])
     golden_stage1(R, only=("cfg4",))
+
+
+def golden_trajectory(R, steps=50, n_batches=5, seed=61):
+    """A TRAINING TRAJECTORY of the reference (Tiny-NewsRec/run.py:173-200: forward, zero_grad, backward, Adam(amsgrad).step,
+    lr 1e-4 as in demo.sh:11): 2-layer student (train 0-1), 2 teachers, B = 2, U = 50, C = 5, L = 30, `steps` steps over a cycle
+    of `n_batches` fixed batches.  Committed: the batches, the four losses and the scores of every step (each taken BEFORE that
+    step's update, as the loop logs them) and 64 samples of every trainable parameter at the end.  The parity evidence of the other
+    goldens stops at two optimiser steps; this one shows the 16-bit engine with its dynamic loss scale following the reference's
+    fp32 trajectory."""
+    nl, T, B, trainable = 2, 2, 2, (0, 1)
+    cfg_json = dict(ref_shim.BASE_CFG, num_hidden_layers=nl)
+    a = ref_shim.make_args(config_name=ref_shim.write_config(cfg_json), num_teachers=T, batch_size=B, num_student_layers=nl,
+                           user_log_mask=False, temperature=1.0, coef=0.2)
+    model = R.model_bert.Model(a)
+    fill(model, seed)
+    for p in model.teachers.parameters():
+        p.requires_grad = False
+    for p in model.student.news_encoder.bert_model.parameters():
+        p.requires_grad = False
+    for i, layer in enumerate(model.student.news_encoder.bert_model.bert.encoder.layer):
+        if i in trainable:
+            for p in layer.parameters():
+                p.requires_grad = True
+    L = a.num_words_title
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    batches = [make_inputs(seed + 1 + i, B, a.user_log_length, a.npratio + 1, L, cfg_json["vocab_size"], T, a.news_dim) for i in range(n_batches)]
+    lr = 1e-4
+    opt = torch.optim.Adam(model.parameters(), lr=lr, amsgrad=True)              # run.py:134
+    rec = dict(meta=np.array([seed, B, T, a.user_log_length, a.npratio + 1, L, a.news_dim, cfg_json["num_attention_heads"], nl]),
+               trainable=np.array(sorted(trainable)), flags=np.array([0.0, 1.0, 0.2]), lr=np.array([lr]), steps=np.array([steps]),
+               n_batches=np.array([n_batches]))
+    for i, (hist, mask, cand, label, th, tc) in enumerate(batches):
+        rec.update({"in_hist_b%d" % i: hist, "in_mask_b%d" % i: mask, "in_cand_b%d" % i: cand, "in_label_b%d" % i: label})
+        for j in range(T):
+            rec["in_th%d_b%d" % (j, i)] = th[j]
+            rec["in_tc%d_b%d" % (j, i)] = tc[j]
+    losses, scores = np.zeros((steps, 4)), np.zeros((steps, B, a.npratio + 1), np.float32)
+    for step in range(steps):
+        hist, mask, cand, label, th, tc = batches[step % n_batches]
+        total, distill, emb, target, score = model(tt(hist), tt(mask), tt(cand), tt(label), [tt(x) for x in th], [tt(x) for x in tc])
+        losses[step] = total.item(), distill.item(), emb.item(), target.item()
+        scores[step] = score.detach().numpy()
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        if step % 10 == 0:
+            print("trajectory step", step, losses[step])
+    rec["losses"], rec["scores"] = losses, scores          # columns: total, distill, emb, target
+    names = []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        names.append(n)
+        idx, val = grad_samples(seed, "traj." + n, p.detach().numpy())
+        rec["widx." + n], rec["wval." + n] = idx, val
+    rec["param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "trajectory_0.npz"), **rec)
+    print("trajectory_0", losses[0], losses[-1])
 
 
 def golden_pretrained_like(R):
@@ -676,6 +735,8 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "hf":
         golden_plmnr_hf("bert", 51)
         golden_plmnr_hf("roberta", 52)
+    elif len(sys.argv) > 1 and sys.argv[1] == "trajectory":
+        golden_trajectory(ref_shim.load_reference())
     elif len(sys.argv) > 1 and sys.argv[1] == "dropout":
         golden_stage1_dropout(ref_shim.load_reference())
     else:

@@ -37,6 +37,20 @@ def load_case(name):
     return z, P, cfg, inp
 
 
+def load_trajectory_case(name="trajectory_0.npz"):
+    """Reference training trajectory (make_golden.golden_trajectory) -> (z, P, cfg, [batch inputs], lr, steps)."""
+    z = np.load(os.path.join(GOLDEN, name))
+    seed, B, T, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
+    P = hashinit.init_state_dict(seed, state_shapes(FULL, nl, D, T))
+    ulm, tau, coef = [float(x) for x in z["flags"]]
+    cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]], user_log_mask=bool(ulm), temperature=tau,
+               coef=coef, pooling="att", nrms_heads=0)
+    batches = [(z["in_hist_b%d" % i], z["in_mask_b%d" % i], z["in_cand_b%d" % i], z["in_label_b%d" % i],
+                [z["in_th%d_b%d" % (j, i)] for j in range(T)], [z["in_tc%d_b%d" % (j, i)] for j in range(T)])
+               for i in range(int(z["n_batches"][0]))]
+    return z, P, cfg, batches, float(z["lr"][0]), int(z["steps"][0])
+
+
 def load_stage1_case(name):
     """Stage-1 KD golden (Post-train_KD.ipynb DistillModel) -> (z, P, cfg, inputs)."""
     z = np.load(os.path.join(GOLDEN, name))

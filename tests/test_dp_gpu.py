@@ -113,3 +113,42 @@ def test_bucketwise_optimiser_step_is_bit_identical_to_one_launch(rates):
         assert torch.equal(a, b)
     rng = outs[0][0]
     assert not torch.equal(rng, torch.from_numpy(np.zeros(1, np.float32)).to(rng.device).expand_as(rng))
+
+
+def test_fp16_guarded_step_scans_bucket_by_bucket_and_skips_as_one():
+    """fp16 under data parallelism (Engine.step(sync=...) with the dynamic loss scale's guard): every bucket is scanned for inf /
+    nan behind its own collective, in completion order, and the update follows the LAST scan - a clean step is bit-identical to the
+    one-launch guarded step, and one non-finite value in the bucket that arrives LAST (or in the first) leaves every slice,
+    the early buckets' too, untouched and counts one skipped step."""
+    import torch
+    import engine as E
+    import hashinit
+    from schema import FULL, state_shapes
+    cfg = E.EngineConfig(n_layers=2, trainable_layers=(0, 1), num_teachers=2)
+    P = hashinit.init_state_dict(3, state_shapes(FULL, 2, cfg.D, 2))
+    outs = []
+    for bucketed in (False, True):
+        eng = E.Engine(cfg, "cuda:0", max_batch=2, dtype="fp16")
+        eng.load_state_dict(P)
+        assert eng.scaler.enabled
+        g = torch.Generator(device="cuda:0").manual_seed(5)
+        ranges = eng.bucket_ranges()
+        for step in range(5):
+            eng.flat_g.copy_(torch.randn(eng.n_train, device="cuda:0", generator=g) * 1e-3)
+            if step == 1:
+                eng.flat_g[ranges[-1][1] - 1] = float("inf")          # the last element of the bucket that lands last
+            if step == 3:
+                eng.flat_g[ranges[0][0]] = float("nan")               # the first element of the first
+            before = [x.clone() for x in (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax)]
+            sync = _FakeSync(ranges) if bucketed else None
+            eng.step(1e-4, grad_scale=0.5, sync=sync)
+            torch.cuda.synchronize()
+            if bucketed:
+                assert sync.waited == list(range(len(ranges))) and not sync.pending
+            same = all(torch.equal(a, b) for a, b in zip(before, (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax)))
+            assert same == (step in (1, 3)), step
+        eng.scaler.drain(eng)
+        assert eng.scaler.skipped == 2 and int(eng.scaler.guard[1]) == 2 and eng.step_count == 3
+        outs.append([x.clone() for x in (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax)] + [eng.sh[1]["w1"].clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -97,6 +97,41 @@ def test_bench_dp_path_under_torchrun_single_rank():
     assert {(x["wgrad_units"], x["buckets"], x["algo"]) for x in sw} == {(u, b, g) for u in (1, 2) for b in (5, 3) for g in ("allreduce", "rs_ag")}
 
 
+def test_bench_two_ranks_over_gloo_match_one_rank_on_the_concatenated_batch(tmp_path):
+    """bench.py's OWN world > 1 path before the first 8-GPU lease runs it: `python bench.py --gpus 2` (self_launch ->
+    torch.distributed.run -> two workers) with the test-only backend override - gloo, both ranks on the one GPU, B / 2 each -
+    through the per-rank batches, the bucketed all-reduce with its per-bucket waits and scans (fp16 guard), max over ranks, the dp
+    object and --dp-sweep (rs_ag falls back to all-reduce off RCCL).  The parameters after the timed steps equal the one-rank run
+    on the concatenated batches (horovod's average, Tiny-NewsRec/run.py:141-149) to the bound of tests/test_dp_gpu.py.  No
+    throughput figure is taken from this."""
+    steps, warm, lr = 3, 1, 1e-4
+    outs = {}
+    for tag, gpus, batch in (("two", 2, 8), ("one", 1, 16)):
+        dump = str(tmp_path / (tag + ".npy"))
+        env = dict(os.environ, TNR_BENCH_BACKEND="gloo", TNR_BENCH_SHARE_GPU="1", TNR_BENCH_DUMP_PARAMS=dump)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--batch", str(batch), "--steps", str(steps),
+               "--warmup", str(warm), "--concat-batches", "--no-cpu-baseline", "--no-configs", "--no-larger-batch", "--no-other-dtype",
+               "--dedup", "off", "--no-kernel-timing"] + (["--dp-sweep"] if gpus == 2 else [])
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == gpus and d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
+        assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp%d" % gpus
+        outs[tag] = (d, np.load(dump))
+    dp = outs["two"][0]["dp"]
+    assert dp["backend"] == "gloo" and dp["algo"] == "allreduce" and dp["wgrad_units_per_workgroup"] == 2
+    assert len(dp["exposed_allreduce_ms_per_step_by_collective_rank0"]) == 5 and dp["exposed_allreduce_ms_per_step_max_over_ranks"] > 0
+    assert dp["fp16_tail_ms_per_step"]["amsgrad"] > 0 and dp["fp16_tail_ms_per_step"]["scans"] > 0
+    sw = dp["sweep"]
+    assert len(sw) == 8 and all("error" not in x and x["value"] > 0 and x["algo"] == "allreduce" for x in sw), sw
+    assert "dp" not in outs["one"][0]
+    p2, p1 = outs["two"][1].astype(np.float64), outs["one"][1].astype(np.float64)
+    diff = np.abs(p2 - p1)
+    n_upd = steps + warm
+    print("bench, 2 ranks (gloo) vs 1 rank: |param diff| mean %.2e max %.2e after %d steps at lr %g" % (diff.mean(), diff.max(), n_upd, lr))
+    assert diff.mean() < 0.02 * lr and diff.max() <= 2.05 * lr * n_upd
+
+
 def test_construction_time_init_and_pretrained_import(tmp_path):
     """Model(args) starts from the reference's construction-time distributions, and --model_name pointing at a
     unilm2-layout checkpoint fills the student's encoder like from_pretrained does (model_bert.py:109-114,

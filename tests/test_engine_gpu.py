@@ -497,10 +497,11 @@ def test_fp16_overflow_skips_the_step_and_halves_the_scale():
     for a, b in ((eng.flat[True], ref.flat[True]), (eng.adam_m, ref.adam_m), (eng.adam_v, ref.adam_v), (eng.adam_vmax, ref.adam_vmax)):
         assert torch.equal(a, b)                 # a clean guarded step == the unguarded step, bit for bit
     snap = [x.clone() for x in (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax, eng.sh[eng.lo]["w1"], eng.sh[eng.lo]["qkvT"])]
-    # inject an overflow: a scale of 2^40 x the shipped one for ONE step
-    sc.mult = 2.0 ** 40
+    # inject an overflow: a BASE scale of 2^40 x the shipped one for ONE step (the multiplier the scaler answers for stays 1: an
+    # overflow takes it to half of what the overflowing backward ran with)
+    eng._gbase *= 2.0 ** 40
     one(eng)
-    sc.mult = 1.0
+    eng._gbase /= 2.0 ** 40
     torch.cuda.synchronize()
     assert not bool(torch.isfinite(eng.flat_g).all())           # the gradient did overflow ...
     for a, b in zip(snap, (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax, eng.sh[eng.lo]["w1"], eng.sh[eng.lo]["qkvT"])):
@@ -556,14 +557,14 @@ def test_training_step_on_pretrained_like_statistics(dtype):
     serr = np.abs(sc - z["score"]).max() / max(1.0, np.abs(z["score"]).max())
     print("\n[pretrained-like %s] score rel err %.3e (|ref| max %.2f); losses" % (dtype, serr, np.abs(z["score"]).max()),
           {k: "%.2e" % abs(got[k] - float(z[k])) for k in got})
-    tol = TOL[dtype]
-    # logits reach |13| on these weights; a relative logit error eps is an ABSOLUTE logit error eps x 13, and a cross-entropy moves
-    # by up to that much - so the losses (|ref| ~ 1 ... 3) are held to tol x the logit scale, the logits themselves to tol relative
-    # (measured, fp16: logits 6.2e-4 relative, losses 1.5e-3 ... 1.8e-3 absolute; bf16: 1.1e-2, 5.6e-2)
-    lscale = max(1.0, float(np.abs(z["score"]).max()))
+    # logits reach |13| on these weights: a relative logit error eps is an ABSOLUTE logit error eps x 13 and a cross-entropy moves
+    # by up to that much.  Bounds = 1.5 x what was measured (fp16: logits 6.2e-4 of the logit scale, losses 1.5e-3 ... 1.8e-3
+    # absolute; bf16: 1.1e-2 and 5.6e-2) - DESIGN.md section 2 quotes the same numbers
+    LOGIT_REL = {"fp16": 1.0e-3, "bf16": 1.6e-2}[dtype]
+    LOSS_ABS = {"fp16": 3.0e-3, "bf16": 8.5e-2}[dtype]
     for k in got:
-        assert abs(got[k] - float(z[k])) <= tol * max(1.0, abs(float(z[k])), lscale), k
-    assert serr <= tol
+        assert abs(got[k] - float(z[k])) <= LOSS_ABS, (k, abs(got[k] - float(z[k])))
+    assert serr <= LOGIT_REL, serr
     out = O.model_fwd(P, cfg, *inp)
     G = O.model_bwd(P, cfg, out)
     errs = []
@@ -583,3 +584,56 @@ def test_training_step_on_pretrained_like_statistics(dtype):
     # tame-statistics one for the worst parameter and 1 x / 1.5 x for the median
     assert errs[0][0] < (2.0 if dtype == "fp16" else 5.0) * GTOL[dtype]
     assert errs[len(errs) // 2][0] < (1.0 if dtype == "fp16" else 1.5) * GTOL[dtype]      # bf16 median measured 6.3e-2
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_fifty_training_steps_follow_the_reference_trajectory(dtype):
+    """trajectory_0.npz: 50 steps of the reference's own loop (Tiny-NewsRec/run.py:173-200: forward, backward, Adam(amsgrad) at
+    lr 1e-4, demo.sh:11) over a cycle of 5 fixed batches, 2-layer student + 2 teachers, every step's losses and scores and 64
+    samples of every trained parameter at the end.  The engine replays them with 16-bit activations / weight copies and (fp16)
+    the dynamic loss scale LIVE.  The reference's run has a violent start (B = 2, Adam's first steps move every element by ~lr:
+    logits grow from 4.6 to 14.9 and the hard-label CE to 10.5 within ten steps, then settle) - a cross-entropy moves by up to the
+    ABSOLUTE logit error, so the per-step bound is relative to that step's logit scale; where the run has settled (the last 25
+    steps) the total loss is held absolutely.  Bounds = 1.5 x measured (fp16: every loss within 0.80e-3 x the logit scale, scores
+    within 1.9e-3 x, last 25 steps' total loss within 3.2e-4, update 12.7 %; bf16: 5.6e-3 x, 2.0e-2 x, 2.3e-3).  For scale: the
+    fp32 numpy oracle follows the same 50 steps to 3e-6 in every loss (tools/scratch/traj_detail.py prints the per-step table)."""
+    from helpers import load_trajectory_case
+    z, P, cfg, batches, lr, steps = load_trajectory_case()
+    T_ = len(batches[0][4])
+    eng, B = _engine_for(cfg, z, T_, dtype)
+    eng.load_state_dict(P)
+    dev_batches = [_dev_inputs(b) for b in batches]
+    got_losses, score_err = np.zeros((steps, 4)), np.zeros(steps)
+    for step in range(steps):
+        losses, score = eng.forward(*dev_batches[step % len(dev_batches)])
+        eng.backward()
+        eng.step(lr)
+        l = losses.cpu().numpy()
+        got_losses[step] = l[0] + cfg["coef"] * l[1] + l[2], l[0], l[2], l[1]          # total, distill, emb, target
+        score_err[step] = float(np.abs(score.cpu().numpy() - z["scores"][step]).max())
+    if dtype == "fp16":
+        eng.scaler.drain(eng)
+        assert eng.scaler.enabled and eng.scaler.skipped == 0 and eng.step_count == steps
+    err = np.abs(got_losses - z["losses"])
+    lscale = np.maximum(1.0, np.abs(z["scores"]).reshape(steps, -1).max(1))
+    num = den = 0.0
+    worst = (0.0, "")
+    for n in [str(x) for x in z["param_names"]]:
+        idx, ref = z["widx." + n], z["wval." + n].astype(np.float64)
+        got = eng.params[n].reshape(-1)[torch.from_numpy(idx).to(DEV)].cpu().numpy().astype(np.float64)
+        init = P[n].reshape(-1)[idx].astype(np.float64)
+        d, u = ((got - ref) ** 2).sum(), ((ref - init) ** 2).sum()
+        num, den = num + d, den + u
+        if u > 0 and np.sqrt(d / u) > worst[0] and not (n.endswith("self.key.bias") or n.endswith("att_fc2.bias")):
+            worst = (float(np.sqrt(d / u)), n)
+    rel = float(np.sqrt(num / den))
+    loss_rel, score_rel, late = float((err.max(1) / lscale).max()), float((score_err / lscale).max()), float(err[25:, 0].max())
+    print("\n[trajectory %s] loss |err| / logit scale max %.2e (absolute max %.2e at step %d, logits there %.1f) ; score |err| / logit "
+          "scale max %.2e ; total loss |err| over the last 25 steps max %.2e ; update rel L2 %.3e, worst parameter %.3e %s" % (
+              dtype, loss_rel, err.max(), int(err.max(1).argmax()), lscale[int(err.max(1).argmax())], score_rel, late, rel, worst[0], worst[1][-50:]))
+    LOSS_REL, SCORE_REL, LATE, UPD = {"fp16": (1.2e-3, 2.8e-3, 5e-4, 0.19), "bf16": (8.5e-3, 3.0e-2, 3.5e-3, 0.6)}[dtype]
+    assert loss_rel <= LOSS_REL and score_rel <= SCORE_REL and late <= LATE
+    assert got_losses[-1, 0] < 0.6 * got_losses[0, 0]
+    # Adam's first steps move every element by ~lr whatever its gradient's size, so elements whose gradient sits at the rounding
+    # floor (its SIGN is noise) end O(lr) apart between any two arithmetics
+    assert rel <= UPD, rel

@@ -455,6 +455,33 @@ def test_decode_worker_never_imports_torch():
     assert r.returncode == 0, r.stderr
 
 
+def test_spawned_decoder_does_not_reimport_main(tmp_path):
+    """multiprocessing's "spawn" re-imports the parent's __main__ in every child - for run.py that is `import torch` at the start
+    of every epoch, in the process that exists to stay away from it.  decode_worker.start_without_main starts the child without:
+    spawned from a SCRIPT that has imported torch, the child has neither torch nor the script's module."""
+    import subprocess, sys
+    script = tmp_path / "parent_main.py"
+    script.write_text(
+        "import sys, multiprocessing as mp\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "MARK = 'parent main imported'\n"
+        "import decode_worker as d\n"
+        "if __name__ == '__main__':\n"
+        "    ctx = mp.get_context('spawn')\n"
+        "    out = {}\n"
+        "    for name, start in (('plain', lambda p: p.start()), ('hidden', d.start_without_main)):\n"
+        "        q = ctx.Queue()\n"
+        "        p = ctx.Process(target=d.report_modules, args=(q, ['torch', '__mp_main__']), daemon=True)\n"
+        "        start(p); out[name] = q.get(timeout=100); p.join(20)\n"
+        "    assert 'torch' in out['plain'] and '__mp_main__' in out['plain'], out      # what multiprocessing does by itself\n"
+        "    assert 'torch' not in out['hidden'], out\n"
+        "    assert sys.modules['__main__'].__file__.endswith('parent_main.py')          # restored\n"
+        % os.path.join(os.path.dirname(GOLDEN), "..", "tiny-newsrec_amd"))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+
+
 def test_loss_scaler_host_logic():
     """engine.LossScaler.poll (host half of the fp16 loss scale; the reference trains in fp32, run.py:134,194-195): an answer is
     used exactly two steps after its step, an overflow halves the multiplier and takes the skipped step out of Adam's count,
@@ -471,19 +498,22 @@ def test_loss_scaler_host_logic():
     overflow_at = {4, 5, 12}
     seen = []
     for step in range(1, 16):
-        sc.poll(eng)                           # Engine.step: poll, then stamp += 1, launches, record
+        used = sc.mult                         # Engine.step: the multiplier the backward ran with, poll, stamp += 1, launches, record
+        sc.poll(eng)
         sc.stamp += 1
         eng.step_count += 1
-        sc.pending.append((sc.stamp, [sc.stamp if sc.stamp in overflow_at else 0], Ev()))
+        sc.pending.append((sc.stamp, [sc.stamp if sc.stamp in overflow_at else 0], Ev(), used))
         seen.append((sc.mult, sc.skipped, eng.step_count))
-    # the answer of step s is read at the start of step s + 2
-    assert [m for m, _, _ in seen] == [1, 1, 1, 1, 2, 1, 0.5, 0.5, 0.5, 1, 1, 1, 2, 1, 1], seen
+    # the answer of step s is read at the start of step s + 2; an overflow takes the multiplier to half of what THAT step ran with
+    # (steps 4 and 5 both ran at 1: one halving between them; the growth to 2 in between does not survive)
+    assert [m for m, _, _ in seen] == [1, 1, 1, 1, 2, 0.5, 0.5, 0.5, 0.5, 1, 1, 1, 2, 0.5, 0.5], seen
     assert [k for _, k, _ in seen] == [0, 0, 0, 0, 0, 1, 2, 2, 2, 2, 2, 2, 2, 3, 3]
     assert seen[-1][2] == 15 - 3               # three skipped steps taken out of Adam's count
     sc.drain(eng)
     assert not sc.pending
-    # sixteen skips in a row: one warning
-    sc2 = E.LossScaler("cpu", True)
+    # everything overflows (a forward overflow): one halving per three skipped steps (the two steps behind an overflow ran at
+    # the same multiplier), the multiplier stops at min_mult, sixteen skips in a row warn once
+    sc2 = E.LossScaler("cpu", True, min_mult=2.0 ** -4)
     eng2 = types.SimpleNamespace(step_count=100, gscale=1.0)
     records = []
     h = logging.Handler()
@@ -491,10 +521,34 @@ def test_loss_scaler_host_logic():
     logging.getLogger().addHandler(h)
     try:
         for s in range(1, 40):
-            sc2.stamp = s
-            sc2.pending.append((s, [s], Ev()))
+            used = sc2.mult
+            sc2.poll(eng2)
+            sc2.stamp += 1
+            sc2.pending.append((sc2.stamp, [sc2.stamp], Ev(), used))
+            if s == 9:
+                assert sc2.mult == 0.125 and sc2.skipped == 7     # answers 1 .. 7: halved by answers 1, 4 and 7
         sc2.drain(eng2)
     finally:
         logging.getLogger().removeHandler(h)
-    assert sc2.skipped == 39 and sc2.mult == 2.0 ** -20 and eng2.step_count == 100 - 39       # the multiplier stops at min_mult
+    assert sc2.skipped == 39 and sc2.mult == 2.0 ** -4 and eng2.step_count == 100 - 39
     assert sum("bf16" in r.getMessage() for r in records) == 1
+    # the advisor's case (round 4): the scale has grown once, the next backward overflows BECAUSE of it; its answer comes two
+    # steps late, so the two steps behind it overflow at the same scale: three skipped steps, ONE halving (back to where it was)
+    sc3 = E.LossScaler("cpu", True, growth_interval=2, max_mult=64.0)
+    eng3 = types.SimpleNamespace(step_count=0, gscale=1024.0)
+    mults = []
+    for step in range(1, 12):
+        used = sc3.mult
+        sc3.poll(eng3)
+        sc3.stamp += 1
+        eng3.step_count += 1
+        bad = used > 1.0                       # this model overflows whenever its backward runs above the base scale
+        sc3.pending.append((sc3.stamp, [sc3.stamp if bad else 0], Ev(), used))
+        mults.append(sc3.mult)
+    # answers 1, 2 clean -> x2 at the start of step 4; steps 5 and 6 run their backward at 2 and overflow, answers 3, 4 are still
+    # clean -> x2 again at step 6, step 7 runs at 4; step 5's answer arrives at step 7 -> half of the 2 it ran with; the answers of
+    # steps 6 and 7 (2 and 4) change nothing any more: three skipped steps, the multiplier back where it last worked
+    assert mults == [1, 1, 1, 2, 2, 4, 1, 1, 1, 1, 2], mults
+    assert sc3.skipped == 3 and min(mults) == 1
+    sc3.reset(eng3)
+    assert sc3.mult == 1.0 and not sc3.pending

@@ -517,6 +517,29 @@ def test_grad_nonfinite_finds_a_single_bad_value_anywhere():
             stamp += 1
 
 
+def test_grad_nonfinite_in_pieces_equals_one_scan():
+    """tnr_grad_nonfinite_scan over disjoint slices + one tnr_grad_nonfinite_commit == tnr_grad_nonfinite over the whole buffer
+    (data parallelism scans each gradient bucket as its all-reduce lands): the same guard words whichever slice holds the bad value,
+    one counted skip per step however many slices found something, none on a clean gradient."""
+    n = 3 * 4096 + 2048 + 64
+    cuts = [(0, 4096 + 64), (4096 + 64, 3 * 4096), (3 * 4096, n)]
+    g = torch.zeros(n, device=DEV)
+    ga, gb = torch.zeros(4, dtype=torch.int32, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV)
+    rs = np.random.RandomState(11)
+    for stamp, bad in enumerate([(), (5,), (n - 1,), (4096 + 64, 3 * 4096 + 1), (), (7000,)], start=1):
+        a = rs.standard_normal(n).astype(np.float32)
+        for pos in bad:
+            a[pos] = np.inf
+        g.copy_(torch.from_numpy(a))
+        T.call("tnr_grad_nonfinite", g, n, ga, stamp)
+        for s_, e_ in cuts:
+            T.call("tnr_grad_nonfinite_scan", g[s_:e_], e_ - s_, gb, stamp)
+        T.call("tnr_grad_nonfinite_commit", gb, stamp)
+        torch.cuda.synchronize()
+        assert torch.equal(ga, gb), (stamp, ga, gb)
+    assert int(ga[1]) == 4
+
+
 def test_refresh_shadows():
     w1, w2 = rnd((200, 768), 1), rnd((768, 96), 2)
     s1, s2 = dev(w1), dev(w2)

@@ -304,6 +304,25 @@ def test_plmnr_training_steps_match_reference(case):
         np.testing.assert_allclose(got, z["wval." + k], rtol=0, atol=2e-6, err_msg=k)
 
 
+def test_training_trajectory_first_steps_match_reference():
+    """trajectory_0.npz (the reference's own loop, Tiny-NewsRec/run.py:173-200, 50 steps over 5 fixed batches): the oracle's
+    forward + backward + AMSGrad reproduce the first four steps' losses and scores (the GPU test replays all 50 in fp16)."""
+    from helpers import load_trajectory_case
+    z, P, cfg, batches, lr, steps = load_trajectory_case()
+    assert steps == 50 and len(batches) == 5 and z["losses"].shape == (50, 4)
+    assert z["losses"][-1, 0] < 0.6 * z["losses"][0, 0]                 # the reference did learn something over the 50 steps
+    state = {}
+    for step in range(4):
+        out = O.model_fwd(P, cfg, *batches[step % len(batches)])
+        got = [out["total_loss"], out["distill_loss"], out["emb_loss"], out["target_loss"]]
+        np.testing.assert_allclose(np.array(got, np.float64), z["losses"][step], rtol=2e-4, atol=2e-5, err_msg="step %d" % step)
+        np.testing.assert_allclose(out["student_score"], z["scores"][step], rtol=2e-4, atol=2e-4)
+        G = O.model_bwd(P, cfg, out)
+        for k, g in G.items():
+            m, v, vm = state.setdefault(k, [np.zeros_like(P[k]), np.zeros_like(P[k]), np.zeros_like(P[k])])
+            O.amsgrad_step(P[k], g, m, v, vm, step + 1, lr=lr)
+
+
 def test_stage0_contrastive_post_train_matches_notebook():
     """Domian-specific_Post-train.ipynb TitleBodySimModel (12 layers, layers 9-11 trainable, CE over 1+K titles).
     With hash weights twelve layers deep the attention (and the pooling) is close to uniform, so the q / k and pooling-head

@@ -134,6 +134,21 @@ extern "C" int tnr_amsgrad_step(float* p, const float* g, float* m, float* v, fl
     return tnr_amsgrad_step_guarded(p, g, m, v, vmax, n, step, lr, beta1, beta2, eps, grad_scale, nullptr, 0u, 0u, stream);
 }
 
+extern "C" int tnr_grad_nonfinite_scan(const float* g, int64_t n, unsigned* guard, unsigned stamp, void* stream) {
+    TNR_CHECK_ARG(g && guard && n >= 1 && stamp >= 1 && ((uintptr_t)g % 16) == 0, "tnr_grad_nonfinite_scan: bad argument");
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 4095) / 4096, 2048);
+    hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, guard, stamp);
+    TNR_CHECK_LAUNCH("tnr_grad_nonfinite_scan");
+    return TNR_OK;
+}
+
+extern "C" int tnr_grad_nonfinite_commit(unsigned* guard, unsigned stamp, void* stream) {
+    TNR_CHECK_ARG(guard && stamp >= 1, "tnr_grad_nonfinite_commit: bad argument");
+    hipLaunchKernelGGL(grad_nonfinite_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, guard, stamp);
+    TNR_CHECK_LAUNCH("tnr_grad_nonfinite_commit");
+    return TNR_OK;
+}
+
 extern "C" int tnr_grad_nonfinite(const float* g, int64_t n, unsigned* guard, unsigned stamp, void* stream) {
     TNR_CHECK_ARG(g && guard && n >= 1 && stamp >= 1 && ((uintptr_t)g % 16) == 0, "tnr_grad_nonfinite: bad argument");
     const unsigned grid = (unsigned)std::min<int64_t>((n + 4095) / 4096, 2048);

@@ -17,7 +17,7 @@ import threading
 import numpy as np
 import torch
 
-from decode_worker import decode_lines, decode_process
+from decode_worker import decode_lines, decode_process, start_without_main
 from streaming import StreamSampler, _count_lines, shard_files
 
 _END = object()
@@ -156,7 +156,7 @@ class DataLoaderTrain:
         cfg = dict(sampler=self._sampler_args(), news_index=self.news_index, user_log_length=self.user_log_length,
                    npratio=self.npratio, dedup=self.dedup)
         proc = ctx.Process(target=decode_process, args=(cfg, random.getstate(), q), daemon=True)
-        proc.start()
+        start_without_main(proc)             # no re-import of run.py (and with it torch) in the child
         self._proc = proc
         try:
             while True:

@@ -54,3 +54,32 @@ def decode_process(cfg, rnd_state, q):
     except BaseException as e:          # noqa: BLE001 - reported to the parent, which raises
         import traceback
         q.put(("error", "%r\n%s" % (e, traceback.format_exc())))
+
+
+def start_without_main(proc):
+    """proc.start() of a "spawn" process WITHOUT the child re-importing the parent's __main__ (multiprocessing does that for every
+    spawned child: run.py's top-level `import torch` would then cost the decoder a second or two at the start of every epoch and
+    put a GPU framework into a process that is there to stay off the GPU).  The child's target lives in this module and needs
+    nothing from __main__."""
+    import sys
+    main = sys.modules.get("__main__")
+    saved = {}
+    for k in ("__spec__", "__file__"):
+        if main is not None and hasattr(main, k):
+            saved[k] = getattr(main, k)
+    try:
+        if main is not None:
+            if "__spec__" in saved:
+                main.__spec__ = None
+            if "__file__" in saved:
+                del main.__file__
+        proc.start()
+    finally:
+        for k, v in saved.items():
+            setattr(main, k, v)
+
+
+def report_modules(q, names):
+    """test hook: which of `names` the spawned child has imported"""
+    import sys
+    q.put([n for n in names if sys.modules.get(n) is not None])

@@ -81,6 +81,10 @@ class GradSync:
         if self.algo == "rs_ag" and t.numel() % max(self.world, 1) == 0:
             w = max(self.world, 1)
             k = t.numel() // w
+            # ONE shard buffer per size, shared by every in-flight collective of that size (the two per-layer buckets of a model
+            # have equal sizes).  Safe only because ProcessGroupNCCL issues all collectives of this group on ONE internal stream in
+            # call order: the reduce-scatter of collective n + 1 cannot start before the all-gather of collective n has read the
+            # shard.  A backend with one stream per collective would need a shard per in-flight collective.
             shard = self._shard.get(k)
             if shard is None:
                 shard = self._shard[k] = torch.empty(k, dtype=t.dtype, device=t.device)
@@ -134,7 +138,8 @@ class GradSync:
             self.wait_bucket(self.groups[g][0])
 
     def exposed_ms(self):
-        """-> {bucket: [ms, ...]} of the waits recorded since the last call (synchronises the device)."""
+        """-> {collective: [ms, ...]} of the waits recorded since the last call (synchronises the device).  Keys are COLLECTIVE
+        indices (self.groups / collective_bytes order): with merge_layers a layer's two buckets share one."""
         torch.cuda.synchronize()
         out = {}
         for b, e0, e1 in self._events:
@@ -169,7 +174,12 @@ def barrier():
 
 def all_reduce_max(x):
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        if dist.get_backend() == "gloo" and x.is_cuda:           # gloo moves host memory (tests: ranks sharing one GPU)
+            h = x.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            x.copy_(h)
+        else:
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
     return x
 
 

@@ -211,20 +211,25 @@ class LossScaler:
         self.mult, self.stamp, self.clean, self.skipped, self.run_of_skips = 1.0, 0, 0, 0, 0
         self.growth_interval, self.max_mult, self.min_mult = growth_interval, max_mult, min_mult
         self.guard = torch.zeros(4, dtype=torch.int32, device=dev) if self.enabled else None
-        self.pending = []                    # (stamp, pinned host word, event) in issue order
+        self.pending = []                    # (stamp, pinned host word, event, multiplier that step's backward ran with) in issue order
+        self._ring = torch.zeros(8, dtype=torch.int32).pin_memory() if self.enabled else None    # at most lag + 1 answers are outstanding
 
     def poll(self, eng, lag=2):
         """Answers of the steps at least `lag` stamps back.  Deterministic (which answers are used depends on the step number
         only, never on timing: data-parallel ranks must change their scale and step count at the same step); the event of a step
-        two back has normally long completed - a host running further ahead than that waits here, with a full step still queued."""
+        two back has normally long completed - a host running further ahead than that waits here, with a full step still queued.
+        An answer arrives two steps late, so the two backwards after an overflow have already run at the old scale and
+        overflow with it: an overflow takes the multiplier to HALF OF WHAT THAT STEP'S BACKWARD RAN WITH, if it is not below
+        that already - one cause, one halving; the later two steps are still skipped on the device and still leave Adam's
+        count."""
         while self.pending and self.pending[0][0] <= self.stamp - lag + 1:
-            stamp, host, ev = self.pending.pop(0)
+            stamp, host, ev, used = self.pending.pop(0)
             ev.synchronize()
             if int(host[0]) == stamp:        # that step found inf / nan: it was skipped on the device
                 self.skipped += 1
                 self.clean = 0
                 self.run_of_skips += 1
-                self.mult = max(self.mult * 0.5, self.min_mult)
+                self.mult = max(min(self.mult, used * 0.5), self.min_mult)
                 eng.step_count = max(eng.step_count - 1, 0)
                 if self.run_of_skips == 16:  # a smaller scale cures a backward overflow within a few steps, never a forward one
                     logging.warning("16 optimiser steps in a row skipped for inf / nan gradients although the loss scale went down "
@@ -235,16 +240,23 @@ class LossScaler:
                 if self.clean >= self.growth_interval and self.mult < self.max_mult:
                     self.mult, self.clean = self.mult * 2.0, 0
 
-    def record(self):
-        host = torch.empty(1, dtype=torch.int32).pin_memory()
+    def record(self, used):
+        """`used`: the multiplier this step's backward ran with (Engine.step reads it before poll may change it)."""
+        host = self._ring[self.stamp % 8: self.stamp % 8 + 1]
         host.copy_(self.guard[:1], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending.append((self.stamp, host, ev))
+        self.pending.append((self.stamp, host, ev, used))
 
     def drain(self, eng):
         """Wait for every outstanding answer (end of an epoch / before a checkpoint / tests)."""
         self.poll(eng, lag=0)
+
+    def reset(self, eng):
+        """New weights (load_state_dict) or a new benchmark leg: outstanding answers are consumed, then the scale starts over;
+        skipped-step totals stay (they are a log figure)."""
+        self.drain(eng)
+        self.mult, self.clean, self.run_of_skips = 1.0, 0, 0
 
 
 class Engine:
@@ -395,6 +407,8 @@ class Engine:
                 raise ValueError("%s: shape %s != %s" % (k, tuple(v.shape), shp))
             self.params[k].copy_(v.to(self.dev, torch.float32))
         self.refresh_shadows(all_layers=True)
+        if self.scaler.enabled:              # answers still outstanding belong to the old weights; the scale starts over
+            self.scaler.reset(self)
 
     def state_dict(self):
         return {k: v.detach().clone() for k, v in self.params.items()}
@@ -1198,6 +1212,7 @@ class Engine:
         sc = self.scaler
         guard, stamp = None, 0
         if sc.enabled:
+            used = sc.mult                   # what this step's backward ran with
             sc.poll(self)                    # overflows of steps two or more back: scale halved, Adam's count corrected
             sc.stamp += 1
             guard, stamp = sc.guard, sc.stamp
@@ -1219,14 +1234,22 @@ class Engine:
 
         if guard is not None:
             # the WHOLE (reduced) gradient decides before any slice is updated - identically on every rank, since inf / nan
-            # survive the all-reduce; so under data parallelism every bucket is waited for first (the bucket-wise update below
-            # is the bf16 path)
-            if sync is not None:
-                sync.wait()
-            T.call("tnr_grad_nonfinite", self.flat_g, self.n_train, guard, stamp)
+            # survive the all-reduce.  Under data parallelism each bucket is scanned as soon as ITS all-reduce has landed (the
+            # scans hide under the collectives still in flight; what lies between buckets are alignment gaps, zero gradients); only
+            # the last bucket's scan, the one-thread commit and the update itself (79 us at the headline) stay behind the last
+            # collective.  (bf16 has no guard and updates bucket by bucket, below.)
+            if sync is not None and sync.pending:
+                for b, (s_, e_) in enumerate(sync.ranges):
+                    sync.wait_bucket(b)
+                    T.call("tnr_grad_nonfinite_scan", self.flat_g[s_:e_], e_ - s_, guard, stamp)
+                T.call("tnr_grad_nonfinite_commit", guard, stamp)
+            else:
+                if sync is not None:
+                    sync.wait()
+                T.call("tnr_grad_nonfinite", self.flat_g, self.n_train, guard, stamp)
             for lo_, hi_, rate in ranges:
                 launch(lo_, hi_, rate)
-            sc.record()
+            sc.record(used)
         elif sync is not None and sync.pending:
             done = []
             for b, (s_, e_) in enumerate(sync.ranges):       # completion order of backward = launch order of the all-reduces

@@ -236,6 +236,8 @@ def train(args):
                 logging.info("[%d] ed: %d, loss: %.5f, t_loss: %.5f, d_loss: %.5f, e_loss: %.5f, acc: %.5f, %.1f pairs/s%s" % (
                     rank, cnt * B, s[0], s[1], s[2], s[3], s[4], size * cnt * B / max(time.time() - t0, 1e-9),
                     ", loss scale %g, %d steps skipped (fp16 overflow)" % (eng.title.gscale, sc.skipped) if sc.enabled and sc.skipped else ""))
+        if eng.title.scaler.enabled:
+            eng.title.scaler.drain(eng.title)
         if rank == 0:
             os.makedirs(args.save_dir, exist_ok=True)
             name = "first_stage_%d_layer.pt" if args.stage == 1 else "DP_%d_layer.pt"

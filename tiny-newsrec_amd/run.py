@@ -165,6 +165,8 @@ def train(args):
                     size * cnt * args.batch_size / max(time.time() - t0, 1e-9),
                     ", loss scale {:g}, {} steps skipped (fp16 overflow)".format(eng.gscale, sc.skipped) if sc.enabled and sc.skipped else ""))
         print(ep + 1)
+        if eng.scaler.enabled:
+            eng.scaler.drain(eng)        # the epoch's last two overflow answers, before the step count goes into a log line or a file
         if rank == 0:                                                        # run.py:205-214
             os.makedirs(args.model_dir, exist_ok=True)
             ckpt_path = os.path.join(args.model_dir, f"epoch-{ep + 1}.pt")

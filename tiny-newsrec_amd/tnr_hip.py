@@ -141,6 +141,8 @@ _SIG = {
     "tnr_amsgrad_step": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P],
     "tnr_amsgrad_step_guarded": [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P, _c.c_uint, _c.c_uint, _P],
     "tnr_grad_nonfinite": [_P, _L, _P, _c.c_uint, _P],
+    "tnr_grad_nonfinite_scan": [_P, _L, _P, _c.c_uint, _P],
+    "tnr_grad_nonfinite_commit": [_P, _c.c_uint, _P],
     "tnr_refresh_shadows": [_P, _I, _L, _P, _P],
     "tnr_cast_f32_to_bf16": [_P, _P, _L, _P],
     "tnr_cast_bf16_to_f32": [_P, _P, _L, _P],
