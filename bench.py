@@ -163,6 +163,8 @@ def main():
                     help="tools only: tnr_gemm_set_option(KEY, INT) before the run (A/B profiles; the default is the shipped configuration)")
     ap.add_argument("--no-larger-batch", action="store_true", help="skip the extra timed loop at 4 x the per-GPU batch")
     ap.add_argument("--no-configs", action="store_true", help="skip the timed legs of the other BASELINE.json configurations")
+    ap.add_argument("--leg", default=None, help="run ONE of the other configurations alone (--warmup / --steps apply) and print its object: "
+                                                "'configs[1]', 'configs[2]', 'configs[4]', 'configs[4] stage 1', 'stage 1 notebook shape'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--concat-batches", action="store_true",
@@ -242,6 +244,104 @@ def main():
                             plans[i] if use_plan else None)
         eng.backward(after_bucket=gs.launch if use_dp else None)
         eng.step(lr=1e-4, grad_scale=gs.scale, sync=gs)      # per bucket: wait for its all-reduce, then its AMSGrad slice
+
+    # The other BASELINE.json configurations, each on its own shapes (never `value`): configs[1] PLM-NR 12-layer fine-tune (train
+    # 10-11, bf16; PLM-NR/demo.sh:3-22), configs[2] 4-layer student + ONE teacher, configs[4] 2-layer student + 4 teachers in fp16
+    # (Tiny-NewsRec/demo.sh:3-36) and its stage-1 form, titles of 30 / bodies of 128 tokens, 1 + 4 titles per body
+    # (Post-train_KD.ipynb cell 4 with BASELINE's lengths), and the notebook's own stage-1 shape: titles of 24 / bodies of 512 tokens,
+    # 1 + 9 titles per body (Post-train_KD.ipynb cells 4, 8).  B = 32 per GPU, 3 warm-up + 20 timed steps each, one GPU.
+    # `--leg NAME` runs one of them alone (tools/make_profiles.sh: a rocprofv3 trace per configuration).
+    legs = {}
+    # what each leg's parity test allows and what it measured (tools/parity_measured.py runs the tests and writes the file; the
+    # allowances beyond 1e-3 are measured ones)
+    PARITY = {}
+    import glob as _glob
+    for pj in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_parity_measured.json")), reverse=True)[:1]:
+        PARITY = json.load(open(pj))
+
+    def stage2_leg(key, nl, tr, T_, dtype, what, W2=3, K2=20):
+        try:
+            c2 = E.EngineConfig(n_layers=nl, trainable_layers=tr, num_teachers=T_)
+            e2 = E.Engine(c2, dev, max_batch=B, dtype=dtype)
+            e2.load_state_dict(hashinit.init_state_dict(seed, state_shapes(FULL, nl, c2.D, T_)))
+            e2.refresh_shadows(all_layers=True)
+
+            def st(i):
+                s2 = slice((i % (K + W)) * B, (i % (K + W) + 1) * B)
+                e2.forward_indexed(comb, hidx[s2], mask[s2], cidx[s2], label[s2], tables[:T_] if T_ else None)
+                e2.backward()
+                e2.step(lr=1e-4)
+            for i in range(W2):
+                st(i)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(W2, W2 + K2):
+                st(i)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t2
+            f2 = flops_per_impression(nl, len(tr))
+            legs[key] = {"workload": what, "dtype": dtype, "batch_per_gpu": B, "steps": K2, "value": round(B * K2 / d2, 2),
+                         "unit": "impressions/s", "ms_per_step": round(1e3 * d2 / K2, 4), "model_flops_per_impression": f2,
+                         "mfma_frac_whole_step": round(f2 * B * K2 / d2 / PEAK_BF16, 4), "final_loss": round(float(e2.total_loss().item()), 5),
+                         "parity": PARITY.get(key)}
+            del e2
+        except Exception as ex:                  # an informational leg must never cost the headline line
+            legs[key] = {"workload": what, "error": repr(ex)[:300]}
+        torch.cuda.empty_cache()
+
+    def stage1_leg(key, Lt, Lb, Kn, what, W2=3, K2=20):
+        try:
+            from stage1 import Stage1Engine
+            nd = 20000
+            s1 = Stage1Engine(n_layers=2, trainable_layers=(0, 1), num_teachers=4, npratio=Kn, title_len=Lt, body_len=Lb, device=dev,
+                              batch=B, dtype="fp16")
+            s1.load_state_dict({k: torch.from_numpy(hashinit.init_tensor(seed, k, tuple(sh))) for k, sh in s1.shapes.items()})
+            s1.title.refresh_shadows(all_layers=True)
+            s1.body.refresh_rel()
+            d_title = torch.from_numpy(synth.news_table(11, nd - 1, Lt)).to(dev)
+            d_body = torch.from_numpy(synth.news_table(12, nd - 1, Lb, mean_len=0.6 * Lb, std_len=0.25 * Lb)).to(dev)
+            d_tt = torch.from_numpy(np.ascontiguousarray(synth.teacher_tables(13, 4, nd - 1, s1.cfg_t.D))).to(dev)
+            d_tb = torch.from_numpy(np.ascontiguousarray(synth.teacher_tables(14, 4, nd - 1, s1.cfg_t.D))).to(dev)
+            rs = np.random.RandomState(seed)
+            pidx = torch.from_numpy(rs.randint(1, nd, ((W2 + K2) * B, 1 + Kn)).astype(np.int32)).to(dev)
+            lab1 = torch.zeros(B, dtype=torch.int64, device=dev)
+
+            def st1(i):
+                s1.forward_indexed(d_title, d_body, pidx[i * B:(i + 1) * B], lab1, d_tt, d_tb)
+                s1.backward()
+                s1.step(1e-5, lr_bert=1e-6, amsgrad=False)
+            for i in range(W2):
+                st1(i)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(W2, W2 + K2):
+                st1(i)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t2
+            H_ = 768
+            ftok = lambda L_: 24 * H_ * H_ + 4 * L_ * H_
+            f1 = (ftok(Lt) * (1 + Kn) * Lt + ftok(Lb) * Lb) * (2 + 2 * 2) + 0.2e9      # per (body, 1 + Kn titles) pair group, 2 layers both trainable
+            legs[key] = {"workload": what, "dtype": "fp16", "batch_per_gpu": B, "steps": K2, "value": round(B * K2 / d2, 2), "unit": "pairs/s",
+                         "ms_per_step": round(1e3 * d2 / K2, 4), "model_flops_per_pair": f1,
+                         "mfma_frac_whole_step": round(f1 * B * K2 / d2 / PEAK_BF16, 4),
+                         "final_loss": round(float(s1.total_loss().item()), 5), "parity": PARITY.get(key)}
+            del s1
+        except Exception as ex:
+            legs[key] = {"workload": what, "error": repr(ex)[:300]}
+        torch.cuda.empty_cache()
+
+    LEGS = {
+        "configs[1]": lambda **kw: stage2_leg("configs[1]", 12, (10, 11), 0, "bf16", "PLM-NR 12-layer UniLM teacher fine-tune (train [10, 11]), CE, two-rate AMSGrad path", **kw),
+        "configs[2]": lambda **kw: stage2_leg("configs[2]", 4, (2, 3), 1, a.dtype, "Tiny-NewsRec 4-layer student (train [2, 3]) + 1-teacher KD", **kw),
+        "configs[4]": lambda **kw: stage2_leg("configs[4]", 2, (0, 1), 4, "fp16", "Tiny-NewsRec 2-layer student (train [0, 1]) + 4-teacher KD", **kw),
+        "configs[4] stage 1": lambda **kw: stage1_leg("configs[4] stage 1", 30, 128, 4, "Post-train_KD stage 1: 2-layer student + 4 teachers, 1 + 4 titles of 30 / body of 128 tokens, plain two-rate Adam", **kw),
+        "stage 1 notebook shape": lambda **kw: stage1_leg("stage 1 notebook shape", 24, 512, 9, "Post-train_KD stage 1 at the notebook's own shape (cells 4, 8): 2-layer student + 4 teachers, 1 + 9 titles of 24 / body of 512 tokens, plain two-rate Adam", **kw),
+    }
+    if a.leg:
+        LEGS[a.leg](W2=W, K2=K)
+        if rank == 0:
+            print(json.dumps({"leg": a.leg, **legs[a.leg]}), flush=True)
+        return
 
     timed_rec = []
 
@@ -415,90 +515,13 @@ def main():
             T.TIMED.pop(TKEY, None)
             bigger = {"error": repr(ex)[:300]}
 
-    # The other BASELINE.json configurations, each on its own shapes (never `value`): configs[1] PLM-NR 12-layer fine-tune (train
-    # 10-11, bf16; PLM-NR/demo.sh:3-22), configs[2] 4-layer student + ONE teacher, configs[4] 2-layer student + 4 teachers in fp16
-    # (Tiny-NewsRec/demo.sh:3-36) and its stage-1 form, titles of 30 / bodies of 128 tokens, 1 + 4 titles per body
-    # (Post-train_KD.ipynb cell 4 with BASELINE's lengths).  B = 32 per GPU, 3 warm-up + 20 timed steps each, one GPU.
-    legs = None
     if world == 1 and not a.no_configs and a.dedup != "only":
-        legs = {}
         eng = gs = None
         torch.cuda.empty_cache()
-
-        def stage2_leg(key, nl, tr, T_, dtype, what):
-            try:
-                c2 = E.EngineConfig(n_layers=nl, trainable_layers=tr, num_teachers=T_)
-                e2 = E.Engine(c2, dev, max_batch=B, dtype=dtype)
-                e2.load_state_dict(hashinit.init_state_dict(seed, state_shapes(FULL, nl, c2.D, T_)))
-                e2.refresh_shadows(all_layers=True)
-                W2, K2 = 3, 20
-
-                def st(i):
-                    s2 = slice(i * B, (i + 1) * B)
-                    e2.forward_indexed(comb, hidx[s2], mask[s2], cidx[s2], label[s2], tables[:T_] if T_ else None)
-                    e2.backward()
-                    e2.step(lr=1e-4)
-                for i in range(W2):
-                    st(i)
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                for i in range(W2, W2 + K2):
-                    st(i)
-                torch.cuda.synchronize()
-                d2 = time.perf_counter() - t2
-                f2 = flops_per_impression(nl, len(tr))
-                legs[key] = {"workload": what, "dtype": dtype, "batch_per_gpu": B, "steps": K2, "value": round(B * K2 / d2, 2),
-                             "unit": "impressions/s", "ms_per_step": round(1e3 * d2 / K2, 4), "model_flops_per_impression": f2,
-                             "mfma_frac_whole_step": round(f2 * B * K2 / d2 / PEAK_BF16, 4), "final_loss": round(float(e2.total_loss().item()), 5)}
-                del e2
-            except Exception as ex:                  # an informational leg must never cost the headline line
-                legs[key] = {"workload": what, "error": repr(ex)[:300]}
-            torch.cuda.empty_cache()
-
-        stage2_leg("configs[1]", 12, (10, 11), 0, "bf16", "PLM-NR 12-layer UniLM teacher fine-tune (train [10, 11]), CE, two-rate AMSGrad path")
-        stage2_leg("configs[2]", 4, (2, 3), 1, a.dtype, "Tiny-NewsRec 4-layer student (train [2, 3]) + 1-teacher KD")
-        stage2_leg("configs[4]", 2, (0, 1), 4, "fp16", "Tiny-NewsRec 2-layer student (train [0, 1]) + 4-teacher KD")
-        try:
-            from stage1 import Stage1Engine
-            Lt, Lb, Kn, nd = 30, 128, 4, 20000
-            s1 = Stage1Engine(n_layers=2, trainable_layers=(0, 1), num_teachers=4, npratio=Kn, title_len=Lt, body_len=Lb, device=dev,
-                              batch=B, dtype="fp16")
-            s1.load_state_dict({k: torch.from_numpy(hashinit.init_tensor(seed, k, tuple(sh))) for k, sh in s1.shapes.items()})
-            s1.title.refresh_shadows(all_layers=True)
-            s1.body.refresh_rel()
-            d_title = torch.from_numpy(synth.news_table(11, nd - 1, Lt)).to(dev)
-            d_body = torch.from_numpy(synth.news_table(12, nd - 1, Lb, mean_len=0.6 * Lb, std_len=0.25 * Lb)).to(dev)
-            d_tt = torch.from_numpy(np.ascontiguousarray(synth.teacher_tables(13, 4, nd - 1, s1.cfg_t.D))).to(dev)
-            d_tb = torch.from_numpy(np.ascontiguousarray(synth.teacher_tables(14, 4, nd - 1, s1.cfg_t.D))).to(dev)
-            W2, K2 = 3, 20
-            rs = np.random.RandomState(seed)
-            pidx = torch.from_numpy(rs.randint(1, nd, ((W2 + K2) * B, 1 + Kn)).astype(np.int32)).to(dev)
-            lab1 = torch.zeros(B, dtype=torch.int64, device=dev)
-
-            def st1(i):
-                s1.forward_indexed(d_title, d_body, pidx[i * B:(i + 1) * B], lab1, d_tt, d_tb)
-                s1.backward()
-                s1.step(1e-5, lr_bert=1e-6, amsgrad=False)
-            for i in range(W2):
-                st1(i)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for i in range(W2, W2 + K2):
-                st1(i)
-            torch.cuda.synchronize()
-            d2 = time.perf_counter() - t2
-            H_ = 768
-            ftok = lambda L_: 24 * H_ * H_ + 4 * L_ * H_
-            f1 = (ftok(Lt) * (1 + Kn) * Lt + ftok(Lb) * Lb) * (2 + 2 * 2) + 0.2e9      # per (body, 1 + 4 titles) pair group, 2 layers both trainable
-            legs["configs[4] stage 1"] = {"workload": "Post-train_KD stage 1: 2-layer student + 4 teachers, 1 + 4 titles of 30 / body of 128 tokens, plain two-rate Adam",
-                                          "dtype": "fp16", "batch_per_gpu": B, "steps": K2, "value": round(B * K2 / d2, 2), "unit": "pairs/s",
-                                          "ms_per_step": round(1e3 * d2 / K2, 4), "model_flops_per_pair": f1,
-                                          "mfma_frac_whole_step": round(f1 * B * K2 / d2 / PEAK_BF16, 4),
-                                          "final_loss": round(float(s1.total_loss().item()), 5)}
-            del s1
-        except Exception as ex:
-            legs["configs[4] stage 1"] = {"error": repr(ex)[:300]}
-        torch.cuda.empty_cache()
+        for name in LEGS:
+            LEGS[name]()
+    else:
+        legs = None
 
     if rank == 0:
         value = world * B * K / dt
@@ -542,6 +565,7 @@ def main():
                                "algorithmic_flops_per_launch": fl / len(rec)}
         else:
             out["roofline"] = None
+        out["parity"] = PARITY.get("headline")       # what the headline model's parity test allows and measured (tools/parity_measured.py)
         if dp_info is not None:
             out["dp"] = dp_info
         if other is not None:
