@@ -1125,6 +1125,9 @@ __device__ __forceinline__ void pp_q_fetch(unsigned& dst, unsigned* ctr, bool on
 }
 __device__ __forceinline__ void pp_q_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0) ; tile queue: %0" : "+v"(v) :: "memory"); }
 
+#ifdef TNR_NT_STAMPS
+__device__ unsigned tnr_nt_stamp_buf[256][8][264];
+#endif
 template <int N_> __device__ __forceinline__ void tnr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 template <int MI, int CF>
@@ -1153,6 +1156,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
     int* const qlds = (int*)(smem + LDS3_BYTES);
+#ifdef TNR_NT_STAMPS
+    unsigned* const nstamps = (unsigned*)(smem + LDS3_BYTES + 64);
+    bool stamped = false;
+#endif
     unsigned q0;                                         // the first tile: in flight while the tables below are set up
     pp_q_fetch(q0, g.queue + xcd * PP_Q_STRIDE, w == 0);
     auto leave = [&]() {                                 // last workgroup out zeroes the counters for the next launch
@@ -1245,16 +1252,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 
     constexpr int ILO = MI < 4 ? MI : 4, IHI = MI - ILO; // 16-row blocks of the wave's lower / upper A half
     bf16x8 af[4][2], bfr[4][2];
-#define TNR_PP_SEG_END()                                            \
+#ifdef TNR_NT_STAMPS
+// probe build only (make BUILD=../../tools/_ntst EXTRA=-DTNR_NT_STAMPS, NT=1 tools/tn_stamps.py): every wave's s_memtime on arrival at
+// each of the 8 barriers of K tiles 0-31 of the workgroup's FIRST tile, as in gemm_tn_rs_kernel's probe
+#define TNR_NT_BARRIER(K)                                                                                      \
+    do {                                                                                                       \
+        unsigned long long ts_;                                                                                \
+        asm volatile("s_memtime %0\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");              \
+        if (lane == 0 && !stamped && kt < 32) nstamps[w * 264 + 8 + 8 * kt + (K)] = (unsigned)ts_;             \
+    } while (0)
+#else
+#define TNR_NT_BARRIER(K) __builtin_amdgcn_s_barrier()
+#endif
+#define TNR_PP_SEG_END(K)                                           \
     __builtin_amdgcn_sched_barrier(0);                              \
-    __builtin_amdgcn_s_barrier();                                   \
+    TNR_NT_BARRIER(K);                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
     __builtin_amdgcn_sched_barrier(0);                              \
     __builtin_amdgcn_s_setprio(1)
-#define TNR_PP_MFMA_END()                                           \
+#define TNR_PP_MFMA_END(K)                                          \
     __builtin_amdgcn_s_setprio(0);                                  \
     __builtin_amdgcn_sched_barrier(0);                              \
-    __builtin_amdgcn_s_barrier();                                   \
+    TNR_NT_BARRIER(K);                                              \
     __builtin_amdgcn_sched_barrier(0)
 #if defined(TNR_PROBES) && TNR_PROBES >= 2
     const bool compute = !(g.probe & 2);
@@ -1335,35 +1354,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
         }                                                                                                        \
         if (more) { issue(2, kt + 1); issue(3, kt + 1); }                                                        \
         TNR_PP_DUMMY_STORE(0);                                                                                   \
-        TNR_PP_SEG_END();                                                                                        \
+        TNR_PP_SEG_END(0);                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < ILO; ++i)                                                      \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
                     acc[i][j] = TNR_MFMA_16x16x32(bfr[BL + j][s], af[i][s], acc[i][j], 0, 0, 0);                 \
-        TNR_PP_MFMA_END();                                                                                       \
+        TNR_PP_MFMA_END(1);                                                                                       \
         /* ---- phase 1: B columns 32-63 ; quadrant (lo, hi) */                                                  \
         if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                              \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) bfr[BH + j][s] = *(const bf16x8*)(sb + (32 + j * 4) * 128 + boff[s]); \
         if (more) issue(1, kt + 1);                                                                              \
         TNR_PP_DUMMY_STORE(1);                                                                                   \
-        TNR_PP_SEG_END();                                                                                        \
+        TNR_PP_SEG_END(2);                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < ILO; ++i)                                                      \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
                     acc[i][2 + j] = TNR_MFMA_16x16x32(bfr[BH + j][s], af[i][s], acc[i][2 + j], 0, 0, 0);         \
-        TNR_PP_MFMA_END();                                                                                       \
+        TNR_PP_MFMA_END(3);                                                                                       \
         /* ---- phase 2: A rows 64-127 ; quadrant (hi, hi) ; B of K tile kt+1 must have landed before phase 3 reads it */ \
         if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                              \
             _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
                 if (i + 1 < IHI || tall) af[i][s] = *(const bf16x8*)(sa + (ILO + i) * 16 * 128 + foff[s]);       \
         TNR_PP_DUMMY_WAIT(2);                                                                                    \
         TNR_PP_DUMMY_STORE(2);                                                                                   \
-        TNR_PP_SEG_END();                                                                                        \
+        TNR_PP_SEG_END(4);                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
                 if (i + 1 < IHI || tall) _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
                     acc[ILO + i][2 + j] = TNR_MFMA_16x16x32(bfr[BH + j][s], af[i][s], acc[ILO + i][2 + j], 0, 0, 0); \
-        TNR_PP_MFMA_END();                                                                                       \
+        TNR_PP_MFMA_END(5);                                                                                       \
         /* ---- phase 3: B columns 0-31 of K tile kt+1 into the BH pair ; quadrant (hi, lo) ; A1(kt+1) must have landed */ \
         if (more) {                                                                                              \
             if (reads_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                          \
@@ -1372,12 +1391,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
             TNR_PP_DUMMY_WAIT(3);                                                                                \
         }                                                                                                        \
         TNR_PP_DUMMY_STORE(3);                                                                                   \
-        TNR_PP_SEG_END();                                                                                        \
+        TNR_PP_SEG_END(6);                                                                                        \
         if (mfma_on) _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
             _Pragma("unroll") for (int i = 0; i < IHI; ++i)                                                      \
                 if (i + 1 < IHI || tall) _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
                     acc[ILO + i][j] = TNR_MFMA_16x16x32(bfr[BL + j][s], af[i][s], acc[ILO + i][j], 0, 0, 0);     \
-        TNR_PP_MFMA_END();                                                                                       \
+        TNR_PP_MFMA_END(7);                                                                                       \
     }
     for (int kt2 = 0; kt2 < nk; kt2 += 2) {              // two K tiles per trip: the B register roles alternate at compile time
         TNR_PP_KTILE(kt2, 0, 2)
@@ -1388,6 +1407,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 #undef TNR_PP_DUMMY_WAIT
 #undef TNR_PP_SEG_END
 #undef TNR_PP_MFMA_END
+#ifdef TNR_NT_STAMPS
+    if (!stamped) {
+        if (lane == 0) nstamps[w * 264 + 4] = (unsigned)nk;
+        __syncthreads();
+        if (blockIdx.x < 256)
+            for (int i = tid; i < 8 * 264; i += 512) (&tnr_nt_stamp_buf[blockIdx.x][0][0])[i] = nstamps[i];
+        stamped = true;
+    }
+#endif
     pp_q_wait(qn);                                       // (the K loop's last waits were vmcnt(0) already)
     if (tid == 0) {
         qlds[1] = c0 + (int)qn;
@@ -2162,7 +2190,11 @@ static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
 // ONE table for both builds of this file (bf16 and -DTNR_BUILD_F16): it is defined in the bf16 translation unit and the fp16
 // one calls into it (tnr_pp_queue_of, declared in common.h), so a stream that launches kernels of both builds is bound once and
 // tnr_gemm_queue_reset reaches the counters whichever build's kernel was aborted.
+#ifdef TNR_NT_STAMPS
+constexpr int PP_LDS = LDS3_BYTES + 64 + 8 * 264 * 4;
+#else
 constexpr int PP_LDS = LDS3_BYTES + 64;
+#endif
 [[maybe_unused]] constexpr int PP_QUEUE_SETS = 128;
 #ifdef TNR_BUILD_F16
 static unsigned* pp_queue_of(hipStream_t st, bool reset = false) { return tnr_pp_queue_of(st, reset); }
@@ -2440,6 +2472,11 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_group)(const tnr_wgrad_problem_t* p, i
     return TNR_OK;
 }
 
+#ifdef TNR_NT_STAMPS
+extern "C" int TNR_NAME(tnr_debug_nt_stamps)(void* host_dst, int64_t bytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(tnr_nt_stamp_buf), (size_t)bytes) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef TNR_TN_STAMPS
 extern "C" int TNR_NAME(tnr_debug_tn_stamps)(void* host_dst, int64_t bytes) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(tnr_tn_stamp_buf), (size_t)bytes) == hipSuccess ? 0 : -1;
