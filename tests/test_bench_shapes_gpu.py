@@ -142,7 +142,10 @@ def test_gemm_nt_plain_loop_variant_bit_exact():
             test_gemm_nt_epilogues_at_bench_shape("fp16", name, N, K, flags)
         test_gemm_nt_epilogues_at_bench_shape("bf16", *NT_LAUNCHES[2])
     finally:
-        L.tnr_gemm_set_option(b"pp", 1)
+        L.tnr_gemm_set_option(b"pp", PP_DEFAULT)
+
+
+PP_DEFAULT = 1                            # the library's default NT main loop (tnr_gemm_set_option "pp")
 
 
 @pytest.mark.parametrize("cus", [128, 100, 8])

@@ -75,6 +75,10 @@ __device__ __forceinline__ void tile_coords(int wg, int nbm, int nbn, int GM, in
 constexpr int LUT_N = 2048;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// LDS accesses by 32-bit LDS address (the address of `smem` folded into the per-lane base once): `smem + offset` costs a v_add per
+// access otherwise, and a vector instruction in a load segment waits ~16 clk for its issue slot
+#define TNR_LDS(T, ADDR) (*(__attribute__((address_space(3))) T*)(size_t)(ADDR))
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // node i holds {f(x_i), f(x_i+1) - f(x_i)}: ONE 8-byte gather per element on the 64-bank ds_read_b64 path
 __device__ __forceinline__ void lut_build(f32x2* lut, bool grad) {
@@ -1819,10 +1823,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNGroup grp) {
 //   WAR  half 0 of step t - 1 (same stage): last read in interval 1 of step t - 1 ... overwritten from interval 1 of step t;
 //        half 1: last read in interval 3 of step t - 1, overwritten from interval 3 of step t.
 constexpr int RS_OP = 2 * TILE_BYTES;        // dY image | X image, 32 KB each per stage
-// LDS accesses by 32-bit LDS address (the address of `smem` folded into the per-lane base once): `smem + offset` costs a v_add per
-// access otherwise, and a vector instruction in a load segment waits ~16 clk for its issue slot
-#define TNR_LDS(T, ADDR) (*(__attribute__((address_space(3))) T*)(size_t)(ADDR))
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
 #ifdef TNR_TN_STAMPS
 // probe build only (make BUILD=../../tools/_tnst EXTRA=-DTNR_TN_STAMPS, tools/tn_stamps.py): every wave records s_memtime at its
 // ARRIVAL at each of the 4 barriers of m steps 32-95 (the stamp rides in front of the barrier, its latency under the barrier wait)
@@ -1969,10 +1969,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
     }
+#if defined(TNR_TN_STAMPS) && defined(TNR_TN_NOLOADSEG)      /* probe: empty load segments (what do the MFMA segments cost alone?) */
+#define TNR_RS_READS(S) __builtin_amdgcn_sched_barrier(0)
+#else
 #define TNR_RS_READS(S)                                                                                              \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[j] = TNR_LDS(const bf16x8, rax[j] + (j * 2 + (S)) * 1024);      \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) yf[i] = TNR_LDS(const bf16x8, ray[i & 3] + (i * 2 + (S)) * 1024);  \
     __builtin_amdgcn_sched_barrier(0)
+#endif
         bf16x8 yf[8], xf[4];
         unsigned ray[4], rax[4], wa[8];                     // LDS addresses: fragment reads (dY / X, by block & 3), the 8 stores
         const unsigned lds0 = lds_addr_of(smem);
@@ -2005,6 +2009,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // m step 0 is in LDS
         if (wn == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 runs one interval behind
+#if defined(TNR_TN_STAMPS) && defined(TNR_TN_NOLOADSEG)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yf[i] = TNR_LDS(const bf16x8, ray[i & 3] + (i * 2) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[j] = TNR_LDS(const bf16x8, rax[j] + (j * 2) * 1024);
+#define fetch(T_, H_) ((void)0)
+#endif
         for (int t = 0; t < nk; ++t) {
             TNR_RS_READS(0);
             fetch(t + 1, 1);                                // set B went to LDS in the MFMA segment before
@@ -2018,6 +2029,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
             dlt = 0u - dlt;
             TNR_PP_MFMA_END(3);
         }
+#if defined(TNR_TN_STAMPS) && defined(TNR_TN_NOLOADSEG)
+#undef fetch
+#endif
         if (wn == 0) __builtin_amdgcn_s_barrier();          // all waves execute the same number of barriers
 #undef TNR_RS_READS
 #undef TNR_RS_MFMAS

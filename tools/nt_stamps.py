@@ -16,6 +16,7 @@ a = (torch.randn((M, K), device=dev) * 0.5).to(td); b = (torch.randn((N, K), dev
 c = torch.zeros((M, N), device=dev, dtype=td)
 bias = torch.randn(N, device=dev); r = torch.randn((M, N), device=dev).to(td)
 L = T.lib()
+L.tnr_gemm_set_option(b"pp", int(os.environ.get("PP", 1)))
 run = lambda: T.call("tnr_gemm_nt_ex" + sfx, a, K, b, K, c, N, M, N, K, bias, r if fl & 8 else None, N if fl & 8 else 0, None, 0, fl, None)
 for _ in range(int(os.environ.get("WARM", 300))): run()
 torch.cuda.synchronize()
@@ -24,7 +25,7 @@ e0.record()
 for _ in range(20): run()
 e1.record(); torch.cuda.synchronize()
 print("C %d x %d, K %d, flags %d: %.1f us per launch (probe build)" % (M, N, K, fl, e0.elapsed_time(e1) * 50))
-W, NB = 264, 8
+W, NB = 264, int(os.environ.get("NB", 8))          # NB=4 with PP=2: the register-staged kernel has four barriers per K tile
 buf = np.zeros((256, 8, W), np.uint32)
 fn = getattr(L, "tnr_debug_nt_stamps" + sfx)
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int64]
@@ -33,7 +34,7 @@ rows = []
 for wg in range(256):
     nk = min(int(buf[wg, 0, 4]), 32)
     if nk < 6: continue
-    a_ = buf[wg, :, 8:8 + NB * nk].astype(np.int64)
+    a_ = buf[wg, :, 8:8 + 8 * nk].reshape(8, nk, 8)[:, :, :NB].reshape(8, nk * NB).astype(np.int64)    # 8 slots per K tile, NB used
     a_ = (a_ - a_[0, 0]) & 0xffffffff
     a_[a_ > (1 << 31)] -= (1 << 32)
     n = np.arange(NB + 1, NB * nk - 1)
@@ -49,8 +50,8 @@ for wg in range(256):
     rows.append(per)
 med = np.median(np.array(rows), axis=0)
 print("workgroups analysed: %d" % len(rows))
-names0 = ["L0", "M0", "L1", "M1", "L2", "M2", "L3", "M3"]
-names1 = ["M3", "L0", "M0", "L1", "M1", "L2", "M2", "L3"]
+names0 = ["L0", "M0", "L1", "M1", "L2", "M2", "L3", "M3"][:NB]
+names1 = (["M3", "L0", "M0", "L1", "M1", "L2", "M2", "L3"] if NB == 8 else ["M1", "L0", "M0", "L1"])
 print("interval  length | group 0: segment, cycles until arrival of waves 0-3 | group 1: segment, waves 4-7")
 for k in range(NB):
     print("   %d      %5.0f  |  %s  %5.0f %5.0f %5.0f %5.0f  |  %s  %5.0f %5.0f %5.0f %5.0f" % ((k, med[k, 0], names0[k]) + tuple(med[k, 1:5]) + (names1[k],) + tuple(med[k, 5:9])))
