@@ -216,6 +216,17 @@ int tnr_attpool_bwd(const void* y, const float* e, int64_t lde, const float* w2,
                     const float* alpha, const float* den, void* dy_direct, void* dpre, int64_t lddpre,
                     float* dw2_part, float* db2_part, float* db1_part, int64_t n_seq, int L, int H, void* stream);
 
+/* The same pooling (model_bert.py:15-34) for FEW, LONG sequences - the bodies of stage 1 (Post-train_KD.ipynb cell 12: 32 x 512
+ * tokens): token-parallel parts run per (sequence, 64-token chunk) or one wave per token instead of one workgroup per sequence;
+ * same arguments and outputs plus a caller-owned workspace of tnr_attpool_long_ws_elems(n_seq, L, H, Q, lddpre) floats.  Outputs
+ * equal tnr_attpool_fwd / _bwd up to fp32 rounding (chunk partials are combined in chunk order: deterministic). */
+int64_t tnr_attpool_long_ws_elems(int64_t n_seq, int L, int H, int Q, int64_t lddpre);
+int tnr_attpool_fwd_long(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
+                         float* nv, float* alpha, float* den, float* ws, int64_t n_seq, int L, int H, void* stream);
+int tnr_attpool_bwd_long(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
+                         const float* alpha, void* dy_direct, void* dpre, int64_t lddpre, float* dw2_part,
+                         float* db2_part, float* db1_part, float* ws, int64_t n_seq, int L, int H, void* stream);
+
 /* NewsEncoder pooling 'cls' (mean = 0: hidden state of token 0) or mean over all L positions (mean = 1), model_bert.py:
  * 130-135: y (n_seq*L, H) 16-bit -> nv (n_seq, H) fp32 ; backward dnv -> dy (every row written). */
 int tnr_pool_fwd(const void* y, float* nv, int64_t n_seq, int L, int H, int mean, void* stream);
@@ -462,6 +473,12 @@ int tnr_attpool_fwd_f16(const void* y, const float* e, int64_t lde, const float*
 int tnr_attpool_bwd_f16(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
                     const float* alpha, const float* den, void* dy_direct, void* dpre, int64_t lddpre,
                     float* dw2_part, float* db2_part, float* db1_part, int64_t n_seq, int L, int H, void* stream);
+int64_t tnr_attpool_long_ws_elems_f16(int64_t n_seq, int L, int H, int Q, int64_t lddpre);
+int tnr_attpool_fwd_long_f16(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
+                         float* nv, float* alpha, float* den, float* ws, int64_t n_seq, int L, int H, void* stream);
+int tnr_attpool_bwd_long_f16(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
+                         const float* alpha, void* dy_direct, void* dpre, int64_t lddpre, float* dw2_part,
+                         float* db2_part, float* db1_part, float* ws, int64_t n_seq, int L, int H, void* stream);
 int tnr_refresh_shadows_f16(const int64_t* desc, int n_desc, int64_t total_tiles, const int64_t* tile_start,
                         void* stream);
 int tnr_cast_f32_to_bf16_f16(const float* src, void* dst, int64_t n, void* stream);

@@ -304,6 +304,48 @@ def test_attpool_fwd_bwd(L):
     np.testing.assert_allclose(db2p.sum().cpu().numpy(), gb2[0], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("L", [65, 128, 500])
+@pytest.mark.parametrize("sfx", ["", "_f16"])
+def test_attpool_long_equals_the_one_workgroup_kernels(L, sfx):
+    """tnr_attpool_fwd_long / _bwd_long (stage-1 bodies, Post-train_KD.ipynb cell 12: few, long sequences; token-parallel parts per
+    64-token chunk / one wave per token) against tnr_attpool_fwd / _bwd on the same operands: every output equal up to fp32
+    rounding of the chunked sums (16-bit outputs: equal bits but for values that round differently), L = 65 (a one-token second
+    chunk), 128 and 500 (a ragged last chunk), and deterministic run to run."""
+    N, H, Q, QP = 5, 768, 200, 256
+    td = torch.bfloat16 if sfx == "" else torch.float16
+    Lr = (L + 31) // 32 * 32
+    y = dev(rnd((N * L, H), 1), td)
+    e = torch.zeros((N * L, QP), device=DEV)
+    e[:, :Q] = torch.tanh(dev(rnd((N * L, Q), 2, 0.7)))
+    w2, b2, dnv = dev(rnd((Q,), 4, 0.2)), dev(rnd((1,), 5, 0.05)), dev(rnd((N, H), 6))
+    ws = torch.zeros(T.query("tnr_attpool_long_ws_elems" + sfx, N, L, H, Q, QP), device=DEV)
+
+    def run(long):
+        nv, alpha, den = torch.zeros((N, H), device=DEV), torch.full((N, Lr), 7.0, device=DEV), torch.zeros(N, device=DEV)
+        dy = torch.zeros((N * L, H), device=DEV, dtype=td)
+        dpre = torch.ones((N * L, QP), device=DEV, dtype=td)
+        dw2p, db2p, db1p = torch.zeros((N, Q), device=DEV), torch.zeros(N, device=DEV), torch.zeros((N, QP), device=DEV)
+        if long:
+            T.call("tnr_attpool_fwd_long" + sfx, y, e, QP, w2, b2, Q, nv, alpha, den, ws, N, L, H)
+            T.call("tnr_attpool_bwd_long" + sfx, y, e, QP, w2, Q, dnv, alpha, dy, dpre, QP, dw2p, db2p, db1p, ws, N, L, H)
+        else:
+            T.call("tnr_attpool_fwd" + sfx, y, e, QP, w2, b2, Q, nv, alpha, den, N, L, H)
+            T.call("tnr_attpool_bwd" + sfx, y, e, QP, w2, Q, dnv, alpha, den, dy, dpre, QP, dw2p, db2p, db1p, N, L, H)
+        torch.cuda.synchronize()
+        return [nv, alpha, den, dy.float(), dpre.float(), dw2p, db2p, db1p]
+    ref, got, again = run(False), run(True), run(True)
+    for a_, b_ in zip(got, again):
+        assert torch.equal(a_, b_)
+    names = ["nv", "alpha", "den", "dy", "dpre", "dw2_part", "db2_part", "db1_part"]
+    for n_, r_, g_ in zip(names, ref, got):
+        # db2_part = sum_i alpha_i (dw_i - S) is a cancelling sum (0 in exact arithmetic): its rounding noise is held against the
+        # size of its neighbour dw2_part, not against itself
+        scale = (float(ref[5].abs().max()) if n_ == "db2_part" else float(r_.abs().max())) + 1e-30
+        tol = 1e-5 if n_ in ("nv", "alpha", "den") else (8e-3 if n_ in ("dy", "dpre") else 2e-4)
+        assert float((r_ - g_).abs().max()) <= tol * scale, (n_, float((r_ - g_).abs().max()), scale)
+    assert (got[1][:, L:] == 0).all() and (got[4][:, Q:] == 0).all()
+
+
 def test_sgemm_variants():
     M, N, K, Z = 150, 200, 77, 3
     A, B, bias, C0 = rnd((Z, M, K), 1), rnd((Z, N, K), 2), rnd((Z, N), 3), rnd((Z, M, N), 4)

@@ -102,6 +102,149 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const bf16* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pooling for FEW, LONG sequences (stage 1: 32 bodies of 128 ... 512 tokens).  One workgroup per sequence leaves 7 of 8
+// CUs idle and walks the tokens in latency-bound loops (round-5 profile: 240 us backward / 131 us forward at 32 x 512); here every
+// token-parallel part runs over (sequence, 64-token chunk) or one wave per token, and only the two sequence-wide scalars (the
+// softmax-free denominator, the dot product S) are sums over the whole sequence - in token order, as above.  Chunk partials are
+// combined in chunk order: deterministic, no atomics; the values differ from the one-workgroup kernels' by fp32 rounding only.
+// ws (caller-owned, tnr_attpool_long_ws_elems floats): forward [n_seq][n_chunk][H] ; backward [n_seq][L] dw, then [n_seq][n_chunk][Q + lddpre + 1].
+constexpr int AP_CH = 64;
+__global__ __launch_bounds__(256) void attpool_long_score_kernel(const float* __restrict__ e, int64_t lde, const float* __restrict__ w2,
+                                                                 const float* __restrict__ b2, int Q, float* __restrict__ alpha,
+                                                                 int64_t n_tok, int L) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tok) return;
+    const float* er = e + t * lde;
+    float s = 0.f;
+    for (int q = lane; q < Q; q += 64) s += er[q] * w2[q];
+    s = wave_sum(s);
+    const int Lr = (L + 31) & ~31;
+    if (lane == 0) alpha[(t / L) * Lr + (t % L)] = __expf(s + b2[0]);          // unnormalised; attpool_long_fwd_fin divides
+}
+__global__ __launch_bounds__(256) void attpool_long_fwd_part_kernel(const bf16* __restrict__ y, const float* __restrict__ alpha,
+                                                                    float* __restrict__ ws, int L, int H) {
+    __shared__ float al[AP_CH];
+    const int Lr = (L + 31) & ~31, nch = (L + AP_CH - 1) / AP_CH;
+    const int64_t n = blockIdx.x;
+    const int ch = blockIdx.y, i0 = ch * AP_CH, cnt = min(AP_CH, L - i0);
+    if ((int)threadIdx.x < cnt) al[threadIdx.x] = alpha[n * Lr + i0 + threadIdx.x];
+    __syncthreads();
+    for (int c = threadIdx.x * 4; c < H; c += 1024) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < cnt; ++i) {
+            bf16x4 v = *(const bf16x4*)(y + (n * L + i0 + i) * H + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += al[i] * (float)v[r];
+        }
+        *(f32x4*)(ws + (n * nch + ch) * H + c) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    }
+}
+__global__ __launch_bounds__(256) void attpool_long_fwd_fin_kernel(const float* __restrict__ ws, float* __restrict__ alpha,
+                                                                   float* __restrict__ nv, float* __restrict__ den, int L, int H) {
+    __shared__ float dsh;
+    const int Lr = (L + 31) & ~31, nch = (L + AP_CH - 1) / AP_CH;
+    const int64_t n = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float d = 0.f;
+        for (int i = 0; i < L; ++i) d += alpha[n * Lr + i];
+        dsh = d + 1e-8f;
+        den[n] = d + 1e-8f;
+    }
+    __syncthreads();
+    const float d = dsh;
+    for (int c = threadIdx.x * 4; c < H; c += 1024) {
+        f32x4 a = *(const f32x4*)(ws + (n * nch) * H + c);
+        for (int ch = 1; ch < nch; ++ch) a += *(const f32x4*)(ws + (n * nch + ch) * H + c);
+        *(f32x4*)(nv + n * H + c) = a / d;
+    }
+    for (int i = threadIdx.x; i < Lr; i += 256) alpha[n * Lr + i] = i < L ? alpha[n * Lr + i] / d : 0.f;
+}
+__global__ __launch_bounds__(256) void attpool_long_dw_kernel(const bf16* __restrict__ y, const float* __restrict__ dnv,
+                                                              float* __restrict__ dwbuf, int64_t n_tok, int L, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tok) return;
+    const int64_t n = t / L;
+    float s = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        bf16x4 v = *(const bf16x4*)(y + t * H + c);
+        f32x4 g = *(const f32x4*)(dnv + n * H + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += g[r] * (float)v[r];
+    }
+    s = wave_sum(s);
+    if (lane == 0) dwbuf[t] = s;
+}
+__global__ __launch_bounds__(256) void attpool_long_bwd_part_kernel(const float* __restrict__ e, int64_t lde, const float* __restrict__ w2,
+                                                                    int Q, const float* __restrict__ dnv, const float* __restrict__ alpha,
+                                                                    const float* __restrict__ dwbuf, bf16* __restrict__ dy,
+                                                                    bf16* __restrict__ dpre, int64_t lddpre, float* __restrict__ part,
+                                                                    int L, int H) {
+    __shared__ float prod[512], da[AP_CH], al[AP_CH];
+    __shared__ float Sred;
+    const int Lr = (L + 31) & ~31, nch = (L + AP_CH - 1) / AP_CH;
+    const int64_t n = blockIdx.x;
+    const int ch = blockIdx.y, i0 = ch * AP_CH, cnt = min(AP_CH, L - i0);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L; i += 256) prod[i] = dwbuf[n * L + i] * alpha[n * Lr + i];
+    __syncthreads();
+    if (tid == 0) {                                      // the sequence-wide dot product, in token order
+        float t = 0.f;
+        for (int i = 0; i < L; ++i) t += prod[i];
+        Sred = t;
+    }
+    __syncthreads();
+    if (tid < cnt) {
+        const float a = alpha[n * Lr + i0 + tid];
+        al[tid] = a;
+        da[tid] = a * (dwbuf[n * L + i0 + tid] - Sred);
+    }
+    __syncthreads();
+    for (int c = tid * 4; c < H; c += 1024) {
+        f32x4 g = *(const f32x4*)(dnv + n * H + c);
+        for (int i = 0; i < cnt; ++i) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)(al[i] * g[r]);
+            *(bf16x4*)(dy + (n * L + i0 + i) * H + c) = o;
+        }
+    }
+    float* const pr = part + (n * nch + ch) * (Q + lddpre + 1);
+    for (int q = tid; q < lddpre; q += 256) {
+        float sw2 = 0.f, sb1 = 0.f;
+        const float wq = q < Q ? w2[q] : 0.f;
+        for (int i = 0; i < cnt; ++i) {
+            const float ev = q < Q ? e[(n * L + i0 + i) * lde + q] : 0.f;
+            const bf16 dv = (bf16)(da[i] * wq * (1.f - ev * ev));
+            dpre[(n * L + i0 + i) * lddpre + q] = dv;
+            sb1 += (float)dv;
+            sw2 += da[i] * ev;
+        }
+        if (q < Q) pr[q] = sw2;
+        pr[Q + q] = sb1;
+    }
+    if (tid == 0) {
+        float s = 0.f;
+        for (int i = 0; i < cnt; ++i) s += da[i];
+        pr[Q + lddpre] = s;
+    }
+}
+__global__ __launch_bounds__(256) void attpool_long_bwd_fin_kernel(const float* __restrict__ part, int Q, int64_t lddpre, int nch,
+                                                                   float* __restrict__ dw2_part, float* __restrict__ db2_part,
+                                                                   float* __restrict__ db1_part) {
+    const int64_t n = blockIdx.x;
+    const int64_t W = Q + lddpre + 1;
+    for (int64_t j = threadIdx.x; j < W; j += 256) {
+        float s = part[(n * nch) * W + j];
+        for (int ch = 1; ch < nch; ++ch) s += part[(n * nch + ch) * W + j];
+        if (j < Q) dw2_part[n * Q + j] = s;
+        else if (j < Q + lddpre) { if (db1_part) db1_part[n * lddpre + (j - Q)] = s; }
+        else db2_part[n] = s;
+    }
+}
+
 #ifndef TNR_BUILD_F16
 // ------------------------------------------------------------------------------------------------
 // small batched fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain): tile 64x64, BK 16
@@ -1000,6 +1143,44 @@ extern "C" int TNR_NAME(tnr_attpool_bwd)(const void* y, const float* e, int64_t 
     hipLaunchKernelGGL(attpool_bwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, e,
                        lde, w2, Q, dnv, alpha, (bf16*)dy_direct, (bf16*)dpre, lddpre, dw2_part, db2_part, db1_part, L, H);
     TNR_CHECK_LAUNCH("tnr_attpool_bwd");
+    return TNR_OK;
+}
+
+extern "C" int64_t TNR_NAME(tnr_attpool_long_ws_elems)(int64_t n_seq, int L, int H, int Q, int64_t lddpre) {
+    const int64_t nch = (L + AP_CH - 1) / AP_CH;
+    const int64_t f = n_seq * nch * H, b = n_seq * L + n_seq * nch * (Q + lddpre + 1);
+    return f > b ? f : b;
+}
+
+extern "C" int TNR_NAME(tnr_attpool_fwd_long)(const void* y, const float* e, int64_t lde, const float* w2, const float* b2, int Q,
+                                    float* nv, float* alpha, float* den, float* ws, int64_t n_seq, int L, int H, void* stream) {
+    TNR_CHECK_ARG(y && e && w2 && b2 && nv && alpha && den && ws, "tnr_attpool_fwd_long: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 512 && (H % 4) == 0 && Q >= 1 && lde >= Q && n_seq >= 1, "tnr_attpool_fwd_long: bad shape");
+    const int64_t n_tok = n_seq * L;
+    const unsigned nch = (unsigned)((L + AP_CH - 1) / AP_CH);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attpool_long_score_kernel, dim3((unsigned)((n_tok + 3) / 4)), dim3(256), 0, st, e, lde, w2, b2, Q, alpha, n_tok, L);
+    hipLaunchKernelGGL(attpool_long_fwd_part_kernel, dim3((unsigned)n_seq, nch), dim3(256), 0, st, (const bf16*)y, (const float*)alpha, ws, L, H);
+    hipLaunchKernelGGL(attpool_long_fwd_fin_kernel, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)ws, alpha, nv, den, L, H);
+    TNR_CHECK_LAUNCH("tnr_attpool_fwd_long");
+    return TNR_OK;
+}
+
+extern "C" int TNR_NAME(tnr_attpool_bwd_long)(const void* y, const float* e, int64_t lde, const float* w2, int Q, const float* dnv,
+                                    const float* alpha, void* dy_direct, void* dpre, int64_t lddpre, float* dw2_part,
+                                    float* db2_part, float* db1_part, float* ws, int64_t n_seq, int L, int H, void* stream) {
+    TNR_CHECK_ARG(y && e && w2 && dnv && alpha && dy_direct && dpre && dw2_part && db2_part && ws, "tnr_attpool_bwd_long: null pointer");
+    TNR_CHECK_ARG(L >= 1 && L <= 512 && (H % 4) == 0 && Q >= 1 && lde >= Q && lddpre >= Q && n_seq >= 1, "tnr_attpool_bwd_long: bad shape");
+    const int64_t n_tok = n_seq * L;
+    const unsigned nch = (unsigned)((L + AP_CH - 1) / AP_CH);
+    hipStream_t st = (hipStream_t)stream;
+    float* const part = ws + n_tok;
+    hipLaunchKernelGGL(attpool_long_dw_kernel, dim3((unsigned)((n_tok + 3) / 4)), dim3(256), 0, st, (const bf16*)y, dnv, ws, n_tok, L, H);
+    hipLaunchKernelGGL(attpool_long_bwd_part_kernel, dim3((unsigned)n_seq, nch), dim3(256), 0, st, e, lde, w2, Q, dnv, alpha, (const float*)ws,
+                       (bf16*)dy_direct, (bf16*)dpre, lddpre, part, L, H);
+    hipLaunchKernelGGL(attpool_long_bwd_fin_kernel, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)part, Q, lddpre, (int)nch, dw2_part,
+                       db2_part, db1_part);
+    TNR_CHECK_LAUNCH("tnr_attpool_bwd_long");
     return TNR_OK;
 }
 

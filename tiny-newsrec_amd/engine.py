@@ -21,6 +21,7 @@ import tnr_hip as T
 PFX = "student.news_encoder."
 BERT = PFX + "bert_model.bert."
 QPAD = 256          # news pooling query dim (200) padded to the GEMM tile
+AP_LONG = 64        # sequences longer than this take the chunked pooling kernels (tnr_attpool_*_long); a rule of L alone
 
 
 def _rup(x, m):
@@ -575,6 +576,8 @@ class Engine:
                              T.query("tnr_colsum_part_elems", max(B * cfg.U, 1), 3 * D),
                              T_ * T.query("tnr_colsum_part_elems", Rt, D)))
         self.db1p = f(N, QPAD)
+        # chunked pooling kernels for few, long sequences (stage-1 bodies): their workspace
+        self.ap_ws = f(T.query("tnr_attpool_long_ws_elems", N, L, H, cfg.Qn, QPAD)) if (L > AP_LONG and cfg.pooling == "att") else None
         self.epre_u = f(B * cfg.U, cfg.Qu)
         self.epad_buf = {1: f(1, cfg.Qu), T_: f(T_, cfg.Qu)}      # student / teachers (these run on different streams)
         self.epre_t = f(T_, B * cfg.U, cfg.Qu)
@@ -795,8 +798,12 @@ class Engine:
         # pooling (model_bert.py:130-135: AttentionPooling without mask | token 0 | mean) + dense (:136)
         if cfg.pooling == "att":
             self._gemm(x, self.sh_a1, self.e, M, bias=self.b_a1, flags=T.EPI_BIAS | T.EPI_TANH | T.EPI_OUTF32)
-            self._c("tnr_attpool_fwd", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
-                   self.nv, self.alpha, self.den, n_seq, L, H)
+            if L > AP_LONG:                  # few, long sequences (stage-1 bodies): the chunked kernels fill the chip
+                self._c("tnr_attpool_fwd_long", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
+                        self.nv, self.alpha, self.den, self.ap_ws, n_seq, L, H)
+            else:
+                self._c("tnr_attpool_fwd", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
+                        self.nv, self.alpha, self.den, n_seq, L, H)
         else:
             self._c("tnr_pool_fwd", x, self.nv, n_seq, L, H, int(cfg.pooling == "mean"))
         wd = g(PFX + "dense.weight")
@@ -1087,8 +1094,12 @@ class Engine:
         rb.add(dvec, N, D, D, gr[PFX + "dense.bias"], acc)       # column sums; in place, behind the two GEMMs that read dvec
         y = self.y_last
         if cfg.pooling == "att":
-            self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
-                   self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
+            if L > AP_LONG:
+                self._c("tnr_attpool_bwd_long", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha,
+                        self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, self.ap_ws, N, L, H)
+            else:
+                self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
+                        self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
             rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], acc, gi)
             rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], acc, gi)
             rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), acc, gi)

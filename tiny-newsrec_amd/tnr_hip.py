@@ -101,6 +101,7 @@ _SIG = {
     "tnr_gemm_tn_wgrad": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _P],
     "tnr_gemm_tn_wgrad_ex": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _F, _P],
     "tnr_gemm_tn_ws_elems": [_L, _L, _I],
+    "tnr_attpool_long_ws_elems": [_L, _I, _I, _I, _L],
     "tnr_ln_fwd": [_P, _P, _P, _F, _P, _P, _L, _I, _P],
     "tnr_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "tnr_ln_bwd_part_elems": [_L, _I],
@@ -116,6 +117,8 @@ _SIG = {
     "tnr_colsum_part_elems": [_L, _L],
     "tnr_attpool_fwd": [_P, _P, _L, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P],
     "tnr_attpool_bwd": [_P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _I, _I, _P],
+    "tnr_attpool_fwd_long": [_P, _P, _L, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P],
+    "tnr_attpool_bwd_long": [_P, _P, _L, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _I, _I, _P],
     "tnr_sgemm": [_P, _L, _L, _L, _P, _P, _L, _L, _L, _P, _L, _L, _P, _L, _L, _L, _L, _I, _F, _F, _I, _P, _P],
     "tnr_sgemm_group": [_c.POINTER(SgemmProblem), _I, _P],
     "tnr_gemm_tn_wgrad_group": [_c.POINTER(WgradProblem), _I, _P],
@@ -150,7 +153,7 @@ _SIG = {
 # entry points that exist twice: bf16 (plain name) and fp16 (suffix _f16)
 TYPED = ["tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_gemm_nt", "tnr_gemm_nt_ex", "tnr_gemm_colsum_rows", "tnr_gemm_nt_route",
          "tnr_gemm_tn_wgrad", "tnr_gemm_tn_wgrad_ex", "tnr_gemm_tn_wgrad_group", "tnr_gemm_tn_ws_elems", "tnr_ln_fwd", "tnr_ln_bwd", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd",
-         "tnr_colsum", "tnr_colsum_batched", "tnr_attpool_fwd", "tnr_attpool_bwd", "tnr_refresh_shadows",
+         "tnr_colsum", "tnr_colsum_batched", "tnr_attpool_fwd", "tnr_attpool_bwd", "tnr_attpool_fwd_long", "tnr_attpool_bwd_long", "tnr_attpool_long_ws_elems", "tnr_refresh_shadows",
          "tnr_cast_f32_to_bf16", "tnr_cast_bf16_to_f32", "tnr_pool_fwd", "tnr_pool_bwd"]
 # *_do: the same with a tnr_dropout_t* in front of the stream (tnr_ln_bwd_do: the masked second output first)
 for _n in ("tnr_embed_ln_fwd", "tnr_embed_ln_fwd_indexed", "tnr_attn_l32_fwd", "tnr_attn_l32_bwd", "tnr_attn_long_fwd", "tnr_attn_long_bwd"):
@@ -161,7 +164,7 @@ _SIG["tnr_ln_bwd_do"] = _SIG["tnr_ln_bwd"][:-1] + [_P, _D, _P]
 TYPED += ["tnr_gemm_nt_do", "tnr_ln_bwd_do"]
 for _n in TYPED:
     _SIG[_n + "_f16"] = _SIG[_n]
-_RET = {"tnr_gemm_tn_ws_elems": _L, "tnr_gemm_tn_ws_elems_f16": _L, "tnr_gemm_colsum_rows_f16": _L, "tnr_gemm_colsum_rows": _L, "tnr_ln_bwd_part_elems": _L, "tnr_ln_bwd_blocks": _L, "tnr_colsum_part_elems": _L,
+_RET = {"tnr_attpool_long_ws_elems": _L, "tnr_attpool_long_ws_elems_f16": _L, "tnr_gemm_tn_ws_elems": _L, "tnr_gemm_tn_ws_elems_f16": _L, "tnr_gemm_colsum_rows_f16": _L, "tnr_gemm_colsum_rows": _L, "tnr_ln_bwd_part_elems": _L, "tnr_ln_bwd_blocks": _L, "tnr_colsum_part_elems": _L,
         "tnr_user_bwd_part_stride": _L}
 EXPORTS = sorted(_SIG) + ["tnr_last_error"]
 
