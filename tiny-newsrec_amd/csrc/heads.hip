@@ -143,12 +143,14 @@ __global__ __launch_bounds__(256) void attpool_long_fwd_part_kernel(const bf16* 
 }
 __global__ __launch_bounds__(256) void attpool_long_fwd_fin_kernel(const float* __restrict__ ws, float* __restrict__ alpha,
                                                                    float* __restrict__ nv, float* __restrict__ den, int L, int H) {
-    __shared__ float dsh;
+    __shared__ float dsh, al[512];
     const int Lr = (L + 31) & ~31, nch = (L + AP_CH - 1) / AP_CH;
     const int64_t n = blockIdx.x;
+    for (int i = threadIdx.x; i < L; i += 256) al[i] = alpha[n * Lr + i];      // (512 dependent global reads took 25 us)
+    __syncthreads();
     if (threadIdx.x == 0) {
         float d = 0.f;
-        for (int i = 0; i < L; ++i) d += alpha[n * Lr + i];
+        for (int i = 0; i < L; ++i) d += al[i];                                // the denominator, in token order
         dsh = d + 1e-8f;
         den[n] = d + 1e-8f;
     }
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void attpool_long_fwd_fin_kernel(const float* 
         for (int ch = 1; ch < nch; ++ch) a += *(const f32x4*)(ws + (n * nch + ch) * H + c);
         *(f32x4*)(nv + n * H + c) = a / d;
     }
-    for (int i = threadIdx.x; i < Lr; i += 256) alpha[n * Lr + i] = i < L ? alpha[n * Lr + i] / d : 0.f;
+    for (int i = threadIdx.x; i < Lr; i += 256) alpha[n * Lr + i] = i < L ? al[i] / d : 0.f;
 }
 __global__ __launch_bounds__(256) void attpool_long_dw_kernel(const bf16* __restrict__ y, const float* __restrict__ dnv,
                                                               float* __restrict__ dwbuf, int64_t n_tok, int L, int H) {

@@ -17,12 +17,8 @@ stats = glob.glob(raw + "/trace/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(stats)))
 steps = 25
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-with open("%s/%s_bench_kernel_stats.csv" % (out, tag), "w") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel", "calls", "calls_per_step", "total_us", "avg_us", "min_us", "max_us", "percent"])
-    for r in rows:
-        w.writerow([shortt(r["Name"]), r["Calls"], "%.1f" % (int(r["Calls"]) / steps), "%.1f" % (float(r["TotalDurationNs"]) / 1e3),
-                    "%.2f" % (float(r["AverageNs"]) / 1e3), "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3), r["Percentage"]])
+# (the per-kernel table of the timed steps is written by tools/trace_window.py since round 5: <tag>_bench_kernel_stats.csv, cut to the
+# timed window; this script keeps the PMC summaries)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(raw + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -51,7 +47,7 @@ raw_agg = collections.defaultdict(lambda: collections.defaultdict(list))      # 
 for f in glob.glob(raw + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         raw_agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k in ("gemm_tn_pp_kernel", "slab_reduce_kernel", "attn_fwd_kernel", "attn_bwd_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "embed_ln_kernel",
+for k in ("gemm_tn_rs_kernel", "gemm_tn_pp_kernel", "slab_reduce_kernel", "attn_fwd_kernel", "attn_bwd_kernel", "ln_fwd_kernel", "ln_bwd_kernel", "embed_ln_kernel",
           "attpool_fwd_kernel", "attpool_bwd_kernel", "amsgrad_kernel", "sgemm_group_kernel", "user_fwd_fused_kernel"):
     vals = collections.defaultdict(list)
     for name, cs in raw_agg.items():
