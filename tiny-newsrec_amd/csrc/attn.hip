@@ -394,24 +394,30 @@ __device__ __forceinline__ bf16x8 ld_frag(const bf16* base, int64_t ld, int row,
     return *(const bf16x8*)(base + (int64_t)row * ld + 16 * s + 8 * h);
 }
 
+// Round 5: the four waves of a workgroup take four CONSECUTIVE query tiles of ONE (sequence, head) and share its key / value
+// tiles - each 32-key tile is loaded once per workgroup (256 threads x 16 bytes for K, the same for V, coalesced rows) through
+// registers into a double-buffered LDS pair, the next tile's loads in flight under the current tile's MFMAs and softmax.  Before,
+// every wave loaded every K fragment (strided 16-byte pieces) and V tile of its (sequence, head) by itself, one after the other
+// with nothing in flight: 2.8 x the algorithmic fabric traffic, 2 TB/s, MFMA busy 0.08 (profiles/r05_stage1_24_512_pmc.json).
 __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                             const float* __restrict__ rel, bf16* __restrict__ ctx,
                                                             float* __restrict__ lse, int64_t n_items, int L, int Lr, int A,
                                                             TnrDrop drop) {
-    __shared__ __attribute__((aligned(16))) char lds[4][TB];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int64_t item = (int64_t)blockIdx.x * 4 + w;
-    const bool valid = item < n_items;
-    if (!valid) item = n_items - 1;
-    const int nqt = Lr >> 5;
-    const int qt = (int)(item % nqt);
-    const int64_t na = item / nqt;
+    __shared__ __attribute__((aligned(16))) char sk[2][TB], sv[2][TB], so[4][TB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nqt = Lr >> 5, nqg = (nqt + 3) >> 2;
+    const int qg = (int)(blockIdx.x % nqg);
+    const int64_t na = blockIdx.x / nqg;                   // (sequence, head): n_items = pairs x query tiles is the host's bound
+    (void)n_items;
     const int64_t n = na / A;
     const int a = (int)(na - n * A);
+    const int qt_raw = qg * 4 + w;
+    const bool valid = qt_raw < nqt;                       // a wave past the last query tile still loads and keeps the barriers
+    const int qt = valid ? qt_raw : nqt - 1;
     const int HD = A * 64;
     const int64_t ldq = 3 * HD;
     const int row = lane & 31, h = lane >> 5;
-    char* my = lds[w];
+    char* my = so[w];
     const int qi = qt * 32 + row;                          // this lane's query
     const int qic = qi < L ? qi : L - 1;
     const bf16* qbase = qkv + (n * L) * ldq + a * 64;
@@ -422,19 +428,24 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restri
     float m_run = NEG_BIG, l_run = 0.f;
     const float* relq = rel + ((int64_t)a * Lr + (qi < Lr ? qi : Lr - 1)) * Lr;
     const float* mp = mask_add + n * Lr;
+    const int lr = tid >> 3, lc = tid & 7;                 // this thread's 16 bytes of a [32 keys][64] tile
+    bf16x8 kreg, vreg;
+    auto gload = [&](int kt) {
+        int rc = kt * 32 + lr;
+        rc = rc < L ? rc : L - 1;
+        kreg = *(const bf16x8*)(qbase + HD + (int64_t)rc * ldq + lc * 8);
+        vreg = *(const bf16x8*)(qbase + 2 * HD + (int64_t)rc * ldq + lc * 8);
+    };
+    gload(0);
     for (int kt = 0; kt < nqt; ++kt) {
-        const int kj = kt * 32 + row;
-        const int kjc = kj < L ? kj : L - 1;
+        const int cur = kt & 1;
+        *(bf16x8*)(sk[cur] + lr * TS + lc * 16) = kreg;
+        *(bf16x8*)(sv[cur] + lr * TS + lc * 16) = vreg;
+        __syncthreads();                                   // tile kt is in LDS ; everybody has left tile kt - 1 (the other buffer pair)
+        if (kt + 1 < nqt) gload(kt + 1);
         bf16x8 kf[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) kf[s] = ld_frag(qbase + HD, ldq, kjc, h, s);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {                      // V tile -> LDS (row-major [32 keys][64])
-            int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
-            int rc = kt * 32 + r;
-            rc = rc < L ? rc : L - 1;
-            *(bf16x8*)(my + r * TS + c * 16) = *(const bf16x8*)(qbase + 2 * HD + (int64_t)rc * ldq + c * 8);
-        }
+        for (int s = 0; s < 4; ++s) kf[s] = *(const bf16x8*)(sk[cur] + row * TS + (16 * s + 8 * h) * 2);
         f32x16 st = zero16();
 #pragma unroll
         for (int s = 0; s < 4; ++s) st = TNR_MFMA_32x32x16(kf[s], qf[s], st, 0, 0, 0);
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) o[ct] = TNR_MFMA_32x32x16(tr_frag(my, s, ct, lane), pf[s], o[ct], 0, 0, 0);
+            for (int s = 0; s < 2; ++s) o[ct] = TNR_MFMA_32x32x16(tr_frag(sv[cur], s, ct, lane), pf[s], o[ct], 0, 0, 0);
         }
     }
     const float inv = 1.0f / l_run;
@@ -740,7 +751,8 @@ extern "C" int TNR_NAME(tnr_attn_long_fwd_do)(const void* qkv, const float* mask
     TNR_CHECK_ARG(L >= 1 && L <= 512 && A >= 1 && n_seq >= 1, "tnr_attn_long_fwd: need 1<=L<=512");
     const int Lr = (L + 31) / 32 * 32;
     int64_t items = n_seq * A * (Lr / 32);
-    hipLaunchKernelGGL(attn_long_fwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    const int64_t blocks = n_seq * A * ((Lr / 32 + 3) / 4);      // one workgroup = four consecutive query tiles of one (sequence, head)
+    hipLaunchKernelGGL(attn_long_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)qkv, mask_add, rel, (bf16*)ctx, lse, items, L, Lr, A, dd);
     TNR_CHECK_LAUNCH("tnr_attn_long_fwd");
     return TNR_OK;
