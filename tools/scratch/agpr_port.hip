@@ -1,7 +1,8 @@
-// Does an MFMA's result write-back share a register-file port with the LDS read returns of the OTHER wave on its SIMD, and does it
-// matter whether the accumulators are VGPRs or AGPRs?  One 512-thread workgroup per CU: waves 0-3 issue back-to-back
-// v_mfma_f32_16x16x32_f16 on 16 accumulators, waves 4-7 (their SIMD partners) stream ds_read_b128 (or nothing).  Prints cycles per
-// MFMA (s_memtime) for {VGPR, AGPR accumulators} x {partner idle, partner reading LDS}.
+// What slows an MFMA stream when its SIMD partner works?  One 512-thread workgroup per CU: waves 0-3 issue v_mfma_f32_16x16x32_f16
+// (16 accumulators, back to back, priority 1); waves 4-7 - their SIMD partners - do one of: nothing, stream ds_read_b128, stream
+// global_load_dwordx4 from an L2-resident buffer, stream LDS-DMA (global_load_lds_dwordx4), or a mix like a GEMM load segment
+// (8 reads + 2 DMA per 16 partner MFMAs, barrier-free).  Variants of the MFMA wave: accumulators in VGPRs / AGPRs; operands constant
+// or re-read from LDS before every group of 16 (ds_read_b128 x 2 + s_waitcnt).  Prints cycles per MFMA (s_memtime).
 //   hipcc -O3 --offload-arch=gfx950 tools/scratch/agpr_port.hip -o tools/scratch/agpr_port && tools/scratch/agpr_port
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -9,8 +10,8 @@
 typedef __attribute__((ext_vector_type(8))) _Float16 h8;
 typedef __attribute__((ext_vector_type(4))) float f4;
 
-template <bool AGPR, bool READS>
-__global__ __launch_bounds__(512, 2) void k(unsigned long long* out, int iters) {
+template <bool AGPR, int PARTNER, bool REREAD>
+__global__ __launch_bounds__(512, 2) void k(unsigned long long* out, const f4* gbuf, int iters) {
     __shared__ __attribute__((aligned(16))) char lds[65536];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -24,6 +25,10 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, int iters) 
         __builtin_amdgcn_s_setprio(1);
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         for (int it = 0; it < iters; ++it) {
+            if (REREAD) {
+                a = *(const h8*)(lds + lane * 16 + ((it * 2048) & 32767));
+                b = *(const h8*)(lds + 32768 + lane * 16 + ((it * 2048) & 16383));
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
@@ -35,37 +40,58 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, int iters) 
         for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
         if (lane == 0) out[blockIdx.x * 8 + w] = t1 - t0;
         if (s == 12345.678f) out[0] = 0;
-    } else if (READS) {
+    } else if (PARTNER) {
         const char* p = lds + lane * 16;
+        const f4* gp = gbuf + (blockIdx.x & 63) * 1024 + lane;      // 64 KB windows: L2-resident
         f4 sink = (f4){0.f, 0.f, 0.f, 0.f};
         for (int it = 0; it < iters; ++it) {
+            if (PARTNER == 1 || PARTNER == 4) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {          // 8 reads per 16 MFMAs: the v8 NT kernel's ratio beside a 16-MFMA segment
-                f4 v = *(const f4*)(p + ((i * 1024 + it * 64) & 65535 & ~15));
-                sink += v;
+                for (int i = 0; i < 8; ++i) sink += *(const f4*)(p + ((i * 1024 + it * 64) & 65535 & ~15));
+            }
+            if (PARTNER == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sink += __builtin_nontemporal_load(gp + ((i * 64 + it * 256) & 1023 & ~63));
+            }
+            if (PARTNER == 3 || PARTNER == 4) {
+#pragma unroll
+                for (int i = 0; i < (PARTNER == 3 ? 4 : 2); ++i)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gp + ((i * 64 + it * 256) & 1023 & ~63)),
+                                                     (void __attribute__((address_space(3)))*)(lds + 49152 + (w - 4) * 4096 + i * 1024), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (sink[0] == 12345.678f) out[1] = 0;
     }
 }
 
 int main() {
     unsigned long long* d;
-    hipMalloc(&d, 256 * 8 * 8);
+    f4* g;
+    (void)hipMalloc(&d, 256 * 8 * 8);
+    (void)hipMalloc(&g, 64 * 1024 * 16);
+    (void)hipMemset(g, 0, 64 * 1024 * 16);
     const int iters = 2000;
     std::vector<unsigned long long> h(256 * 8);
     auto run = [&](auto kern, const char* name) {
-        hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, d, iters);
-        hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, d, iters);
-        hipDeviceSynchronize();
-        hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, d, g, iters);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, d, g, iters);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
         double s = 0; int n = 0;
         for (int b = 0; b < 256; ++b) for (int w = 0; w < 4; ++w) { s += (double)h[b * 8 + w]; ++n; }
-        printf("%-44s %.2f cycles per MFMA\n", name, s / n / (iters * 16.0));
+        printf("%-72s %.2f cycles per MFMA\n", name, s / n / (iters * 16.0));
     };
-    run(k<false, false>, "accumulators in VGPRs, partner idle");
-    run(k<false, true>, "accumulators in VGPRs, partner reads LDS");
-    run(k<true, false>, "accumulators in AGPRs, partner idle");
-    run(k<true, true>, "accumulators in AGPRs, partner reads LDS");
+    run(k<false, 0, false>, "VGPR acc, constant operands, partner idle");
+    run(k<false, 1, false>, "VGPR acc, constant operands, partner: 8 ds_read_b128 per 16 MFMAs' time");
+    run(k<false, 2, false>, "VGPR acc, constant operands, partner: global_load_dwordx4 stream");
+    run(k<false, 3, false>, "VGPR acc, constant operands, partner: LDS-DMA stream");
+    run(k<false, 4, false>, "VGPR acc, constant operands, partner: 8 ds_read + 2 LDS-DMA");
+    run(k<false, 0, true>, "VGPR acc, operands re-read from LDS per 16 MFMAs, partner idle");
+    run(k<false, 1, true>, "VGPR acc, operands re-read from LDS, partner: ds_read stream");
+    run(k<false, 4, true>, "VGPR acc, operands re-read from LDS, partner: 8 ds_read + 2 LDS-DMA");
+    run(k<true, 0, false>, "AGPR acc, constant operands, partner idle");
+    run(k<true, 4, true>, "AGPR acc, operands re-read from LDS, partner: 8 ds_read + 2 LDS-DMA");
     return 0;
 }
