@@ -150,13 +150,18 @@ int64_t tnr_gemm_tn_ws_elems(int64_t N, int64_t K, int splits);
  * q / k / v + output Linears of :205-231) - in ONE persistent launch + one slab-sum launch: the (split, tile) units of all of
  * them are pulled from one queue, each computed exactly as in its own tnr_gemm_tn_wgrad_ex call (same unit partition, same slab
  * order: bit-identical results).  Every problem has its own `ws`.  Problems off the 256 x 256 route (N or K not a multiple of
- * 256) make the call fall back to one launch per problem. */
+ * 256) make the call fall back to one launch per problem.
+ * accumulate == 2 CHAINS a problem to its predecessor: another row range of the same gradient (same dW, N, K, lddw, out_scale;
+ * operands and M of its own) - the two encoder passes of a stage-1 step, Post-train_KD.ipynb cell 12, whose autograd sums their
+ * contributions to every shared weight.  Its `ws` is ignored: its slabs follow the predecessor's in the chain HEAD's workspace,
+ * which must hold (sum of the chain's `splits`) * N * K floats, and ONE fixed-order slab sum covers the chain (the head's
+ * `accumulate` decides whether dW is overwritten or added to). */
 typedef struct {
     const void* dY; int64_t lddy;
     const void* X; int64_t ldx;
     float* dW; int64_t lddw;
     int64_t M, N, K;
-    float* ws;               /* splits * N * K fp32, this problem's own */
+    float* ws;               /* splits * N * K fp32, this problem's own (chained problems: see above) */
     int splits, accumulate;
     float out_scale;
 } tnr_wgrad_problem_t;

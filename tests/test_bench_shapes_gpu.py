@@ -471,3 +471,59 @@ def test_wgrad_group_with_fewer_units_than_xcd_labels(dtype):
     torch.cuda.synchronize()
     for q, ref in zip(probs, want):
         assert torch.equal(q["dW"], ref)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_wgrad_group_chained_problems_sum_two_row_ranges_of_one_gradient(dtype):
+    """accumulate = 2 (stage 1: the title rows and the body rows of one Linear): the chained problem's slabs follow its
+    predecessor's in the head's workspace and ONE slab sum covers both.  Checked against (a) the two single calls (write, then
+    add): the same products, summed in another association, so equal to fp32 rounding; (b) an fp64 reference; (c) itself, run
+    twice, bit for bit; (d) a chain off the persistent route (falls back to write + add: equal to (a) bit for bit); and a chain
+    whose members disagree is refused."""
+    td, sfx = TD[dtype], _sfx(dtype)
+    g = torch.Generator(device=DEV).manual_seed(23)
+    M1, M2 = 4800, 4096
+    mk = lambda M, n: (torch.randn((M, n), device=DEV, generator=g) * 0.1).to(td)
+    probs, want, ref64 = [], [], []
+    for (N, K), (s1, s2), scale in (((3 * H, H), (4, 3), 1.0 / 1024), ((H, H), (14, 14), 1.0)):
+        dy1, x1, dy2, x2 = mk(M1, N), mk(M1, K), mk(M2, N), mk(M2, K)
+        ref = torch.full((N, K), float("nan"), device=DEV)
+        ws = torch.zeros(16 * N * K, device=DEV)
+        T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy1, N, x1, K, ref, K, M1, N, K, ws, s1, 0, scale)
+        T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy2, N, x2, K, ref, K, M2, N, K, ws, s2, 1, scale)
+        want.append(ref)
+        ref64.append(((dy1.double().t() @ x1.double()) + (dy2.double().t() @ x2.double())) * scale)
+        common = dict(dW=torch.full((N, K), float("nan"), device=DEV), lddw=K, N=N, K=K, out_scale=scale)
+        probs.append(dict(common, dY=dy1, lddy=N, X=x1, ldx=K, M=M1, ws=torch.full(((s1 + s2) * N * K,), float("nan"), device=DEV),
+                          splits=s1, accumulate=0))
+        probs.append(dict(common, dY=dy2, lddy=N, X=x2, ldx=K, M=M2, ws=None, splits=s2, accumulate=2))
+    T.wgrad_group(probs, f16=dtype == "fp16")
+    torch.cuda.synchronize()
+    first = [probs[0]["dW"].clone(), probs[2]["dW"].clone()]
+    for got, ref, r64 in zip(first, want, ref64):
+        scale_ = float(r64.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-6 * scale_                    # (a)
+        assert float((got.double() - r64).abs().max()) <= 2e-5 * scale_           # (b): fp32 sums of ~9 000 16-bit products
+    for q in probs:
+        if q["accumulate"] == 0:
+            q["dW"].fill_(float("nan"))
+    T.wgrad_group(probs, f16=dtype == "fp16")
+    torch.cuda.synchronize()
+    assert torch.equal(probs[0]["dW"], first[0]) and torch.equal(probs[2]["dW"], first[1])     # (c)
+    # (d) off the 256 x 256 route
+    N, K = 384, 256
+    dy1, x1, dy2, x2 = mk(M1, N), mk(M1, K), mk(M2, N), mk(M2, K)
+    ref = torch.zeros((N, K), device=DEV)
+    ws = torch.zeros(8 * N * K, device=DEV)
+    T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy1, N, x1, K, ref, K, M1, N, K, ws, 4, 0, 1.0)
+    T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy2, N, x2, K, ref, K, M2, N, K, ws, 4, 1, 1.0)
+    common = dict(dW=torch.full((N, K), float("nan"), device=DEV), lddw=K, N=N, K=K, out_scale=1.0)
+    odd = [dict(common, dY=dy1, lddy=N, X=x1, ldx=K, M=M1, ws=torch.zeros(8 * N * K, device=DEV), splits=4, accumulate=0),
+           dict(common, dY=dy2, lddy=N, X=x2, ldx=K, M=M2, ws=None, splits=4, accumulate=2)]
+    T.wgrad_group(odd, f16=dtype == "fp16")
+    torch.cuda.synchronize()
+    assert torch.equal(odd[0]["dW"], ref)
+    with pytest.raises(T.TnrError):                            # a chain to another gradient
+        T.wgrad_group([probs[0], dict(probs[3], accumulate=2)], f16=dtype == "fp16")
+    with pytest.raises(T.TnrError):                            # a chain without a head
+        T.wgrad_group([dict(probs[1]), probs[0]], f16=dtype == "fp16")

@@ -88,6 +88,40 @@ def test_stage1_step_matches_notebook_and_oracle(dtype, case):
     assert torch.equal(g0, eng.title.flat_g)
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_stage1_chained_weight_gradients_equal_the_two_pass_form(dtype):
+    """Stage1Engine.backward runs the title and the body backward in step and launches every shared weight's gradient as one
+    chained problem (tnr_gemm_tn_wgrad_group, accumulate = 2).  Against chain_wgrad = False (title writes, body adds): everything
+    that is not a weight gradient bit for bit; weight gradients the same products summed in another association (fp32 rounding).
+    Under a bucket hook (data parallelism) the hooks fire in the same order, each after both passes' contributions are out."""
+    z, P, cfg, inp = load_stage1_case("stage1_cfg4.npz")
+    eng, B = _make(z, cfg, dtype)
+    eng.load_state_dict(P)
+    d = _dev(inp)
+    res = {}
+    for mode in ("two", "chain", "chain_hooked", "two_hooked"):
+        eng.chain_wgrad = mode.startswith("chain")
+        fired = []
+        eng.title.flat_g.fill_(float("nan"))
+        eng.forward(*d)
+        eng.backward(after_bucket=(lambda i: fired.append(i)) if mode.endswith("hooked") else None)
+        torch.cuda.synchronize()
+        res[mode] = (eng.title.flat_g.clone(), fired)
+    assert res["chain_hooked"][1] == res["two_hooked"][1] and len(res["two_hooked"][1]) == 1 + 2 * len(cfg["trainable_layers"])
+    t = eng.title
+    for a, b_ in (("chain", "two"), ("chain_hooked", "two_hooked"), ("chain", "chain_hooked")):
+        ga, gb = res[a][0], res[b_][0]
+        for k, gk in t.grads.items():
+            o = gk.storage_offset() - t.flat_g.storage_offset()
+            va, vb = ga[o:o + gk.numel()], gb[o:o + gk.numel()]
+            assert bool(torch.isfinite(va).all()), (a, k)          # every gradient was written (flat_g was all NaN)
+            if torch.equal(va, vb):
+                continue
+            is_wgrad = k.endswith(".weight") and gk.dim() == 2 and ("encoder.layer" in k or k.endswith("attn.att_fc1.weight"))
+            assert is_wgrad and (a, b_) != ("chain", "chain_hooked"), (a, b_, k)
+            assert float((va - vb).abs().max()) <= 4e-6 * float(vb.abs().max()) + 1e-12, (a, b_, k)
+
+
 def test_stage1_loss_decreases():
     z, P, cfg, inp = load_stage1_case("stage1_full.npz")
     eng, B = _make(z, cfg, "bf16")

@@ -2427,12 +2427,23 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
 
 extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_group)(const tnr_wgrad_problem_t* p, int n, void* stream) {
     TNR_CHECK_ARG(p && n >= 1 && n <= TN_MAXP, "tnr_gemm_tn_wgrad_group: 1 .. %d problems", TN_MAXP);
+    // accumulate == 2: this problem CONTINUES the sum of its predecessor - another row range (other operands, other M) of the same
+    // gradient: same dW, N, K, lddw, out_scale; its slabs follow the predecessor's in the HEAD problem's workspace and one slab
+    // sum covers the chain (stage 1: the title pass and the body pass of one Linear)
+    for (int i = 0; i < n; ++i)
+        if (p[i].accumulate == 2)
+            TNR_CHECK_ARG(i > 0 && p[i].dW == p[i - 1].dW && p[i].N == p[i - 1].N && p[i].K == p[i - 1].K && p[i].lddw == p[i - 1].lddw &&
+                              p[i].out_scale == p[i - 1].out_scale,
+                          "tnr_gemm_tn_wgrad_group: problem %d continues problem %d but differs from it in dW / N / K / lddw / out_scale", i, i - 1);
+    auto head_of = [&](int i) { while (p[i].accumulate == 2) --i; return i; };
     bool pp = tnr_gemm_opts()->tnpp && tnr_gemm_opts()->ver == 3 && n > 1;
     for (int i = 0; i < n; ++i) pp = pp && p[i].N >= 256 && p[i].K >= 256 && (p[i].N % 256) == 0 && (p[i].K % 256) == 0;
     if (!pp) {                                 // a shape off the persistent kernel's route (or one problem): one launch each, the same results
         for (int i = 0; i < n; ++i) {
-            int rc = TNR_NAME(tnr_gemm_tn_wgrad_ex)(p[i].dY, p[i].lddy, p[i].X, p[i].ldx, p[i].dW, p[i].lddw, p[i].M, p[i].N, p[i].K, p[i].ws,
-                                                     p[i].splits, p[i].accumulate, p[i].out_scale, stream);
+            // (a chained problem - accumulate 2 - simply adds to what its predecessor wrote; the head's workspace serves both in turn)
+            int rc = TNR_NAME(tnr_gemm_tn_wgrad_ex)(p[i].dY, p[i].lddy, p[i].X, p[i].ldx, p[i].dW, p[i].lddw, p[i].M, p[i].N, p[i].K,
+                                                     p[i].accumulate == 2 ? p[head_of(i)].ws : p[i].ws, p[i].splits,
+                                                     p[i].accumulate == 2 ? 1 : p[i].accumulate, p[i].out_scale, stream);
             if (rc != TNR_OK) return rc;
         }
         return TNR_OK;
@@ -2442,29 +2453,39 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_group)(const tnr_wgrad_problem_t* p, i
     int64_t units = 0, maxblk = 0;
     for (int i = 0; i < n; ++i) {
         const tnr_wgrad_problem_t& q = p[i];
-        TNR_CHECK_ARG(q.dY && q.X && q.dW && q.ws, "tnr_gemm_tn_wgrad_group: null operand");
+        const bool chained = q.accumulate == 2;
+        TNR_CHECK_ARG(q.dY && q.X && q.dW && (q.ws || chained), "tnr_gemm_tn_wgrad_group: null operand");
         TNR_CHECK_ARG(q.M >= 1 && (q.lddy % 8) == 0 && (q.ldx % 8) == 0 && (q.lddw % 4) == 0 && q.lddy >= q.N && q.ldx >= q.K && q.lddw >= q.K,
                       "tnr_gemm_tn_wgrad_group: bad shape / leading dimension (problem %d)", i);
-        TNR_CHECK_ARG(((uintptr_t)q.dY % 16) == 0 && ((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dW % 16) == 0 && ((uintptr_t)q.ws % 16) == 0,
+        TNR_CHECK_ARG(((uintptr_t)q.dY % 16) == 0 && ((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.dW % 16) == 0 &&
+                          (chained || ((uintptr_t)q.ws % 16) == 0),
                       "tnr_gemm_tn_wgrad_group: operands must be 16-byte aligned");
         TNR_CHECK_ARG(q.splits >= 1 && q.splits <= 64, "tnr_gemm_tn_wgrad_group: splits out of range");
         int Mt = (int)((q.M + 63) / 64), splits = q.splits;                       // the split arithmetic of tnr_gemm_tn_wgrad_ex
         if (splits > Mt) splits = Mt;
         const int tps = (Mt + splits - 1) / splits;
         splits = (Mt + tps - 1) / tps;
-        grp.p[i] = TNArgs{(const bf16*)q.dY, q.lddy, (const bf16*)q.X, q.ldx, q.ws, Mt, (int)q.N, (int)q.K, tps, splits, nullptr};
+        const int h = head_of(i);
+        float* const ws_i = chained ? (float*)sg.ws[h] + (int64_t)sg.splits[h] * q.N * q.K : q.ws;   // behind the chain's slabs so far
+        grp.p[i] = TNArgs{(const bf16*)q.dY, q.lddy, (const bf16*)q.X, q.ldx, ws_i, Mt, (int)q.N, (int)q.K, tps, splits, nullptr};
         grp.ubase[i] = (int)units;
         units += (q.N / 256) * (q.K / 256) * splits;
-        sg.ws[i] = q.ws; sg.out[i] = q.dW; sg.NK[i] = q.N * q.K; sg.ldo[i] = q.lddw;
-        sg.splits[i] = splits; sg.K[i] = (int)q.K; sg.accumulate[i] = q.accumulate; sg.out_scale[i] = q.out_scale;
+        sg.ws[i] = ws_i; sg.out[i] = q.dW; sg.ldo[i] = q.lddw; sg.K[i] = (int)q.K; sg.out_scale[i] = q.out_scale;
+        if (chained) {                      // its slabs are summed with the head's: no slab sum of its own
+            sg.splits[h] += splits; sg.NK[i] = 0; sg.splits[i] = 0; sg.accumulate[i] = 0;
+        } else {
+            sg.NK[i] = q.N * q.K; sg.splits[i] = splits; sg.accumulate[i] = q.accumulate;
+        }
         maxblk = std::max<int64_t>(maxblk, (q.N * q.K / 4 + 255) / 256);
     }
     if (units < 8) {
         // fewer units than XCD labels: the grid min(units, ...) would leave labels that tn_group_ranges gives work without a
         // workgroup (their units never computed, the slab sum reading unwritten slabs) -> one launch per problem, the same results
         for (int i = 0; i < n; ++i) {
-            int rc = TNR_NAME(tnr_gemm_tn_wgrad_ex)(p[i].dY, p[i].lddy, p[i].X, p[i].ldx, p[i].dW, p[i].lddw, p[i].M, p[i].N, p[i].K, p[i].ws,
-                                                     p[i].splits, p[i].accumulate, p[i].out_scale, stream);
+            // (a chained problem - accumulate 2 - simply adds to what its predecessor wrote; the head's workspace serves both in turn)
+            int rc = TNR_NAME(tnr_gemm_tn_wgrad_ex)(p[i].dY, p[i].lddy, p[i].X, p[i].ldx, p[i].dW, p[i].lddw, p[i].M, p[i].N, p[i].K,
+                                                     p[i].accumulate == 2 ? p[head_of(i)].ws : p[i].ws, p[i].splits,
+                                                     p[i].accumulate == 2 ? 1 : p[i].accumulate, p[i].out_scale, stream);
             if (rc != TNR_OK) return rc;
         }
         return TNR_OK;

@@ -601,6 +601,7 @@ class Engine:
                          # one unit per workgroup, all units equal and in lockstep, is the better schedule; kept as a switch for the
                          # data-parallel case, where a workgroup held off its CU by a collective costs a quarter of what it costs now
     _wg = None           # the collected weight gradients while a layer's backward runs
+    _wg_defer = None     # ... while a backward runs step by step beside another engine's (backward_encoder_steps)
 
     @staticmethod
     def _wgrad_splits(N, K, units=None):
@@ -624,6 +625,9 @@ class Engine:
         N, K = dw.shape
         if self._wg is not None:           # inside a layer's backward: collected, launched together by _wgrad_flush
             self._wg.append((dy, x, dw, M, N, K, acc))
+            return
+        if self._wg_defer is not None:     # stage 1: collected for a launch shared with the other pass's (Stage1Engine.backward)
+            self._wg_defer.append((dy, x, dw, M, N, K, acc))
             return
         self._c("tnr_gemm_tn_wgrad_ex", dy, dy.stride(0), x, x.stride(0), dw, dw.stride(0), M, N, K, self.ws,
                self._wgrad_splits(N, K)[0], acc, self.ginv)
@@ -1075,7 +1079,16 @@ class Engine:
     def backward_encoder(self, dvec, N, acc=0, after_bucket=None):
         """NewsEncoder backward for the N sequences of the last encode(): dvec (N,D) fp32 = d loss / d news vectors.
         acc=1 adds to the gradients already in flat_g (second pass over the same parameters, stage 1)."""
+        for _ in self.backward_encoder_steps(dvec, N, acc, after_bucket):
+            pass
+
+    def backward_encoder_steps(self, dvec, N, acc=0, after_bucket=None, defer=False, split_ffn=False):
+        """backward_encoder as a generator.  defer=True (stage 1): the weight gradients are not launched but collected in
+        self._wg_defer, and the generator yields wherever they have to be on their way - after the pooling head, after every
+        trainable layer (and, split_ffn, after its FFN block: the point a gradient bucket completes) - so that a caller running
+        two passes over the same parameters in step can launch both passes' contributions to a weight as ONE chained problem."""
         cfg = self.cfg
+        self._wg_defer = [] if defer else None
         L, D, H, I = cfg.L, cfg.D, cfg.H, cfg.I
         M = N * L
         g, gr = self.p, self.grads
@@ -1107,9 +1120,12 @@ class Engine:
             rb.flush()
         if cfg.pooling == "att":
             self._wgrad(self.dpre, y, self._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M, acc)
+        if defer:
+            yield "heads"
         if after_bucket:
             after_bucket(0)
         if not cfg.trainable_layers:
+            self._wg_defer = None
             return
         if cfg.pooling == "att":
             self._gemm(self.dpre, self.sh_a1T, self.dy, M, res=self.dy2, flags=T.EPI_RES)
@@ -1128,7 +1144,7 @@ class Engine:
             # (attention block of layer lo) is then a third of a layer instead of a whole one
             # (without a bucket hook - one GPU - nothing waits for any bucket: the partial sums of all layers and of the heads go
             # into one batched reduction at the end of the backward)
-            self._wg = [] if (tr and self.group_wgrad) else None
+            self._wg = [] if (tr and self.group_wgrad and not defer) else None
             rba = (rb_heads if one else self.red.setdefault((l, acc, N, "att"), _ReduceBatch(self.dev))) if tr else None
             rb = (rb_heads if one else self.red.setdefault((l, acc, N, "ffn"), _ReduceBatch(self.dev))) if tr else None
             P = self.lpart.get(l)
@@ -1156,6 +1172,8 @@ class Engine:
                 self._wgrad(self.du, a["h1"], gr[names[10]], M, acc)
                 if not one:
                     rb.flush()
+                if defer and split_ffn:
+                    yield (l, "ffn")
                 if after_bucket:
                     if self._wg is not None:
                         self._wgrad_flush()            # the FFN block's two gradients: its bucket goes out now
@@ -1185,6 +1203,8 @@ class Engine:
                 if self._wg is not None:               # all four of the layer (two under a bucket hook), before the next layer overwrites their operands
                     self._wgrad_flush()
                     self._wg = None
+                if defer:
+                    yield (l, "att")
                 if not one:
                     rba.flush()
             if l > self.lo:
@@ -1196,6 +1216,7 @@ class Engine:
                 bucket += 1
         if one:
             rb_heads.flush()
+        self._wg_defer = None
 
     def grad(self, name):
         """Gradient of a trainable parameter (a view into flat_g; the fp16 loss scale never reaches it)."""

@@ -10,7 +10,9 @@ for the weighted sum is evaluated as the stacked product it intends (oracle/news
 that reading against the notebook's own modules).
 
 One model, two sequence lengths: two Engine instances share parameters / gradients / optimiser state / 16-bit
-weight copies and own their workspaces.  The title pass writes its gradients, the body pass accumulates.
+weight copies and own their workspaces.  Their backwards run in step, layer by layer: the bias / LayerNorm sums of the title pass
+are written and those of the body pass added; every weight gradient is ONE chained problem over the title rows and the body rows
+(tnr_gemm_tn_wgrad_group, accumulate = 2).
 Student rows live in one table S = [B*(1+K) title rows | B body rows], the layout tnr_kd_embed_loss and
 tnr_score_bwd already use in stage 2 with the body vector in the "user" slot.
 
@@ -38,6 +40,7 @@ class Stage1Engine:
         self.title = Engine(self.cfg_t, device, max_batch=batch, dtype=dtype)
         self.body = Engine(self.cfg_b, device, max_batch=batch, dtype=dtype, share=self.title)
         self.dev = self.title.dev
+        self.ws = None               # slabs of the chained weight gradients (allocated by the first backward)
 
     def set_dropout(self, p_hidden, p_attn, seed):
         """Train-mode dropout of both encoder passes (tnlrv3/config/*.json:2,4 under Post-train_KD.ipynb cell 19:6)."""
@@ -147,11 +150,53 @@ class Stage1Engine:
         B, N, Rt = self.cur
         C, D = self.cfg_t.C, self.cfg_t.D
         S, dS = t.S[:Rt], t.dS
+        # the title pass's heads batch (backward_encoder's key): merged into one reduction at its end unless it flushes by bucket
+        one_t = t.merge_reductions and not (self.chain_wgrad and after_bucket is not None)
         if self.cfg_t.T:
-            t._transform_grads(Rt, t.red.setdefault(("heads", 0, N, t.merge_reductions), _ReduceBatch(t.dev)))   # the title pass's batch (no bucket hook there)
+            t._transform_grads(Rt, t.red.setdefault(("heads", 0, N, one_t), _ReduceBatch(t.dev)))
         T.call("tnr_score_bwd", S, t.cidx, S[N:], t.dscore, dS, dS[N:], B, C, D)
-        t.backward_encoder(dS[:N], N, acc=0)
-        b.backward_encoder(dS[N:Rt], B, acc=1, after_bucket=after_bucket)
+        if not self.chain_wgrad:
+            t.backward_encoder(dS[:N], N, acc=0)
+            b.backward_encoder(dS[N:Rt], B, acc=1, after_bucket=after_bucket)
+            return
+        # The two passes' backwards in step, layer by layer: every shared weight gets ONE chained weight-gradient problem (title
+        # rows, then body rows; one fixed-order slab sum) instead of a launch + slab sum that writes and a launch + slab sum that
+        # adds.  The title's segment runs first, so wherever both flush partial sums the writing flush precedes the adding one;
+        # under a bucket hook the title pass flushes bucket by bucket as well (a hook of its own that does nothing).
+        hooked = after_bucket is not None
+        gt = t.backward_encoder_steps(dS[:N], N, acc=0, after_bucket=(lambda i: None) if hooked else None, defer=True, split_ffn=hooked)
+        gb = b.backward_encoder_steps(dS[N:Rt], B, acc=1, after_bucket=after_bucket, defer=True, split_ffn=hooked)
+        while True:
+            at, ab = next(gt, None), next(gb, None)
+            assert at == ab, (at, ab)
+            if at is None:
+                break
+            self._wgrad_flush_chained()
+
+    chain_wgrad = True      # False: the title pass writes, the body pass accumulates (two launches + two slab sums per weight)
+
+    def _wgrad_flush_chained(self):
+        t, b = self.title, self.body
+        pt, pb = t._wg_defer, b._wg_defer
+        assert len(pt) == len(pb) and t.ginv == b.ginv
+        if self.ws is None or self.ws.numel() < 2 * t.ws.numel():
+            self.ws = torch.zeros(2 * t.ws.numel() + 256, device=self.dev, dtype=torch.float32)
+        probs, off = [], 0
+        for (dy1, x1, dw, M1, N_, K_, acc1), (dy2, x2, dw2, M2, N2, K2, acc2) in zip(pt, pb):
+            assert dw.data_ptr() == dw2.data_ptr() and (N_, K_) == (N2, K2) and acc1 == 0 and acc2 == 1
+            total = t._wgrad_splits(N_, K_)[0]                   # the units of one round, shared out by rows
+            s1 = min(max(1, round(total * M1 / (M1 + M2))), max(1, total - 1))
+            s2 = max(1, total - s1)
+            elems = (s1 + s2) * N_ * K_
+            common = dict(dW=dw, lddw=dw.stride(0), N=N_, K=K_, out_scale=t.ginv)
+            probs.append(dict(common, dY=dy1, lddy=dy1.stride(0), X=x1, ldx=x1.stride(0), M=M1, ws=self.ws[off:off + elems], splits=s1,
+                              accumulate=0))
+            probs.append(dict(common, dY=dy2, lddy=dy2.stride(0), X=x2, ldx=x2.stride(0), M=M2, ws=None, splits=s2, accumulate=2))
+            off += (elems + 63) // 64 * 64
+            assert off <= self.ws.numel()
+        for i in range(0, len(probs), 4):
+            T.wgrad_group(probs[i:i + 4], f16=t.f16)
+        del pt[:], pb[:]
 
     def bucket_ranges(self):
         return self.title.bucket_ranges()
