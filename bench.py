@@ -295,6 +295,9 @@ def main():
             nd = 20000
             s1 = Stage1Engine(n_layers=2, trainable_layers=(0, 1), num_teachers=4, npratio=Kn, title_len=Lt, body_len=Lb, device=dev,
                               batch=B, dtype="fp16")
+            for knob in ("chain_wgrad", "two_streams"):              # A/B switches of tools/ only (defaults = the class's)
+                if os.environ.get("TNR_S1_" + knob.upper()) is not None:
+                    setattr(s1, knob, os.environ["TNR_S1_" + knob.upper()] == "1")
             s1.load_state_dict({k: torch.from_numpy(hashinit.init_tensor(seed, k, tuple(sh))) for k, sh in s1.shapes.items()})
             s1.title.refresh_shadows(all_layers=True)
             s1.body.refresh_rel()

@@ -99,16 +99,19 @@ def test_stage1_chained_weight_gradients_equal_the_two_pass_form(dtype):
     eng.load_state_dict(P)
     d = _dev(inp)
     res = {}
-    for mode in ("two", "chain", "chain_hooked", "two_hooked"):
+    for mode in ("two", "chain", "chain_hooked", "two_hooked", "chain_streams"):
         eng.chain_wgrad = mode.startswith("chain")
+        eng.two_streams = mode.endswith("streams")       # the body pass on a second stream: the same kernels on the same operands
         fired = []
         eng.title.flat_g.fill_(float("nan"))
         eng.forward(*d)
         eng.backward(after_bucket=(lambda i: fired.append(i)) if mode.endswith("hooked") else None)
         torch.cuda.synchronize()
-        res[mode] = (eng.title.flat_g.clone(), fired)
+        res[mode] = (eng.title.flat_g.clone(), fired, eng.title.losses.clone(), eng.title.S.clone())
     assert res["chain_hooked"][1] == res["two_hooked"][1] and len(res["two_hooked"][1]) == 1 + 2 * len(cfg["trainable_layers"])
     t = eng.title
+    for k in (0, 2, 3):
+        assert torch.equal(torch.nan_to_num(res["chain"][k]), torch.nan_to_num(res["chain_streams"][k])), k     # (flat_g's padding stays NaN)
     for a, b_ in (("chain", "two"), ("chain_hooked", "two_hooked"), ("chain", "chain_hooked")):
         ga, gb = res[a][0], res[b_][0]
         for k, gk in t.grads.items():
