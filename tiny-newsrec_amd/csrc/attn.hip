@@ -510,26 +510,30 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restri
     }
 }
 
-// backward pass 1: dQ per (sequence, head, query tile); also writes delta_i = sum_d dO[i][d] O[i][d]
+// backward pass 1: dQ per (sequence, head, query tile); also writes delta_i = sum_d dO[i][d] O[i][d].
+// Round 5, as the forward: the four waves of a workgroup take four consecutive query tiles of ONE (sequence, head) and share its
+// K / V tiles (loaded once per workgroup, 16 bytes per thread each, coalesced rows, through registers into a double-buffered LDS
+// pair with the next tile in flight); the K tile in LDS serves both as the S^T operand (rows) and, read transposed, as the dQ
+// product's.  The same arithmetic in the same order as the one-wave-per-item kernel it replaces: bit-identical results.
 __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                                const float* __restrict__ rel, const bf16* __restrict__ ctx,
                                                                const bf16* __restrict__ dctx, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                                int64_t n_items, int L, int Lr, int A, TnrDrop drop) {
-    __shared__ __attribute__((aligned(16))) char lds[4][TB];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int64_t item = (int64_t)blockIdx.x * 4 + w;
-    const bool valid = item < n_items;
-    if (!valid) item = n_items - 1;
-    const int nqt = Lr >> 5;
-    const int qt = (int)(item % nqt);
-    const int64_t na = item / nqt;
+    __shared__ __attribute__((aligned(16))) char lds[4][TB];             // K pair, V pair ; after the loop: one staging tile per wave
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    (void)n_items;
+    const int nqt = Lr >> 5, nqg = (nqt + 3) >> 2;
+    const int qg = (int)(blockIdx.x % nqg);
+    const int64_t na = blockIdx.x / nqg;
     const int64_t n = na / A;
     const int a = (int)(na - n * A);
+    const int qt_raw = qg * 4 + w;
+    const bool valid = qt_raw < nqt;                       // a wave past the last query tile still loads and keeps the barriers
+    const int qt = valid ? qt_raw : nqt - 1;
     const int HD = A * 64;
     const int64_t ldq = 3 * HD;
     const int row = lane & 31, h = lane >> 5;
-    char* my = lds[w];
     const int qi = qt * 32 + row;
     const int qic = qi < L ? qi : L - 1;
     const bf16* qbase = qkv + (n * L) * ldq + a * 64;
@@ -556,15 +560,27 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
     const float* relq = rel + ((int64_t)a * Lr + (qi < Lr ? qi : Lr - 1)) * Lr;
     const float* mp = mask_add + n * Lr;
     f32x16 dq[2] = {zero16(), zero16()};
+    const int lr = tid >> 3, lc = tid & 7;                 // this thread's 16 bytes of a [32 keys][64] tile
+    bf16x8 kreg, vreg;
+    auto gload = [&](int kt) {
+        int rc = kt * 32 + lr;
+        rc = rc < L ? rc : L - 1;
+        kreg = *(const bf16x8*)(qbase + HD + (int64_t)rc * ldq + lc * 8);
+        vreg = *(const bf16x8*)(qbase + 2 * HD + (int64_t)rc * ldq + lc * 8);
+    };
+    gload(0);
     for (int kt = 0; kt < nqt; ++kt) {
-        const int kj = kt * 32 + row;
-        const int kjc = kj < L ? kj : L - 1;
+        char* sk = lds[kt & 1];
+        char* sv = lds[2 + (kt & 1)];
+        *(bf16x8*)(sk + lr * TS + lc * 16) = kreg;
+        *(bf16x8*)(sv + lr * TS + lc * 16) = vreg;
+        __syncthreads();                                   // tile kt is in LDS ; everybody has left tile kt - 1 (the other pair)
+        if (kt + 1 < nqt) gload(kt + 1);
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            kf[s] = ld_frag(qbase + HD, ldq, kjc, h, s);
-            vf[s] = ld_frag(qbase + 2 * HD, ldq, kjc, h, s);
-            *(bf16x8*)(my + row * TS + (16 * s + 8 * h) * 2) = kf[s];       // K tile for the dQ product
+            kf[s] = *(const bf16x8*)(sk + row * TS + (16 * s + 8 * h) * 2);
+            vf[s] = *(const bf16x8*)(sv + row * TS + (16 * s + 8 * h) * 2);
         }
         f32x16 st = zero16(), dpt = zero16();
 #pragma unroll
@@ -589,8 +605,10 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) dq[ct] = TNR_MFMA_32x32x16(dsf[s], tr_frag(my, s, ct, lane), dq[ct], 0, 0, 0);
+            for (int s = 0; s < 2; ++s) dq[ct] = TNR_MFMA_32x32x16(dsf[s], tr_frag(sk, s, ct, lane), dq[ct], 0, 0, 0);
     }
+    __syncthreads();                                       // the last tiles have been read: the four buffers become staging tiles
+    char* my = lds[w];
     acc_to_lds(my, dq[0], 0, lane, 0.125f);
     acc_to_lds(my, dq[1], 1, lane, 0.125f);
 #pragma unroll
@@ -601,27 +619,29 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
     }
 }
 
-// backward pass 2: dK, dV per (sequence, head, key tile), looping over the query tiles
+// backward pass 2: dK, dV per (sequence, head, key tile), looping over the query tiles.  Round 5: four consecutive key tiles of one
+// (sequence, head) per workgroup share its Q / dO tiles (one coalesced 16-byte load per thread and tile each, double-buffered through
+// registers); a wave reads its row fragments and the transposed fragments of the dK / dV products from the shared tiles.  Rows of
+// dO past L are zeroed by the loader, rows of Q past L repeat row L - 1, as the per-wave loads did: bit-identical results.
 __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                                 const float* __restrict__ rel, const bf16* __restrict__ dctx,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 bf16* __restrict__ dqkv, int64_t n_items, int L, int Lr, int A,
                                                                 TnrDrop drop) {
-    __shared__ __attribute__((aligned(16))) char lds[4][2 * TB];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int64_t item = (int64_t)blockIdx.x * 4 + w;
-    const bool valid = item < n_items;
-    if (!valid) item = n_items - 1;
-    const int nqt = Lr >> 5;
-    const int kt = (int)(item % nqt);
-    const int64_t na = item / nqt;
+    __shared__ __attribute__((aligned(16))) char lds[8][TB];             // dO pair, Q pair ; after the loop: two staging tiles per wave
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    (void)n_items;
+    const int nqt = Lr >> 5, nkg = (nqt + 3) >> 2;
+    const int kg = (int)(blockIdx.x % nkg);
+    const int64_t na = blockIdx.x / nkg;
     const int64_t n = na / A;
     const int a = (int)(na - n * A);
+    const int kt_raw = kg * 4 + w;
+    const bool valid = kt_raw < nqt;
+    const int kt = valid ? kt_raw : nqt - 1;
     const int HD = A * 64;
     const int64_t ldq = 3 * HD;
     const int row = lane & 31, h = lane >> 5;
-    char* tO = lds[w];
-    char* tQ = tO + TB;
     const int kj = kt * 32 + row;                          // this lane's key
     const int kjc = kj < L ? kj : L - 1;
     const bf16* qbase = qkv + (n * L) * ldq + a * 64;
@@ -637,21 +657,31 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_kernel(const bf16* _
     const float* lsep = lse + (n * A + a) * Lr;
     const float* dlp = delta + (n * A + a) * Lr;
     f32x16 dv[2] = {zero16(), zero16()}, dk[2] = {zero16(), zero16()};
+    const int lr = tid >> 3, lc = tid & 7;                 // this thread's 16 bytes of a [32 queries][64] tile
+    bf16x8 qreg, dreg;
+    auto gload = [&](int qt) {
+        const int q = qt * 32 + lr;
+        const int qc = q < L ? q : L - 1;
+        qreg = *(const bf16x8*)(qbase + (int64_t)qc * ldq + lc * 8);
+        dreg = *(const bf16x8*)(dobase + (int64_t)qc * HD + lc * 8);
+        if (q >= L) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dreg[e] = (bf16)0.f;
+        }
+    };
+    gload(0);
     for (int qt = 0; qt < nqt; ++qt) {
-        const int qi = qt * 32 + row;
-        const int qic = qi < L ? qi : L - 1;
+        char* tO = lds[qt & 1];
+        char* tQ = lds[2 + (qt & 1)];
+        *(bf16x8*)(tO + lr * TS + lc * 16) = dreg;
+        *(bf16x8*)(tQ + lr * TS + lc * 16) = qreg;
+        __syncthreads();                                   // tile qt is in LDS ; everybody has left tile qt - 1 (the other pair)
+        if (qt + 1 < nqt) gload(qt + 1);
         bf16x8 qf[4], df[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            qf[s] = ld_frag(qbase, ldq, qic, h, s);
-            df[s] = ld_frag(dobase, HD, qic, h, s);
-            if (qi >= L) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) df[s][e] = (bf16)0.f;
-            }
-            int off = row * TS + (16 * s + 8 * h) * 2;
-            *(bf16x8*)(tO + off) = df[s];
-            *(bf16x8*)(tQ + off) = qf[s];
+            qf[s] = *(const bf16x8*)(tQ + row * TS + (16 * s + 8 * h) * 2);
+            df[s] = *(const bf16x8*)(tO + row * TS + (16 * s + 8 * h) * 2);
         }
         f32x16 sn = zero16(), dpn = zero16();
 #pragma unroll
@@ -684,18 +714,21 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_kernel(const bf16* _
                 dk[ct] = TNR_MFMA_32x32x16(dsf[s], tr_frag(tQ, s, ct, lane), dk[ct], 0, 0, 0);
             }
     }
-    acc_to_lds(tO, dk[0], 0, lane, 0.125f);
-    acc_to_lds(tO, dk[1], 1, lane, 0.125f);
-    acc_to_lds(tQ, dv[0], 0, lane, 1.0f);
-    acc_to_lds(tQ, dv[1], 1, lane, 1.0f);
+    __syncthreads();                                       // the last tiles have been read: buffers 4-7 (unused so far) + 0-3 become staging
+    char* sK = lds[2 * w];
+    char* sV = lds[2 * w + 1];
+    acc_to_lds(sK, dk[0], 0, lane, 0.125f);
+    acc_to_lds(sK, dk[1], 1, lane, 0.125f);
+    acc_to_lds(sV, dv[0], 0, lane, 1.0f);
+    acc_to_lds(sV, dv[1], 1, lane, 1.0f);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
         int j = kt * 32 + r;
         if (valid && j < L) {
             bf16* dst = dqkv + (n * L + j) * ldq + a * 64 + c * 8;
-            *(bf16x8*)(dst + HD) = *(const bf16x8*)(tO + r * TS + c * 16);
-            *(bf16x8*)(dst + 2 * HD) = *(const bf16x8*)(tQ + r * TS + c * 16);
+            *(bf16x8*)(dst + HD) = *(const bf16x8*)(sK + r * TS + c * 16);
+            *(bf16x8*)(dst + 2 * HD) = *(const bf16x8*)(sV + r * TS + c * 16);
         }
     }
 }
@@ -772,7 +805,7 @@ extern "C" int TNR_NAME(tnr_attn_long_bwd_do)(const void* qkv, const float* mask
     TNR_CHECK_ARG(L >= 1 && L <= 512 && A >= 1 && n_seq >= 1, "tnr_attn_long_bwd: need 1<=L<=512");
     const int Lr = (L + 31) / 32 * 32;
     int64_t items = n_seq * A * (Lr / 32);
-    dim3 grid((unsigned)((items + 3) / 4)), blk(256);
+    dim3 grid((unsigned)(n_seq * A * ((Lr / 32 + 3) / 4))), blk(256);      // one workgroup = four consecutive tiles of one (sequence, head)
     hipLaunchKernelGGL(attn_long_bwd_dq_kernel, grid, blk, 0, (hipStream_t)stream, (const bf16*)qkv, mask_add, rel,
                        (const bf16*)ctx, (const bf16*)dctx, lse, delta, (bf16*)dqkv, items, L, Lr, A, dd);
     TNR_CHECK_LAUNCH("tnr_attn_long_bwd/dq");
