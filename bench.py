@@ -308,9 +308,10 @@ def main():
             rs = np.random.RandomState(seed)
             pidx = torch.from_numpy(rs.randint(1, nd, ((W2 + K2) * B, 1 + Kn)).astype(np.int32)).to(dev)
             lab1 = torch.zeros(B, dtype=torch.int64, device=dev)
+            pcol = pidx[:, 0].contiguous()                 # the positives' (= bodies') indices, as the loader hands them over
 
             def st1(i):
-                s1.forward_indexed(d_title, d_body, pidx[i * B:(i + 1) * B], lab1, d_tt, d_tb)
+                s1.forward_indexed(d_title, d_body, pidx[i * B:(i + 1) * B], lab1, d_tt, d_tb, body_idx=pcol[i * B:(i + 1) * B])
                 s1.backward()
                 s1.step(1e-5, lr_bert=1e-6, amsgrad=False)
             for i in range(W2):

@@ -217,8 +217,10 @@ def train(args):
         sums = torch.zeros(5, device=dev)                                          # loss, target, distill, emb, acc
         t0 = time.time()
         for cnt in range(1, steps + 1):
-            idx = torch.from_numpy(sample_indices(random, order[(cnt - 1) * B:cnt * B], n_docs, args.npratio)).to(dev)
-            losses, score = eng.forward_indexed(d_title, d_body, idx, label, d_tt, d_tb)
+            idx_h = sample_indices(random, order[(cnt - 1) * B:cnt * B], n_docs, args.npratio)
+            idx = torch.from_numpy(idx_h).to(dev)
+            body_idx = torch.from_numpy(np.ascontiguousarray(idx_h[:, 0])).to(dev) if idx_h.dtype == np.int32 else None
+            losses, score = eng.forward_indexed(d_title, d_body, idx, label, d_tt, d_tb, body_idx=body_idx)
             sums[0] += eng.total_loss()
             sums[1] += losses[1]
             sums[2] += losses[0]

@@ -62,10 +62,11 @@ class Stage1Engine:
     def shapes(self):
         return self.title.shapes
 
-    def forward_indexed(self, title_table, body_table, idx, label, t_title_tables, t_body_tables):
+    def forward_indexed(self, title_table, body_table, idx, label, t_title_tables, t_body_tables, body_idx=None):
         """The same step fed by index (DistillDataset.__getitem__, cell 8, at index level): title_table (n, 2Lt) and
         body_table (n, 2Lb) int32 token tables and teacher tables (T, n, D) fp32 stay in HBM; idx (B, 1+K) int32 holds the
-        positive document first, then its sampled negatives (the body is the positive's)."""
+        positive document first, then its sampled negatives (the body is the positive's).  body_idx (B,) int32 contiguous = idx[:, 0]
+        if the loader has it (saves the step its one strided copy)."""
         t, b = self.title, self.body
         cfg = self.cfg_t
         B = idx.shape[0]
@@ -77,7 +78,7 @@ class Stage1Engine:
         self.cur = (B, N, Rt)
         t.label = label.to(torch.int64).contiguous()
         tidx = idx.reshape(-1).to(torch.int32).contiguous()
-        bidx = idx[:, 0].to(torch.int32).contiguous()
+        bidx = idx[:, 0].to(torch.int32).contiguous() if body_idx is None else body_idx
         self._encode_both(lambda: b.encode(body_table, B, nidx=bidx, out=t.S[N:]), lambda: t.encode(title_table, N, nidx=tidx))
         if T_:
             T.call("tnr_gather_rows", t_title_tables, t_title_tables.shape[1], tidx, N, D, T_, t.X, t.X.shape[1], 0)
