@@ -125,6 +125,34 @@ def test_stage1_chained_weight_gradients_equal_the_two_pass_form(dtype):
             assert float((va - vb).abs().max()) <= 4e-6 * float(vb.abs().max()) + 1e-12, (a, b_, k)
 
 
+def test_stage1_training_on_two_streams_equals_one_stream_bit_for_bit():
+    """Eight optimiser steps (dropout live, the fp16 loss scaler live) with the body pass on its own stream against the same steps
+    on one stream: parameters, optimiser state and every loss equal bit for bit - the cross-stream joins order every shared
+    buffer (gradients, the chained weight-gradient slabs, the student rows) or the two runs would drift apart."""
+    z, P, cfg, inp = load_stage1_case("stage1_cfg4.npz")
+    d = _dev(inp)
+    res = []
+    for streams in (False, True, True):
+        eng, B = _make(z, cfg, "fp16")
+        eng.two_streams = streams
+        eng.load_state_dict(P)
+        eng.set_dropout(0.1, 0.1, seed=3)
+        losses = []
+        for _ in range(8):
+            l, _s = eng.forward(*d)
+            losses.append(l.clone())
+            eng.backward()
+            eng.step(1e-4, lr_bert=1e-5)
+        torch.cuda.synchronize()
+        t = eng.title
+        res.append((torch.stack(losses), t.flat[True].clone(), t.adam_m.clone(), t.adam_v.clone()))
+        del eng
+    for other in res[1:]:
+        for a, b_ in zip(res[0], other):
+            assert torch.equal(a, b_)
+    assert float(res[0][0][-1, 1]) < float(res[0][0][0, 1])         # and it trains
+
+
 def test_stage1_loss_decreases():
     z, P, cfg, inp = load_stage1_case("stage1_full.npz")
     eng, B = _make(z, cfg, "bf16")
