@@ -22,6 +22,8 @@ if os.environ.get("AB"):                  # AB=pp:1:2 -> interleaved A/B of a li
     key, va, vb = os.environ["AB"].split(":")
     PROBES = [(int(va), "%s=%s" % (key, va)), (int(vb), "%s=%s" % (key, vb))]
 PKEY = os.environ["AB"].split(":")[0] if os.environ.get("AB") else "probe"
+if os.environ.get("CUS"):                 # CUS=128 M=26400: the same tiles per CU on half the chip - does a launch-wide burst of epilogue traffic cost?
+    opt("cus", int(os.environ["CUS"]))
 tot = {n: 0.0 for _, n in PROBES}
 for name, N, K, fl, cnt in LAUNCHES:
     a = (torch.randn((M, K), device=dev) * 0.5).to(td); b = (torch.randn((N, K), device=dev) * 0.05).to(td)
