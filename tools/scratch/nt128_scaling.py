@@ -19,9 +19,13 @@ def timeit(fn, cold):
 FORCES = ("ver=1 (128 x 128)", "allow_fine=0 (256 x 256 ping-pong)")
 if os.environ.get("FINE_ST"):          # LIB=tools/_st4 (the retired four-stage ring applied): both loops of the 128 x 128 kernel
     FORCES = ("ver=1 fine_st=2", "ver=1 fine_st=4")
+if os.environ.get("FINE_NW"):          # four waves of 64 x 64 against eight of 32 x 64 per tile
+    FORCES = ("ver=1 fine_nw=4", "ver=1 fine_nw=8")
 for force in FORCES:
     if "fine_st" in force:
         T.lib().tnr_gemm_set_option(b"fine_st", int(force[-1]))
+    if "fine_nw" in force:
+        T.lib().tnr_gemm_set_option(b"fine_nw", int(force[-1]))
     T.lib().tnr_gemm_set_option(b"ver", 1 if force.startswith("ver") else 3)
     T.lib().tnr_gemm_set_option(b"allow_fine", 0 if force.startswith("allow") else 1)
     print(force)
