@@ -146,8 +146,12 @@ def main():
     ap.add_argument("--wgrad-units", type=int, default=0,
                     help="work units per workgroup of the weight-gradient kernel; 0 = 1 on one GPU, 2 under data parallelism (a "
                          "workgroup kept off its CU by an overlapped collective then costs half a round, DESIGN.md: multi-GPU)")
-    ap.add_argument("--dp-buckets", type=int, choices=[5, 3], default=5,
-                    help="gradient collectives per step: 5 = heads + FFN / attention block of each trainable layer, 3 = heads + one per layer")
+    ap.add_argument("--dp-buckets", type=int, choices=[5, 3], default=None,
+                    help="gradient collectives per step: 5 = heads + FFN / attention block of each trainable layer, 3 = heads + one per layer "
+                         "(default: 5 on one GPU; with more than one rank chosen by the warm-up autotune, see --no-dp-autotune)")
+    ap.add_argument("--no-dp-autotune", action="store_true",
+                    help="more than one rank: skip the pre-pass that times {wgrad units 2, 1} x {5, 3 buckets} for 3 + 10 untimed steps each "
+                         "and runs the headline with the fastest (max over ranks; knobs given explicitly are kept) - defaults 2 / 5 then")
     ap.add_argument("--dp-algo", choices=["allreduce", "rs_ag"], default="allreduce",
                     help="one all-reduce per bucket, or reduce-scatter + all-gather (direct exchange on the xGMI mesh)")
     ap.add_argument("--dp-sweep", action="store_true",
@@ -207,6 +211,9 @@ def main():
     B, K, W = a.batch, a.steps, a.warmup
     use_dp = world > 1 or a.force_dp
     wgrad_units = a.wgrad_units or (2 if use_dp else 1)
+    tune_units, tune_buckets = a.wgrad_units == 0, a.dp_buckets is None
+    if a.dp_buckets is None:
+        a.dp_buckets = 5
     E.Engine.WGRAD_UNITS = wgrad_units           # before any engine is built: the slab workspace is sized by it
     comb = torch.from_numpy(synth.news_table(seed, N_NEWS, cfg.L)).to(dev)
     tables = torch.from_numpy(synth.teacher_tables(seed, max(a.teachers, 1), N_NEWS, cfg.D)).to(dev)
@@ -374,6 +381,27 @@ def main():
         t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         return float(D.all_reduce_max(t).item())
 
+    autotune = None
+    if world > 1 and not a.no_dp_autotune and (tune_units or tune_buckets):
+        # The two knobs whose best setting depends on what the collectives do to the compute kernels on THIS node (how many CUs
+        # RCCL's kernels hold and for how long) cannot be set from a one-GPU lease: every rank times the candidates for 3 + 10
+        # untimed steps (the same collective sequence on every rank; max over ranks, so all ranks pick the same) and the headline's
+        # W warm-up + K timed steps then run with the fastest.  horovod's own HOROVOD_AUTOTUNE does the like for its fusion buffer.
+        K_, W_, cands = K, W, []
+        for units in ((2, 1) if tune_units else (wgrad_units,)):
+            for nb in ((5, 3) if tune_buckets else (a.dp_buckets,)):
+                E.Engine.WGRAD_UNITS, a.dp_buckets = units, nb
+                e_, g_ = build(a.dtype)
+                K, W = min(10, K_), min(3, W_)
+                d_ = timed_loop(e_, g_, False)
+                cands.append({"wgrad_units": units, "buckets": nb, "ms_per_step": round(1e3 * d_ / K, 4)})
+                del e_, g_
+                torch.cuda.empty_cache()
+        K, W = K_, W_
+        best = min(cands, key=lambda c: c["ms_per_step"])
+        wgrad_units, a.dp_buckets = best["wgrad_units"], best["buckets"]
+        E.Engine.WGRAD_UNITS = wgrad_units
+        autotune = {"candidates": cands, "chosen": best, "note": "3 + 10 untimed steps per candidate before the headline's warm-up; max over ranks"}
     eng, gs = build(a.dtype)
     dt_dedup = dt_cache = None
     if a.dedup == "also":
@@ -427,7 +455,8 @@ def main():
             gs._events = []
         dp_info = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                    "fp16_tail_ms_per_step": tail,
-                   "rccl_version": rccl, "algo": gs.algo, "wgrad_units_per_workgroup": wgrad_units,
+                   "rccl_version": rccl, "algo": gs.algo, "wgrad_units_per_workgroup": wgrad_units, "buckets": a.dp_buckets,
+                   "autotune": autotune,
                    "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                           "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY")},
                    "collectives_mb_in_launch_order": [round(x / 1e6, 2) for x in gs.collective_bytes()],

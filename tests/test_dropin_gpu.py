@@ -101,7 +101,7 @@ def test_bench_two_ranks_over_gloo_match_one_rank_on_the_concatenated_batch(tmp_
     """bench.py's OWN world > 1 path before the first 8-GPU lease runs it: `python bench.py --gpus 2` (self_launch ->
     torch.distributed.run -> two workers) with the test-only backend override - gloo, both ranks on the one GPU, B / 2 each -
     through the per-rank batches, the bucketed all-reduce with its per-bucket waits and scans (fp16 guard), max over ranks, the dp
-    object and --dp-sweep (rs_ag falls back to all-reduce off RCCL).  The parameters after the timed steps equal the one-rank run
+    object, the warm-up autotune and --dp-sweep (rs_ag falls back to all-reduce off RCCL).  The parameters after the timed steps equal the one-rank run
     on the concatenated batches (horovod's average, Tiny-NewsRec/run.py:141-149) to the bound of tests/test_dp_gpu.py.  No
     throughput figure is taken from this."""
     steps, warm, lr = 3, 1, 1e-4
@@ -119,8 +119,13 @@ def test_bench_two_ranks_over_gloo_match_one_rank_on_the_concatenated_batch(tmp_
         assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp%d" % gpus
         outs[tag] = (d, np.load(dump))
     dp = outs["two"][0]["dp"]
-    assert dp["backend"] == "gloo" and dp["algo"] == "allreduce" and dp["wgrad_units_per_workgroup"] == 2
-    assert len(dp["exposed_allreduce_ms_per_step_by_collective_rank0"]) == 5 and dp["exposed_allreduce_ms_per_step_max_over_ranks"] > 0
+    assert dp["backend"] == "gloo" and dp["algo"] == "allreduce"
+    # the warm-up autotune timed {2, 1 wgrad units} x {5, 3 buckets} and the headline ran with the fastest (the same on both ranks)
+    at = dp["autotune"]
+    assert len(at["candidates"]) == 4 and all(c["ms_per_step"] > 0 for c in at["candidates"])
+    assert at["chosen"] == min(at["candidates"], key=lambda c: c["ms_per_step"])
+    assert (dp["wgrad_units_per_workgroup"], dp["buckets"]) == (at["chosen"]["wgrad_units"], at["chosen"]["buckets"])
+    assert len(dp["exposed_allreduce_ms_per_step_by_collective_rank0"]) == dp["buckets"] and dp["exposed_allreduce_ms_per_step_max_over_ranks"] > 0
     assert dp["fp16_tail_ms_per_step"]["amsgrad"] > 0 and dp["fp16_tail_ms_per_step"]["scans"] > 0
     sw = dp["sweep"]
     assert len(sw) == 8 and all("error" not in x and x["value"] > 0 and x["algo"] == "allreduce" for x in sw), sw
