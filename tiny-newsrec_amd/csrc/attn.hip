@@ -436,13 +436,28 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restri
         kreg = *(const bf16x8*)(qbase + HD + (int64_t)rc * ldq + lc * 8);
         vreg = *(const bf16x8*)(qbase + 2 * HD + (int64_t)rc * ldq + lc * 8);
     };
+    // the additive terms of the NEXT key tile (mask of its keys, bias row pieces of this lane's query) are requested a tile ahead as
+    // well: asked for behind the score MFMAs they were a round trip to L2 / the MALL in every tile's critical path (the (A, Lr, Lr)
+    // bias table does not fit an XCD's L2: 2.2 us per tile for 0.25 us of MFMAs)
+    f32x4 mkn[4], rln[4];
+    auto aload = [&](int kt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mkn[g] = *(const f32x4*)(mp + kt * 32 + 8 * g + 4 * h);
+            rln[g] = *(const f32x4*)(relq + kt * 32 + 8 * g + 4 * h);
+        }
+    };
     gload(0);
+    aload(0);
     for (int kt = 0; kt < nqt; ++kt) {
         const int cur = kt & 1;
         *(bf16x8*)(sk[cur] + lr * TS + lc * 16) = kreg;
         *(bf16x8*)(sv[cur] + lr * TS + lc * 16) = vreg;
+        f32x4 mkc[4], rlc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { mkc[g] = mkn[g]; rlc[g] = rln[g]; }
         __syncthreads();                                   // tile kt is in LDS ; everybody has left tile kt - 1 (the other buffer pair)
-        if (kt + 1 < nqt) gload(kt + 1);
+        if (kt + 1 < nqt) { gload(kt + 1); aload(kt + 1); }
         bf16x8 kf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[s] = *(const bf16x8*)(sk[cur] + row * TS + (16 * s + 8 * h) * 2);
@@ -452,8 +467,7 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restri
         float mx = NEG_BIG;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 mk = *(const f32x4*)(mp + kt * 32 + 8 * g + 4 * h);
-            f32x4 rl = *(const f32x4*)(relq + kt * 32 + 8 * g + 4 * h);
+            const f32x4 mk = mkc[g], rl = rlc[g];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = st[4 * g + e] * 0.125f + mk[e] + rl[e];
@@ -568,14 +582,26 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
         kreg = *(const bf16x8*)(qbase + HD + (int64_t)rc * ldq + lc * 8);
         vreg = *(const bf16x8*)(qbase + 2 * HD + (int64_t)rc * ldq + lc * 8);
     };
+    f32x4 mkn[4], rln[4];                                  // the next key tile's additive terms, a tile ahead (see the forward)
+    auto aload = [&](int kt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mkn[g] = *(const f32x4*)(mp + kt * 32 + 8 * g + 4 * h);
+            rln[g] = *(const f32x4*)(relq + kt * 32 + 8 * g + 4 * h);
+        }
+    };
     gload(0);
+    aload(0);
     for (int kt = 0; kt < nqt; ++kt) {
         char* sk = lds[kt & 1];
         char* sv = lds[2 + (kt & 1)];
         *(bf16x8*)(sk + lr * TS + lc * 16) = kreg;
         *(bf16x8*)(sv + lr * TS + lc * 16) = vreg;
+        f32x4 mkc[4], rlc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { mkc[g] = mkn[g]; rlc[g] = rln[g]; }
         __syncthreads();                                   // tile kt is in LDS ; everybody has left tile kt - 1 (the other pair)
-        if (kt + 1 < nqt) gload(kt + 1);
+        if (kt + 1 < nqt) { gload(kt + 1); aload(kt + 1); }
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -590,8 +616,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_kernel(const bf16* __res
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 mk = *(const f32x4*)(mp + kt * 32 + 8 * g + 4 * h);
-            f32x4 rl = *(const f32x4*)(relq + kt * 32 + 8 * g + 4 * h);
+            const f32x4 mk = mkc[g], rl = rlc[g];
             float dm[4] = {1.f, 1.f, 1.f, 1.f};
             if (drop.thresh) tnr_drop_prob_row(drop, (uint64_t)na, Lr >> 2, qi < Lr ? qi : Lr - 1, kt * 32 + 8 * g + 4 * h, dm);
 #pragma unroll
@@ -628,7 +653,9 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_kernel(const bf16* _
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 bf16* __restrict__ dqkv, int64_t n_items, int L, int Lr, int A,
                                                                 TnrDrop drop) {
-    __shared__ __attribute__((aligned(16))) char lds[8][TB];             // dO pair, Q pair ; after the loop: two staging tiles per wave
+    // dO pair, Q pair, this wave's K and V tile (fragments re-read every query tile: held in registers for the whole loop they
+    // pushed the kernel over its 256 registers - 84 bytes of scratch per lane) ; after the loop: two staging tiles per wave
+    __shared__ __attribute__((aligned(16))) char lds[12][TB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     (void)n_items;
     const int nqt = Lr >> 5, nkg = (nqt + 3) >> 2;
@@ -646,11 +673,13 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_kernel(const bf16* _
     const int kjc = kj < L ? kj : L - 1;
     const bf16* qbase = qkv + (n * L) * ldq + a * 64;
     const bf16* dobase = dctx + (n * L) * HD + a * 64;
-    bf16x8 kf[4], vf[4];
+    char* const myK = lds[4 + 2 * w];
+    char* const myV = lds[5 + 2 * w];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        kf[s] = ld_frag(qbase + HD, ldq, kjc, h, s);
-        vf[s] = ld_frag(qbase + 2 * HD, ldq, kjc, h, s);
+        const int off = row * TS + (16 * s + 8 * h) * 2;
+        *(bf16x8*)(myK + off) = ld_frag(qbase + HD, ldq, kjc, h, s);
+        *(bf16x8*)(myV + off) = ld_frag(qbase + 2 * HD, ldq, kjc, h, s);
     }
     const float mk = mask_add[n * Lr + (kj < Lr ? kj : Lr - 1)];
     const float* relc = rel + (int64_t)a * Lr * Lr + (kj < Lr ? kj : Lr - 1);
@@ -686,8 +715,10 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_kernel(const bf16* _
         f32x16 sn = zero16(), dpn = zero16();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            sn = TNR_MFMA_32x32x16(qf[s], kf[s], sn, 0, 0, 0);             // S[i][j]: regs = queries, lanes = keys
-            dpn = TNR_MFMA_32x32x16(df[s], vf[s], dpn, 0, 0, 0);
+            const bf16x8 kfs = *(const bf16x8*)(myK + row * TS + (16 * s + 8 * h) * 2);
+            const bf16x8 vfs = *(const bf16x8*)(myV + row * TS + (16 * s + 8 * h) * 2);
+            sn = TNR_MFMA_32x32x16(qf[s], kfs, sn, 0, 0, 0);               // S[i][j]: regs = queries, lanes = keys
+            dpn = TNR_MFMA_32x32x16(df[s], vfs, dpn, 0, 0, 0);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -714,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_kernel(const bf16* _
                 dk[ct] = TNR_MFMA_32x32x16(dsf[s], tr_frag(tQ, s, ct, lane), dk[ct], 0, 0, 0);
             }
     }
-    __syncthreads();                                       // the last tiles have been read: buffers 4-7 (unused so far) + 0-3 become staging
+    __syncthreads();                                       // the last tiles have been read: buffers 0-7 become staging
     char* sK = lds[2 * w];
     char* sV = lds[2 * w + 1];
     acc_to_lds(sK, dk[0], 0, lane, 0.125f);

@@ -1,4 +1,4 @@
-"""Long-sequence attention backward of two builds of the library on the same seeded operands: outputs saved for a bitwise comparison,
+"""Long-sequence attention (forward and backward) of two builds of the library on the same seeded operands: outputs saved for a bitwise comparison,
 timing printed; GPU box.    LIB=tools/_old/libtnr_hip.so OUT=/tmp/a.pt python tools/scratch/attn_long_bwd_check.py ; (again without LIB,
 OUT=/tmp/b.pt) ; python tools/scratch/attn_long_bwd_check.py cmp /tmp/a.pt /tmp/b.pt"""
 import os, sys
@@ -37,6 +37,7 @@ for dt, td, sfx in (("fp16", torch.float16, "_f16"), ("bf16", torch.bfloat16, ""
         torch.cuda.synchronize()
         key = "%s L=%d N=%d%s" % (dt, L, N, " dropout" if site is not None else "")
         out[key + " dqkv"], out[key + " delta"] = dqkv.cpu(), delta.cpu()
+        out[key + " ctx"], out[key + " lse"] = ctx.cpu(), lse.cpu()
         if N >= 32 and dt == "fp16":
             ts = []
             for _ in range(10):
@@ -44,5 +45,11 @@ for dt, td, sfx in (("fp16", torch.float16, "_f16"), ("bf16", torch.bfloat16, ""
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); T.call("tnr_attn_long_bwd" + sfx, *ba); e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3)
-            print("%-24s bwd (dq + dkv) %.1f us" % (key, sorted(ts)[5]), flush=True)
+            tf = []
+            for _ in range(10):
+                junk.zero_()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); T.call("tnr_attn_long_fwd" + sfx, *fa); e1.record(); torch.cuda.synchronize()
+                tf.append(e0.elapsed_time(e1) * 1e3)
+            print("%-24s fwd %.1f us   bwd (dq + dkv) %.1f us" % (key, sorted(tf)[5], sorted(ts)[5]), flush=True)
 torch.save(out, os.environ.get("OUT", "/tmp/attn_long_bwd.pt"))
