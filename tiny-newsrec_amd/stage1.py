@@ -79,10 +79,15 @@ class Stage1Engine:
         t.label = label.to(torch.int64).contiguous()
         tidx = idx.reshape(-1).to(torch.int32).contiguous()
         bidx = idx[:, 0].to(torch.int32).contiguous() if body_idx is None else body_idx
-        self._encode_both(lambda: b.encode(body_table, B, nidx=bidx, out=t.S[N:]), lambda: t.encode(title_table, N, nidx=tidx))
-        if T_:
-            T.call("tnr_gather_rows", t_title_tables, t_title_tables.shape[1], tidx, N, D, T_, t.X, t.X.shape[1], 0)
-            T.call("tnr_gather_rows", t_body_tables, t_body_tables.shape[1], bidx, B, D, T_, t.X, t.X.shape[1], N)
+        def title_pass():
+            # the teacher side (row gathers, teacher scores, projections) needs nothing of the student's: in front of the title pass,
+            # where it runs beside the start of the body pass instead of alone between the encoders and the losses
+            if T_:
+                T.call("tnr_gather_rows", t_title_tables, t_title_tables.shape[1], tidx, N, D, T_, t.X, t.X.shape[1], 0)
+                T.call("tnr_gather_rows", t_body_tables, t_body_tables.shape[1], bidx, B, D, T_, t.X, t.X.shape[1], N)
+                self._teacher_side(B, N, Rt)
+            t.encode(title_table, N, nidx=tidx)
+        self._encode_both(lambda: b.encode(body_table, B, nidx=bidx, out=t.S[N:]), title_pass)
         return self._heads(B, N, Rt)
 
     def forward(self, title, body, label, teacher_titles, teacher_bodies):
@@ -100,10 +105,15 @@ class Stage1Engine:
         t.label = label.to(torch.int64).contiguous()
         b.tok[:B].copy_(body)
         t.tok[:N].copy_(title.reshape(N, 2 * cfg.L))
-        self._encode_both(lambda: b.encode(b.tok[:B], B, out=t.S[N:]), lambda: t.encode(t.tok[:N], N))    # cell 12 encodes the bodies first
         for i in range(T_):
             t.X[i, :N].copy_(teacher_titles[i].reshape(N, D))
             t.X[i, N:Rt].copy_(teacher_bodies[i].reshape(B, D))
+
+        def title_pass():
+            if T_:
+                self._teacher_side(B, N, Rt)
+            t.encode(t.tok[:N], N)
+        self._encode_both(lambda: b.encode(b.tok[:B], B, out=t.S[N:]), title_pass)    # cell 12 encodes the bodies first
         return self._heads(B, N, Rt)
 
     # The body pass on a second stream beside the title pass: most launches of either pass are partial rounds (4 800 / 4 096 token
@@ -128,24 +138,27 @@ class Stage1Engine:
             self._side = torch.cuda.Stream(self.dev)
         return self._side
 
+    def _teacher_side(self, B, N, Rt):
+        """Teacher scores <title_emb[b, c], body_emb[b]> and the teachers' projections from the teacher rows X: independent fp32
+        GEMMs of a few microseconds each - one grouped launch (each computed exactly as by its own tnr_sgemm call)."""
+        t = self.title
+        C, D, T_ = self.cfg_t.C, self.cfg_t.D, self.cfg_t.T
+        X = t.X
+        group = [t._sgemm_problem(X[i], D, 1, C * D, X[i, N:], D, 1, D, t.t_score[i], 1, C, None, 0, C, 1, D, batch=B) for i in range(T_)]
+        Wt = t._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
+        bt = t._view("transform_matrix.0.bias", T_ * D, (T_, D))
+        group.append(t._sgemm_problem(X, D, 1, X.stride(0), Wt, D, 1, D * D, t.Pm, D, t.Pm.stride(0), bt, D, Rt, D, D, batch=T_))
+        for i in range(0, len(group), 8):
+            t._sgemm_group(group[i:i + 8])
+
     def _heads(self, B, N, Rt):
         """Scores, teacher weights and the three losses from the student rows S and the teacher rows X."""
         t = self.title
         cfg = self.cfg_t
         C, D, T_ = cfg.C, cfg.D, cfg.T
         S = t.S[:Rt]
-        # score[b, c] = <title_vec[b, c], body_vec[b]> for the student and every teacher, and the teachers' projections: independent
-        # fp32 GEMMs of a few microseconds each - one grouped launch (each computed exactly as by its own tnr_sgemm call)
-        X = t.X
-        group = [t._sgemm_problem(S, D, 1, C * D, S[N:], D, 1, D, t.score, 1, C, None, 0, C, 1, D, batch=B)]
-        for i in range(T_):
-            group.append(t._sgemm_problem(X[i], D, 1, C * D, X[i, N:], D, 1, D, t.t_score[i], 1, C, None, 0, C, 1, D, batch=B))
-        if T_:
-            Wt = t._view("transform_matrix.0.weight", T_ * D * D, (T_, D, D))
-            bt = t._view("transform_matrix.0.bias", T_ * D, (T_, D))
-            group.append(t._sgemm_problem(X, D, 1, X.stride(0), Wt, D, 1, D * D, t.Pm, D, t.Pm.stride(0), bt, D, Rt, D, D, batch=T_))
-        for i in range(0, len(group), 8):
-            t._sgemm_group(group[i:i + 8])
+        # score[b, c] = <title_vec[b, c], body_vec[b]>
+        t._sgemm(S, D, 1, C * D, S[N:], D, 1, D, t.score, 1, C, None, 0, C, 1, D, batch=B)
         T.call("tnr_kd_score_loss", t.score, t.t_score if T_ else None, t.label, 1.0, 1.0, t.tw if T_ else None, t.dscore,
                t.losses, B, C, T_)
         if T_:
