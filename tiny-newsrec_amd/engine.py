@@ -1076,13 +1076,14 @@ class Engine:
         for i in range(T_):
             rb.add(self.dP[i], Rt, D, D, dbt[i])
 
-    def backward_encoder(self, dvec, N, acc=0, after_bucket=None):
+    def backward_encoder(self, dvec, N, acc=0, after_bucket=None, pend=None):
         """NewsEncoder backward for the N sequences of the last encode(): dvec (N,D) fp32 = d loss / d news vectors.
-        acc=1 adds to the gradients already in flat_g (second pass over the same parameters, stage 1)."""
-        for _ in self.backward_encoder_steps(dvec, N, acc, after_bucket):
+        acc=1 adds to the gradients already in flat_g (second pass over the same parameters, stage 1).
+        pend: fp32 GEMM problems of the caller that depend on nothing computed here; they ride in the first grouped launch."""
+        for _ in self.backward_encoder_steps(dvec, N, acc, after_bucket, pend=pend):
             pass
 
-    def backward_encoder_steps(self, dvec, N, acc=0, after_bucket=None, defer=False, split_ffn=False):
+    def backward_encoder_steps(self, dvec, N, acc=0, after_bucket=None, defer=False, split_ffn=False, pend=None):
         """backward_encoder as a generator.  defer=True (stage 1): the weight gradients are not launched but collected in
         self._wg_defer, and the generator yields wherever they have to be on their way - after the pooling head, after every
         trainable layer (and, split_ffn, after its FFN block: the point a gradient bucket completes) - so that a caller running
@@ -1100,7 +1101,7 @@ class Engine:
         rb = rb_heads = self.red.setdefault(("heads", acc, N, one), _ReduceBatch(self.dev))
         # dense + pooling of the news encoder
         wd = g(PFX + "dense.weight")
-        self._sgemm_group([
+        self._sgemm_group(list(pend or []) + [
             self._sgemm_problem(dvec, 1, D, 0, self.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, N, ksplit=self.KS,
                                 beta=float(acc)),
             self._sgemm_problem(dvec, D, 1, 0, wd, 1, H, 0, self.dnv, H, 0, None, 0, N, H, D, alpha=self.gscale)])   # loss scale enters here

@@ -190,11 +190,12 @@ class Stage1Engine:
         S, dS = t.S[:Rt], t.dS
         # the title pass's heads batch (backward_encoder's key): merged into one reduction at its end unless it flushes by bucket
         one_t = t.merge_reductions and not (self.chain_wgrad and after_bucket is not None)
+        pend = []                 # the transform matrices' gradient GEMM rides in the title pass's first grouped launch
         if self.cfg_t.T:
-            t._transform_grads(Rt, t.red.setdefault(("heads", 0, N, one_t), _ReduceBatch(t.dev)))
+            t._transform_grads(Rt, t.red.setdefault(("heads", 0, N, one_t), _ReduceBatch(t.dev)), pend)
         T.call("tnr_score_bwd", S, t.cidx, S[N:], t.dscore, dS, dS[N:], B, C, D)
         if not self.chain_wgrad:
-            t.backward_encoder(dS[:N], N, acc=0)
+            t.backward_encoder(dS[:N], N, acc=0, pend=pend)
             b.backward_encoder(dS[N:Rt], B, acc=1, after_bucket=after_bucket)
             return
         # The two passes' backwards in step, layer by layer: every shared weight gets ONE chained weight-gradient problem (title
@@ -202,7 +203,8 @@ class Stage1Engine:
         # adds.  The title's segment runs first, so wherever both flush partial sums the writing flush precedes the adding one;
         # under a bucket hook the title pass flushes bucket by bucket as well (a hook of its own that does nothing).
         hooked = after_bucket is not None
-        gt = t.backward_encoder_steps(dS[:N], N, acc=0, after_bucket=(lambda i: None) if hooked else None, defer=True, split_ffn=hooked)
+        gt = t.backward_encoder_steps(dS[:N], N, acc=0, after_bucket=(lambda i: None) if hooked else None, defer=True, split_ffn=hooked,
+                                      pend=pend)
         gb = b.backward_encoder_steps(dS[N:Rt], B, acc=1, after_bucket=after_bucket, defer=True, split_ffn=hooked)
         if not (self.two_streams and not hooked and self.dev.type == "cuda"):
             while True:
