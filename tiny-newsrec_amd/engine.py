@@ -1255,7 +1255,12 @@ class Engine:
         rest0 = min(_rup(e, 64), self.n_train)   # user encoders / transform matrices start here
         lb = lr if lr_bert is None else lr_bert
         lh = lr if lr_news_head is None else lr_news_head
-        ranges = [(0, self.n_train, lr)] if (lb == lr and lh == lr) else [(0, head0, lb), (head0, rest0, lh), (rest0, self.n_train, lr)]
+        ranges = []
+        for lo_, hi_, rate in ((0, head0, lb), (head0, rest0, lh), (rest0, self.n_train, lr)):     # neighbours with one rate: one launch
+            if ranges and ranges[-1][2] == rate and ranges[-1][1] == lo_:
+                ranges[-1] = (ranges[-1][0], hi_, rate)
+            elif hi_ > lo_:
+                ranges.append((lo_, hi_, rate))
         def launch(lo_, hi_, rate):
             if hi_ > lo_:
                 args = (self.flat[True][lo_:hi_], self.flat_g[lo_:hi_], self.adam_m[lo_:hi_], self.adam_v[lo_:hi_],
