@@ -265,6 +265,9 @@ struct SgemmArgs {
 // a step costs about one memory latency OR its MFMA time (32 x 64 cycles), whichever is longer -- with 16-deep steps every
 // step paid a full latency for 8 MFMAs (44 us for the 1760 x 256 x 768 dense layer, 13 us for an M = 1 call).
 constexpr int SG_BK = 64;
+#ifndef TNR_SG_SKIP
+#define TNR_SG_SKIP 0                          // probe builds (tools/scratch/sgemm_probe.py): 1 no MFMAs, 2 no global loads after the first step, 4 no LDS stores / barriers
+#endif
 __device__ __forceinline__ void sgemm_tile(const SgemmArgs& g, int bx, int by, int bz, float (&As)[64][SG_BK + 1], float (&Bs)[64][SG_BK + 1]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     const int zb = bz / g.ksplit, zk = bz - zb * g.ksplit;
@@ -303,11 +306,12 @@ __device__ __forceinline__ void sgemm_tile(const SgemmArgs& g, int bx, int by, i
             Bs[rb][kb] = bv[q];
         }
         __syncthreads();
-        if (k0 + SG_BK < kend) fetch(k0 + SG_BK);    // next step's global loads fly under the MFMAs
+        if (k0 + SG_BK < kend && !(TNR_SG_SKIP & 2)) fetch(k0 + SG_BK);    // next step's global loads fly under the MFMAs
         const int kk_end = kend - k0 < SG_BK ? kend - k0 : SG_BK;
         for (int kk = 0; kk < kk_end; kk += 2) {      // fixed order: an fp32 fma chain over k (zero padding beyond kend)
             float a = As[wm * 32 + (lane & 31)][kk + (lane >> 5)];
             float b = Bs[wn * 32 + (lane & 31)][kk + (lane >> 5)];
+            if (TNR_SG_SKIP & 1) { acc[0] += a * b; continue; }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
