@@ -578,7 +578,8 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
 #define TNR_UF_SKIP 0                          // probe builds: 1 no fc1 MFMA loop, 2 no tanh / e store, 4 no gather of the history rows
 #endif
 constexpr int UF_XTRA = 4;                     // LDS row pitch D + 4 floats: 16-byte aligned rows, banks shifted by 4 per row
-constexpr int UF_THREADS = 512;                // two waves per SIMD: one wave's W1 loads fly under the other's MFMAs
+constexpr int UF_THREADS = 1024;               // four waves per SIMD: the 14 (slot block, unit block) pairs of U = 50, Q = 200 in ONE round of
+                                               // 16 waves (512 threads: two rounds of 8; 42 -> 37 us), a wave's W1 loads under the others' MFMAs
 __global__ __launch_bounds__(UF_THREADS) void user_fwd_fused_kernel(
     const float* __restrict__ vec, int64_t R, const int32_t* __restrict__ hidx, const int32_t* __restrict__ cidx,
     const float* __restrict__ mask, const float* __restrict__ pad, const float* __restrict__ w1,
