@@ -323,6 +323,151 @@ def golden_trajectory(R, steps=50, n_batches=5, seed=61):
     print("trajectory_0", losses[0], losses[-1])
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# quality golden (round 6): a corpus a recommender can LEARN, the reference trained on it by its own loop and evaluated by its
+# own test(): what "AUC / nDCG within 0.1 pt of the reference" (BASELINE.json north_star) is checked against on the GPU box.
+
+from quality_corpus import dequantize_delta, quality_corpus, quantize_delta  # noqa: E402
+
+
+def _quality_model(R, seed, nl, T, B, trainable):
+    cfg_json = dict(ref_shim.BASE_CFG, num_hidden_layers=nl)
+    a = ref_shim.make_args(config_name=ref_shim.write_config(cfg_json), num_teachers=T, batch_size=B, num_student_layers=nl,
+                           user_log_mask=True, temperature=1.0, coef=0.2)
+    model = R.model_bert.Model(a)
+    P0 = fill(model, seed)
+    for p in model.teachers.parameters():                                         # run.py:101-112
+        p.requires_grad = False
+    for p in model.student.news_encoder.bert_model.parameters():
+        p.requires_grad = False
+    for i, layer in enumerate(model.student.news_encoder.bert_model.bert.encoder.layer):
+        if i in trainable:
+            for p in layer.parameters():
+                p.requires_grad = True
+    return model, a, P0, cfg_json
+
+
+def _quality_eval(R, model, a, c, B):
+    """run.py:219-379 on `model`: -> dict(news_scoring, user_vecs, scores, score_offsets, per_impression, metrics)."""
+    import importlib
+    comb = c["news_combined"]
+    was_training = model.training
+    model.eval()
+    torch.set_grad_enabled(False)
+    try:
+        scoring = np.concatenate([model.student.news_encoder(torch.from_numpy(comb[i:i + 4 * B])).numpy()
+                                  for i in range(0, comb.shape[0], 4 * B)], 0)                       # run.py:276-287
+        dt = R.dataloader.DataLoaderTest(data_dir=".", filename_pat="x", args=a, world_size=1, worker_rank=0, cuda_device_idx=0,
+                                         news_index=c["news_index"], news_scoring=scoring, word_dict=None, enable_prefetch=False,
+                                         enable_shuffle=False, enable_gpu=False)
+        sys.path.insert(0, R.path)
+        try:
+            sys.modules.pop("metrics", None)
+            RM = importlib.import_module("metrics")                                                  # the reference's own metrics.py
+        finally:
+            sys.path.remove(R.path)
+            sys.modules.pop("metrics", None)
+        tl = [l.encode() for l in c["test_lines"]]
+        per, scores, users = [], [], []
+        for i in range(0, len(tl), B):
+            log_vecs, log_mask, news_vecs, labs = dt._process(tl[i:i + B])
+            uv = model.student.user_encoder(log_vecs, log_mask).numpy()                                # run.py:343
+            for u, nv, lab in zip(uv, news_vecs, labs):
+                sc = np.dot(nv, u)
+                scores.append(sc.astype(np.float32))
+                users.append(u)
+                if lab.mean() == 0 or lab.mean() == 1:                                                 # run.py:346
+                    per.append([np.nan] * 4)
+                    continue
+                per.append([RM.roc_auc_score(lab, sc), RM.mrr_score(lab, sc), RM.ndcg_score(lab, sc, k=5), RM.ndcg_score(lab, sc, k=10)])
+    finally:
+        torch.set_grad_enabled(True)
+        model.train(was_training)
+    per = np.array(per)
+    return dict(news_scoring=scoring.astype(np.float32), user_vecs=np.array(users, np.float32),
+                score_offsets=np.concatenate([[0], np.cumsum([len(x) for x in scores])]), scores=np.concatenate(scores),
+                per_impression=per, metrics=np.nanmean(per, 0))          # AUC, MRR, nDCG@5, nDCG@10 over the impressions run.py scores
+
+
+def golden_quality(R, steps=400, B=8, lr=1e-4, seed=71, nl=2, T=2, trainable=(0, 1), out_name="quality_0.npz", save=True, requantize=0):
+    """The reference TRAINED by its own loop (Tiny-NewsRec/run.py:173-200: forward, zero_grad, backward, Adam(amsgrad).step;
+    freeze policy :101-112) on the learnable corpus of quality_corpus.py, batches decoded by the reference's own
+    DataLoaderTrain._process (dataloader.py:118-172; label draws from random.seed(seed)), then EVALUATED the way run.py:219-379
+    does it: every news through student.news_encoder (:276-287), the reference's DataLoaderTest._process per batch
+    (dataloader.py:282-310), user vectors through student.user_encoder (:343), np.dot scores and the reference's own metrics.py on
+    every impression with both labels present (:346-361).  Committed: the corpus (token table, teacher tables, behaviors
+    lines), the label draws, every step's four losses, the per-impression scores and metrics at the end, and the trained
+    parameters as int8 DELTAS from the hash init (quantize_delta) - the evaluation runs on exactly W0 + dequantised delta,
+    reloaded into the reference model before it is evaluated, so the engine is held to the reference's numbers on bit-identical
+    weights; the metrics of the unquantised trained model are kept beside them (`metrics_unquantised`).
+    requantize=1: take the trained parameters from an existing fixture's fp16 deltas instead of training again."""
+    import time
+    c = quality_corpus(seed, T=T, n_train=steps * B)
+    model, a, P0, cfg_json = _quality_model(R, seed, nl, T, B, trainable)
+    comb = c["news_combined"]
+    out_path = os.path.join(HERE, out_name)
+    if requantize:
+        old = np.load(out_path)
+        losses, accs, labels = old["losses"], old["accs"], old["labels"]
+        assert int(old["steps"][0]) == steps and float(old["lr"][0]) == lr
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    p.copy_(torch.from_numpy(P0[n] + old["delta." + n].astype(np.float32)))
+    else:
+        dl = R.dataloader.DataLoaderTrain(data_dir=".", filename_pat="x", args=a, world_size=1, worker_rank=0, cuda_device_idx=0,
+                                          news_index=c["news_index"], news_combined=comb, teacher_embs=c["tables"], word_dict=None,
+                                          enable_prefetch=False, enable_shuffle=False, enable_gpu=False)
+        opt = torch.optim.Adam(model.parameters(), lr=lr, amsgrad=True)              # run.py:134
+        random.seed(seed)
+        lines = [l.encode() for l in c["train_lines"]]
+        assert len(lines) >= steps * B
+        losses, accs, labels = np.zeros((steps, 4)), np.zeros(steps), np.zeros((steps, B), np.int64)
+        t0 = time.time()
+        for step in range(steps):
+            log_ids, log_mask, input_ids, targets, th, tc = dl._process(lines[step * B:(step + 1) * B])
+            total, distill, emb, target, y = model(log_ids, log_mask, input_ids, targets, th, tc)
+            losses[step] = total.item(), distill.item(), emb.item(), target.item()
+            accs[step] = R.utils.acc(targets, y).item()
+            labels[step] = targets.numpy()
+            opt.zero_grad()
+            total.backward()
+            opt.step()
+            if step % 10 == 0:
+                print("quality step %d  %.1f s  losses %s  acc(last 10) %.3f" % (step, time.time() - t0, np.round(losses[step], 4), accs[max(0, step - 9):step + 1].mean()), flush=True)
+    ev_full = _quality_eval(R, model, a, c, B)
+    rec = dict(meta=np.array([seed, B, T, a.user_log_length, a.npratio + 1, a.num_words_title, a.news_dim, cfg_json["num_attention_heads"], nl]),
+               trainable=np.array(sorted(trainable)), flags=np.array([1.0, 1.0, 0.2]), lr=np.array([lr]), steps=np.array([steps]),
+               news_combined=comb.astype(np.int16), train_lines=np.array(c["train_lines"][:steps * B]), test_lines=np.array(c["test_lines"]),
+               labels=labels, losses=losses, accs=accs, metrics_unquantised=ev_full["metrics"])
+    for i, t in enumerate(c["tables"]):
+        rec["table%d" % i] = t
+    # trained parameters -> int8 deltas -> back into the model: what is evaluated below is what is committed
+    names, num, den = [], 0.0, 0.0
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            d = p.detach().numpy() - P0[n]
+            q, scale = quantize_delta(d)
+            dq = dequantize_delta(q, scale)
+            num, den = num + float(((dq - d).astype(np.float64) ** 2).sum()), den + float((d.astype(np.float64) ** 2).sum())
+            names.append(n)
+            rec["dq." + n], rec["ds." + n] = q, scale
+            p.copy_(torch.from_numpy(P0[n] + dq))
+    rec["param_names"] = np.array(names)
+    rec["delta_quantisation_rel_l2"] = np.array([np.sqrt(num / den)])
+    rec.update(_quality_eval(R, model, a, c, B))
+    per = rec["per_impression"]
+    print("quality: %d steps  loss %.4f -> %.4f  train acc first / last 20: %.3f / %.3f  |  eval on %d impressions: AUC %.4f MRR %.4f nDCG@5 "
+          "%.4f nDCG@10 %.4f  (unquantised weights: %s; int8 deltas are off by %.2f %% of the update's L2)" % (
+              steps, losses[:20, 0].mean(), losses[-20:, 0].mean(), accs[:20].mean(), accs[-20:].mean(), int(np.isfinite(per[:, 0]).sum()),
+              *rec["metrics"], np.round(ev_full["metrics"], 4), 100 * rec["delta_quantisation_rel_l2"][0]))
+    if save:
+        np.savez_compressed(out_path, **rec)
+    return rec
+
+
 def golden_pretrained_like(R):
     """The headline model (4 layers, train 2-3, 4 teachers) on weights with a pretrained checkpoint's statistics
     (hashinit.pretrained_like: LayerNorm gamma outliers x 12 ... 30, large embedding rows, |h| ~ 100): what the fp16 build's 16-bit
@@ -737,6 +882,8 @@ if __name__ == "__main__":
         golden_plmnr_hf("roberta", 52)
     elif len(sys.argv) > 1 and sys.argv[1] == "trajectory":
         golden_trajectory(ref_shim.load_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == "quality":
+        golden_quality(ref_shim.load_reference(), **{k: type(dict(steps=1, B=1, lr=1.0, requantize=0)[k])(v) for k, v in (x.split("=") for x in sys.argv[2:])})
     elif len(sys.argv) > 1 and sys.argv[1] == "dropout":
         golden_stage1_dropout(ref_shim.load_reference())
     else:

@@ -85,3 +85,21 @@ def test_gemm_row_tiling_covers_every_row_exactly_once():
     # the headline step's shapes fill whole rounds of 256 workgroups
     assert _plan(52800, 768) == (7, 256, 114)
     assert _plan(52800, 2304)[0:2] == (8, 227)
+
+
+def test_tile_queue_register_guard():
+    """tools/check_pending_spill.py: the persistent GEMMs keep a queue answer in flight in a register the compiler does not know is
+    pending (csrc/gemm.hip: pp_q_fetch / pp_q_wait).  The guard follows every fetch through the kernel's control-flow graph and
+    fails on ANY instruction that touches the register before an executed s_waitcnt vmcnt(0): its self-test (scratch spill, AGPR
+    spill, v_mov copy, v_readfirstlane, a register range, a clobber - each on a path that branches AROUND a wait) and the shipped
+    objects of both builds."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_pending_spill.py")
+    r = subprocess.run([sys.executable, tool, "--selftest"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    objs = [os.path.join(os.path.dirname(T.LIB_PATH), f) for f in ("gemm.o", "gemm_f16.o")]
+    if all(os.path.exists(o) for o in objs):                      # objects are build products: present wherever build() has run
+        r = subprocess.run([sys.executable, tool] + objs, capture_output=True, text=True)
+        assert r.returncode == 0 and "in-flight fetches followed" in r.stdout, r.stdout + r.stderr
+        assert int(re.search(r"(\d+) in-flight fetches", r.stdout).group(1)) >= 90

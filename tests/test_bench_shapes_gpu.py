@@ -287,6 +287,11 @@ def test_b32_forward_matches_oracle(dtype):
     err = np.abs(score.cpu().numpy() - rs_) / np.maximum(1.0, np.abs(rs_))
     rms = float(np.sqrt((err.astype(np.float64) ** 2).mean()))
     print("B=32 forward %s: score err / max(1,|ref|): max %.2e rms %.2e, |logit| max %.2f" % (dtype, err.max(), rms, np.abs(rs_).max()))
+    import json
+    print("PARITY_JSON " + json.dumps({"key": "b32", "dtype": dtype, "test": "tests/test_bench_shapes_gpu.py::test_b32_forward_matches_oracle",
+                                       "what": "the benchmark's own forward at B = 32 against the fp32 oracle: logits / max(1, |ref|)",
+                                       "logit_bound_max": tol_max, "logit_bound_rms": tol_rms, "logit_err_measured_max": float(err.max()),
+                                       "logit_err_measured_rms": rms, "loss_bound_rel_to_max1_ref": tol_loss}))
     assert err.max() <= tol_max and rms <= tol_rms
 
 

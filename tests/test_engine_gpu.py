@@ -632,6 +632,12 @@ def test_fifty_training_steps_follow_the_reference_trajectory(dtype):
           "scale max %.2e ; total loss |err| over the last 25 steps max %.2e ; update rel L2 %.3e, worst parameter %.3e %s" % (
               dtype, loss_rel, err.max(), int(err.max(1).argmax()), lscale[int(err.max(1).argmax())], score_rel, late, rel, worst[0], worst[1][-50:]))
     LOSS_REL, SCORE_REL, LATE, UPD = {"fp16": (1.2e-3, 2.8e-3, 5e-4, 0.19), "bf16": (8.5e-3, 3.0e-2, 3.5e-3, 0.6)}[dtype]
+    import json
+    print("PARITY_JSON " + json.dumps({"key": "trajectory", "dtype": dtype, "test": "tests/test_engine_gpu.py::test_fifty_training_steps_follow_the_reference_trajectory",
+                                       "what": "50 steps of the reference's own loop (trajectory_0.npz), B = 2: per-step errors relative to that step's logit scale",
+                                       "loss_bound_rel_logit_scale": LOSS_REL, "loss_err_measured": loss_rel, "score_bound_rel_logit_scale": SCORE_REL,
+                                       "score_err_measured": score_rel, "late_total_loss_bound_abs": LATE, "late_total_loss_err_measured": late,
+                                       "update_rel_l2_bound": UPD, "update_rel_l2_measured": rel}))
     assert loss_rel <= LOSS_REL and score_rel <= SCORE_REL and late <= LATE
     assert got_losses[-1, 0] < 0.6 * got_losses[0, 0]
     # Adam's first steps move every element by ~lr whatever its gradient's size, so elements whose gradient sits at the rounding

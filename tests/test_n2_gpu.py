@@ -17,24 +17,32 @@ from oracle import newsrec_oracle as O   # noqa: E402
 DEV = "cuda:0"
 
 
-def _setup(ulm=True):
+# news / user vectors against the fp32 oracle: the bound of tests/test_engine_gpu.py for the same vectors (north_star's 1e-3 for
+# the default fp16 build; bf16's 8-bit mantissa gets the 1.6e-2 every bf16 parametrisation gets)
+VEC_TOL = {"fp16": 1e-3, "bf16": 1.6e-2}
+
+
+def _setup(ulm=True, dtype="fp16"):
     z = np.load(os.path.join(GOLDEN, "datapath.npz"))
     comb = z["news_combined"].astype(np.int32)                    # 41 real tokenised titles incl. pad row 0
     P = hashinit.init_state_dict(7, state_shapes(FULL, 2, 256, 0))
     cfg = E.EngineConfig(n_layers=2, trainable_layers=(), num_teachers=0, user_log_mask=ulm)
-    eng = E.Engine(cfg, DEV, max_batch=4)
+    eng = E.Engine(cfg, DEV, max_batch=4, dtype=dtype)
     eng.load_state_dict(P)
     return z, comb, P, eng
 
 
-def test_news_scoring_and_eval_user_vectors():
-    z, comb, P, eng = _setup()
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_news_scoring_and_eval_user_vectors(dtype):
+    z, comb, P, eng = _setup(dtype=dtype)
     ns = eng.encode_news(torch.from_numpy(comb).to(DEV))
     torch.cuda.synchronize()
     want, _ = O.news_encoder_fwd(P, comb.astype(np.int64), 2, 12)
     got = ns.cpu().numpy()
     assert got.shape == want.shape == (41, 256)
-    np.testing.assert_allclose(got, want, rtol=0, atol=1.6e-2)
+    err = float((np.abs(got - want) / np.maximum(1.0, np.abs(want))).max())
+    print("\n[n2 %s] news_scoring max |err| / max(1, |ref|) %.2e (|ref| max %.2f)" % (dtype, err, np.abs(want).max()))
+    assert err <= VEC_TOL[dtype], err
     rs = np.random.RandomState(0)
     hidx = rs.randint(0, 41, (3, 50)).astype(np.int32)
     mask = (rs.rand(3, 50) > 0.5).astype(np.float32)
@@ -73,25 +81,35 @@ def test_run_test_mode_end_to_end(tmp_path, monkeypatch):
                                  bert_trainable_layer=[], config_name=None, pooling="att", model="NAML", news_dim=256,
                                  news_query_vector_dim=200, user_query_vector_dim=200, num_words_title=30,
                                  user_log_mask=True, temperature=1.0, coef=1.0, num_teacher_layers=12, log_steps=1, dtype="fp16")
-    sums, n_local, n_metric = run.test(args)
-    assert n_local == 9
+    per = []
+    sums, n_local, n_metric = run.test(args, collect=per)
+    assert n_local == 9 and len(per) == 9
     # oracle side: same pipeline in numpy
     vec, _ = O.news_encoder_fwd(P, comb.astype(np.int64), 2, 12)
     from oracle import data_oracle as DO
-    want, cnt = np.zeros(4), 0
-    for ln in lines:
+    # (a) every impression's scores against the oracle's: 1e-3 max(1, |ref|) ...
+    want, cnt, serr = np.zeros(4), 0, 0.0
+    for ln, (got_sc, got_y) in zip(lines, per):
         f = ln.split("\t")
         h, m = DO.pad_to_fix_len(DO.trans_to_nindex(news_index, f[3].split()), 50)
         c = DO.trans_to_nindex(news_index, [i.split("-")[0] for i in f[4].split()])
         y = np.array([int(i.split("-")[1]) for i in f[4].split()])
-        if y.mean() in (0, 1):
-            continue
         u, _ = O.user_encoder_fwd(P, "student.user_encoder.", vec[np.array(h)][None], np.array(m, np.float32)[None], True)
         sc = vec[np.array(c)] @ u[0]
-        want += [metrics.roc_auc_score(y, sc), metrics.mrr_score(y, sc), metrics.ndcg_score(y, sc, 5), metrics.ndcg_score(y, sc, 10)]
+        assert (got_y == y).all()
+        serr = max(serr, float((np.abs(got_sc - sc) / np.maximum(1.0, np.abs(sc))).max()))
+        if y.mean() in (0, 1):
+            continue
+        # (b) ... and the metric pipeline itself (skip rule, metric functions, sums) on the engine's OWN scores, exactly: with 8
+        # impressions on hash-initialised weights a near-tie flips a rank and moves a mean by whole points, which says nothing
+        # about either side - the accuracy check against the reference's metrics (0.1 pt on 590 impressions of a corpus the
+        # reference was trained on) is tests/test_quality_gpu.py
+        want += [metrics.roc_auc_score(y, got_sc), metrics.mrr_score(y, got_sc), metrics.ndcg_score(y, got_sc, 5), metrics.ndcg_score(y, got_sc, 10)]
         cnt += 1
-    assert cnt == n_metric
-    np.testing.assert_allclose(sums / n_metric, want / cnt, rtol=0, atol=0.03)     # rank flips on near-ties only
+    assert cnt == n_metric and cnt >= 5
+    print("\n[n2 run.test] per-impression scores max |err| / max(1, |ref|) %.2e" % serr)
+    assert serr <= 1e-3, serr
+    np.testing.assert_allclose(sums, want, rtol=0, atol=1e-12)
 
 
 @pytest.mark.parametrize("ulm", [True, False])
@@ -108,7 +126,8 @@ def test_eval_paths_of_the_variants(ulm, pooling):
     ns = eng.encode_news(torch.from_numpy(comb).to(DEV))
     want, _ = O.news_encoder_fwd(P, comb.astype(np.int64), 2, 12, None, pooling)
     got = ns.cpu().numpy()
-    np.testing.assert_allclose(got, want, rtol=0, atol=1.6e-2 * max(1.0, np.abs(want).max()))
+    err = float((np.abs(got - want) / np.maximum(1.0, np.abs(want))).max())
+    assert err <= VEC_TOL["fp16"], err
     rs = np.random.RandomState(1)
     hidx = rs.randint(0, 41, (3, 50)).astype(np.int32)
     mask = (rs.rand(3, 50) > 0.5).astype(np.float32)

@@ -385,3 +385,74 @@ def test_torch_port_plmnr_two_rate_steps():
     for k in [f[5:] for f in z.files if f.startswith("widx.")]:
         got = tr.P["student." + k].detach().numpy().reshape(-1)[z["widx." + k]]
         np.testing.assert_allclose(got, z["wval." + k], rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_quality_golden_pins_the_oracle_eval_path_and_the_metrics():
+    """tests/golden/quality_0.npz (reference trained 400 steps + evaluated by its own test(), make_golden.golden_quality): on the
+    TRAINED weights the oracle's news encoder reproduces the reference's news_scoring (a 96-news sample: pad row, every topic), its
+    eval user encoder the reference's user vectors, the product's metrics.py the reference's metrics.py (sklearn AUC included) on
+    the reference's own scores - exactly - and the index-level decode the reference loader's label draws."""
+    import random
+    import sys
+    import hashinit
+    import metrics as PM
+    from helpers import FULL, state_shapes
+    sys.path.insert(0, GOLDEN)
+    from quality_corpus import dequantize_delta, quality_corpus
+    z = np.load(os.path.join(GOLDEN, "quality_0.npz"))
+    seed, B, T_, U, C, L, D, A, nl = [int(x) for x in z["meta"]]
+    assert z["metrics"][0] > 0.75 and abs(z["metrics"] - z["metrics_unquantised"]).max() < 1e-3 and z["delta_quantisation_rel_l2"][0] < 0.01
+    P = hashinit.init_state_dict(seed, state_shapes(FULL, nl, D, T_))
+    for n in [str(x) for x in z["param_names"]]:
+        P[n] = P[n] + dequantize_delta(z["dq." + n], z["ds." + n])
+    comb = z["news_combined"].astype(np.int64)
+    # the committed corpus is the generator's (the fixture travels, the generator documents it)
+    c = quality_corpus(seed, T=T_, n_train=int(z["steps"][0]) * B)
+    assert (c["news_combined"] == comb).all() and list(z["test_lines"]) == c["test_lines"] and list(z["train_lines"]) == c["train_lines"]
+    for i in range(T_):
+        assert (c["tables"][i] == z["table%d" % i]).all()
+    rows = np.r_[0:8, 1 + 50 * np.arange(12), 300:376]
+    got, _ = O.news_encoder_fwd(P, comb[rows], nl, A)
+    np.testing.assert_allclose(got, z["news_scoring"][rows], rtol=2e-4, atol=2e-5)
+    news_index = {"N%d" % i: i for i in range(1, comb.shape[0])}
+    off, per = z["score_offsets"], z["per_impression"]
+    sums, cnt = np.zeros(4), 0
+    for i, ln in enumerate(z["test_lines"]):
+        f = str(ln).split("\t")
+        y = np.array([int(x.split("-")[1]) for x in f[4].split()])
+        sc = z["scores"][off[i]:off[i + 1]]
+        if i < 40:                                   # eval user encoder + scorer on the reference's news vectors
+            h, m = DO.pad_to_fix_len(DO.trans_to_nindex(news_index, f[3].split()), U)
+            cidx = DO.trans_to_nindex(news_index, [x.split("-")[0] for x in f[4].split()])
+            u, _ = O.user_encoder_fwd(P, "student.user_encoder.", z["news_scoring"][np.array(h)][None], np.array(m, np.float32)[None], True)
+            np.testing.assert_allclose(u[0], z["user_vecs"][i], rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(z["news_scoring"][np.array(cidx)] @ u[0], sc, rtol=2e-4, atol=2e-5)
+        if y.mean() in (0, 1):
+            assert np.isnan(per[i]).all()
+            continue
+        mine = [PM.roc_auc_score(y, sc), PM.mrr_score(y, sc), PM.ndcg_score(y, sc, 5), PM.ndcg_score(y, sc, 10)]
+        np.testing.assert_allclose(mine, per[i], rtol=0, atol=1e-12)
+        sums += mine
+        cnt += 1
+    np.testing.assert_allclose(sums / cnt, z["metrics"], rtol=0, atol=1e-12)
+    assert cnt == 591
+    # the label draws of the reference's loader (random.seed(seed), one randint per line): the oracle's and the product's decode
+    from decode_worker import decode_lines
+    lines = [str(l).encode() for l in z["train_lines"]]
+    random.seed(seed)
+    for step in range(int(z["steps"][0])):
+        h, m, cd, y = DO.decode_batch(lines[step * B:(step + 1) * B], news_index, U, C - 1)
+        assert (y == z["labels"][step]).all(), step
+    random.seed(seed)
+    h2, m2, c2, y2 = decode_lines(lines[:B], news_index, U, C - 1)
+    h1, m1, c1, y1 = DO.decode_batch(lines[:B], news_index, U, C - 1, labels=z["labels"][0])
+    assert (h1 == h2).all() and (m1 == m2).all() and (c1 == c2).all() and (y2 == z["labels"][0]).all()
+    # and the training side at step 0: the oracle's four losses on the first batch against the reference's first logged step
+    P0 = hashinit.init_state_dict(seed, state_shapes(FULL, nl, D, T_))
+    tabs = [z["table%d" % i] for i in range(T_)]
+    cfg = dict(n_layers=nl, heads=A, trainable_layers=[int(x) for x in z["trainable"]], user_log_mask=True, temperature=1.0, coef=0.2,
+               pooling="att", nrms_heads=0)
+    out = O.model_fwd(P0, cfg, comb[h1], m1, comb[c1], y1, [t[h1] for t in tabs], [t[c1] for t in tabs], keep=False)
+    want = z["losses"][0]                              # total, distill, emb, target
+    got = [out["total_loss"], out["distill_loss"], out["emb_loss"], out["target_loss"]]
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)

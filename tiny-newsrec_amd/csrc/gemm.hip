@@ -2370,6 +2370,11 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
     return TNR_OK;
 }
 
+// (tiles_per_split + 2) m steps of 64 rows x the larger leading dimension x 2 bytes must fit a 31-bit offset (gemm_tn_rs_kernel)
+static bool tn_rs_unit_fits(int tps, int64_t lddy, int64_t ldx) {
+    return ((int64_t)tps + 2) * 64 * std::max(lddy, ldx) * 2 < ((int64_t)1 << 31);
+}
+
 extern "C" int64_t TNR_NAME(tnr_gemm_tn_ws_elems)(int64_t N, int64_t K, int splits) { return N * K * (int64_t)splits; }
 
 extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
@@ -2389,6 +2394,11 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
     splits = (Mt + tps - 1) / tps;
     TNArgs g{(const bf16*)dY, lddy, (const bf16*)X, ldx, ws, Mt, (int)N, (int)K, tps, splits, nullptr};
     const int ver = tnr_gemm_opts()->ver;
+    // gemm_tn_rs_kernel addresses a unit's rows through a raw buffer with 32-bit byte offsets (its pipeline also issues the loads
+    // of two m steps past the unit's end and relies on them falling OUTSIDE the buffer): a unit must stay under 2 GiB per operand
+    TNR_CHECK_ARG(tn_rs_unit_fits(tps, lddy, ldx),
+                  "tnr_gemm_tn_wgrad: %d rows per split x leading dimension %ld exceed the 2 GiB a unit may span - raise `splits`",
+                  tps * 64, (long)std::max(lddy, ldx));
     TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_tn256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
@@ -2465,6 +2475,9 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_group)(const tnr_wgrad_problem_t* p, i
         if (splits > Mt) splits = Mt;
         const int tps = (Mt + splits - 1) / splits;
         splits = (Mt + tps - 1) / tps;
+        TNR_CHECK_ARG(tn_rs_unit_fits(tps, q.lddy, q.ldx),
+                      "tnr_gemm_tn_wgrad_group: problem %d: %d rows per split x leading dimension %ld exceed the 2 GiB a unit may span - raise "
+                      "`splits`", i, tps * 64, (long)std::max(q.lddy, q.ldx));
         const int h = head_of(i);
         float* const ws_i = chained ? (float*)sg.ws[h] + (int64_t)sg.splits[h] * q.N * q.K : q.ws;   // behind the chain's slabs so far
         grp.p[i] = TNArgs{(const bf16*)q.dY, q.lddy, (const bf16*)q.X, q.ldx, ws_i, Mt, (int)q.N, (int)q.K, tps, splits, nullptr};

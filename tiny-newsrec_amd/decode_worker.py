@@ -2,6 +2,7 @@
 runs it for DataLoaderTrain's resident mode.  Imports numpy and the standard library only: the spawned child must not pay for
 (or touch) torch."""
 import random
+import threading
 
 import numpy as np
 
@@ -56,27 +57,33 @@ def decode_process(cfg, rnd_state, q):
         q.put(("error", "%r\n%s" % (e, traceback.format_exc())))
 
 
+_SPAWN_LOCK = threading.Lock()       # start_without_main patches __main__, which is process-global: one spawn at a time
+
+
 def start_without_main(proc):
     """proc.start() of a "spawn" process WITHOUT the child re-importing the parent's __main__ (multiprocessing does that for every
     spawned child: run.py's top-level `import torch` would then cost the decoder a second or two at the start of every epoch and
     put a GPU framework into a process that is there to stay off the GPU).  The child's target lives in this module and needs
-    nothing from __main__."""
+    nothing from __main__.  The patch of __main__ is process-global: every spawn of this package goes through here under one
+    lock, so two loaders (train + eval) starting their decoders at the same moment cannot restore each other's half-patched
+    state, and the window in which __main__.__file__ is missing is the few hundred microseconds of Popen itself."""
     import sys
-    main = sys.modules.get("__main__")
-    saved = {}
-    for k in ("__spec__", "__file__"):
-        if main is not None and hasattr(main, k):
-            saved[k] = getattr(main, k)
-    try:
-        if main is not None:
-            if "__spec__" in saved:
-                main.__spec__ = None
-            if "__file__" in saved:
-                del main.__file__
-        proc.start()
-    finally:
-        for k, v in saved.items():
-            setattr(main, k, v)
+    with _SPAWN_LOCK:
+        main = sys.modules.get("__main__")
+        saved = {}
+        for k in ("__spec__", "__file__"):
+            if main is not None and hasattr(main, k):
+                saved[k] = getattr(main, k)
+        try:
+            if main is not None:
+                if "__spec__" in saved:
+                    main.__spec__ = None
+                if "__file__" in saved:
+                    del main.__file__
+            proc.start()
+        finally:
+            for k, v in saved.items():
+                setattr(main, k, v)
 
 
 def report_modules(q, names):

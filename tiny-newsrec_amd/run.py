@@ -221,8 +221,10 @@ def get_teacher_emb(args):
         torch.cuda.empty_cache()
 
 
-def test(args):
-    """run.py:219-379: encode all test news once, user vectors per impression batch, host metrics, scalar all-reduce."""
+def test(args, collect=None):
+    """run.py:219-379: encode all test news once, user vectors per impression batch, host metrics, scalar all-reduce.
+    collect: optional list that receives, per impression in file order, (scores, labels) - the reference keeps only the sums;
+    the quality tests compare the per-impression rankings with the reference's."""
     import dist
     from dataloader import DataLoaderTest
     from metrics import mrr_score, ndcg_score, roc_auc_score
@@ -245,6 +247,8 @@ def test(args):
         n_local += h.shape[0]
         users = eng.user_vectors(news_scoring, h, m).cpu().numpy()
         for u, c, y in zip(users, cands, labels):
+            if collect is not None:
+                collect.append((scoring_host[c] @ u, y))
             if y.mean() == 0 or y.mean() == 1:
                 continue
             score = scoring_host[c] @ u

@@ -206,7 +206,10 @@ class Stage1Engine:
         gt = t.backward_encoder_steps(dS[:N], N, acc=0, after_bucket=(lambda i: None) if hooked else None, defer=True, split_ffn=hooked,
                                       pend=pend)
         gb = b.backward_encoder_steps(dS[N:Rt], B, acc=1, after_bucket=after_bucket, defer=True, split_ffn=hooked)
-        if not (self.two_streams and not hooked and self.dev.type == "cuda"):
+        # side by side only when BOTH passes hold their partial sums back for one merged reduction at the very end: with
+        # Engine.merge_reductions off (tools/step_ab.py) each pass flushes inside its own segments, and the title's writing flush
+        # (main stream) would be unordered against the body's adding flush (side stream) on the shared bias / LayerNorm gradients
+        if not (self.two_streams and not hooked and self.dev.type == "cuda" and t.merge_reductions and b.merge_reductions):
             while True:
                 at, ab = next(gt, None), next(gb, None)
                 assert at == ab, (at, ab)
