@@ -25,6 +25,7 @@ import torch         # noqa: E402
 
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 N_NEWS = 51282          # MIND-small-train sized news table (+ pad row 0)
+CAL_REF_US = 100.0      # calibration launch on the round-6 build boxes (median of the leases in README.md); set after measuring
 EVENT_EVERY = 4         # roofline leg: every 4th timed step has its NT GEMM launches bracketed by HIP events
 
 
@@ -110,6 +111,56 @@ def cpu_baseline(cfg_kw, seed):
             "configs0_plmnr_2layer_b16": {"value": round(v_c0, 3), "unit": "impressions/s", "cores": int(th_c0), "threads_sweep": sw_c0,
                                          "sample": "BASELINE configs[0]: PLM-NR 2-layer (train 0,1), B=16, fp32; same sweep, best = %d "
                                                    "threads, 2 warm-up + %d timed steps" % (th_c0, n_c0)}}
+
+
+FAMILIES = (("nt_gemm", ("tnr_gemm_nt",)), ("weight_gradient", ("tnr_gemm_tn_wgrad",)), ("attention", ("tnr_attn_",)),
+            ("layernorm_embed", ("tnr_ln_", "tnr_embed_")),
+            ("optimiser", ("tnr_amsgrad", "tnr_adam", "tnr_refresh", "tnr_grad_nonfinite", "tnr_cast_")))
+
+
+def family_of(name):
+    for fam, prefixes in FAMILIES:
+        if name.startswith(prefixes):
+            return fam
+    return "heads_kd_misc"
+
+
+def box_probe(T, dev, dtype, reps=20):
+    """What this BOX does with a fixed piece of work, so that two bench lines can be told apart into box and build: ONE fixed
+    persistent NT launch (M = 52 800, N = K = 768, plain epilogue, random operands) timed over `reps` back-to-back launches behind
+    60 warm ones, and the shader clock the chip holds under it (tnr_gemm_clock_stamps: cycles / 100 MHz ticks per workgroup)."""
+    sfx = "_f16" if dtype == "fp16" else ""
+    td = torch.float16 if dtype == "fp16" else torch.bfloat16
+    M, N, K = 52800, 768, 768
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    a_ = (torch.randn((M, K), device=dev, generator=g) * 0.5).to(td)
+    b_ = (torch.randn((N, K), device=dev, generator=g) * 0.05).to(td)
+    c_ = torch.zeros((M, N), device=dev, dtype=td)
+    stamps = torch.zeros((256, 2), device=dev, dtype=torch.int64)
+
+    def run():
+        T.call("tnr_gemm_nt_ex" + sfx, a_, K, b_, K, c_, N, M, N, K, None, None, 0, None, 0, 0, None)
+    for _ in range(60):
+        run()
+    T.lib().tnr_gemm_clock_stamps(stamps.data_ptr(), 256)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    T.lib().tnr_gemm_clock_stamps(None, 0)
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    st = stamps.cpu().numpy()
+    ok = st[:, 1] > 0
+    mhz = 100.0 * st[ok, 0] / st[ok, 1]
+    return {"calibration_launch": {"M": M, "N": N, "K": K, "epilogue": "plain", "reps": reps, "us": round(us, 2),
+                                   "tflops": round(2.0 * M * N * K / us / 1e6, 1),
+                                   "route": T.query("tnr_gemm_nt_route" + sfx, M, N, K, 0)},
+            "mfma_clock_mhz_under_calibration": round(float(np.median(mhz)), 0) if ok.any() else None,
+            "mfma_clock_mhz_min_max": [round(float(mhz.min()), 0), round(float(mhz.max()), 0)] if ok.any() else None,
+            "workgroups_stamped": int(ok.sum())}
 
 
 def self_launch(a):
@@ -355,6 +406,7 @@ def main():
         return
 
     timed_rec = []
+    clock_stamps = torch.zeros((256, 2), device=dev, dtype=torch.int64)
 
     def timed_loop(eng, gs, use_plan, time_kernels=None):
         """W untimed warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks (seconds)."""
@@ -367,13 +419,17 @@ def main():
         t0 = time.perf_counter()
         for i in range(W, W + K):
             # the NT GEMM launches of every 4th timed step are bracketed by HIP events on their stream (two event records per
-            # launch cost ~1.4 % of the step when every step carries them; sampled, the timed region stays what it measures)
+            # launch cost ~1.4 % of the step when every step carries them; sampled, the timed region stays what it measures);
+            # the same steps' persistent NT launches stamp their shader clock (two scalar loads per workgroup: `box`)
             if rec is not None and (i - W) % EVENT_EVERY == 0:
                 T.TIMED[time_kernels] = rec
+                T.lib().tnr_gemm_clock_stamps(clock_stamps.data_ptr(), 256)
             else:
                 T.TIMED.pop(time_kernels, None)
+                T.lib().tnr_gemm_clock_stamps(None, 0)
             one_step(eng, gs, i, use_plan)
         T.TIMED.pop(time_kernels, None)
+        T.lib().tnr_gemm_clock_stamps(None, 0)
         if rec is not None:
             timed_rec.extend(rec)
         torch.cuda.synchronize()
@@ -418,6 +474,36 @@ def main():
     TKEY = "tnr_gemm_nt_ex_f16" if a.dtype == "fp16" else "tnr_gemm_nt_ex"
     dt = timed_loop(eng, gs, a.dedup == "only", None if a.no_kernel_timing else TKEY)
     rec = timed_rec or None
+    box = breakdown = None
+    if not a.no_kernel_timing:
+        # `box`: the clock the chip held under the LAST stamped NT launch of the timed region + a fixed calibration launch, both
+        # OUTSIDE the timed region's clock; `step_breakdown_ms`: 8 more steps (untimed) with EVERY library call bracketed by events
+        st_ = clock_stamps.cpu().numpy()
+        ok_ = st_[:, 1] > 0
+        box = box_probe(T, dev, a.dtype)
+        box["mfma_clock_mhz_under_load"] = round(float(np.median(100.0 * st_[ok_, 0] / st_[ok_, 1])), 0) if ok_.any() else None
+        box["note"] = ("under_load: median over the workgroups of the last event-sampled step's last persistent NT launch inside the timed "
+                       "region (shader cycles / 100 MHz ticks of a workgroup's life); calibration: right after the timed region")
+        n_bd = min(8, K)
+        T.TIMED_ALL = []
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        for i in range(W, W + n_bd):
+            one_step(eng, gs, i, a.dedup == "only")
+        torch.cuda.synchronize()
+        tb = 1e3 * (time.perf_counter() - tb0) / n_bd
+        rec_all, T.TIMED_ALL = T.TIMED_ALL, None
+        fam_ms, fam_calls = {}, {}
+        for e0_, e1_, nm_ in rec_all:
+            f_ = family_of(nm_)
+            fam_ms[f_] = fam_ms.get(f_, 0.0) + e0_.elapsed_time(e1_) / n_bd
+            fam_calls[f_] = fam_calls.get(f_, 0) + 1
+        breakdown = {k_: round(v_, 4) for k_, v_ in sorted(fam_ms.items(), key=lambda kv: -kv[1])}
+        breakdown["sum_of_calls"] = round(sum(fam_ms.values()), 4)
+        breakdown["step_with_events"] = round(tb, 4)
+        breakdown["calls_per_step"] = {k_: v_ // n_bd for k_, v_ in fam_calls.items()}
+        breakdown["note"] = ("%d extra steps AFTER the timed region, every C-ABI call bracketed by two HIP events on its stream (weight_gradient "
+                             "includes its slab reductions; step_with_events carries the ~170 event records, ms_per_step does not)" % n_bd)
     if rank == 0 and os.environ.get("TNR_BENCH_DUMP_PARAMS"):
         np.save(os.environ["TNR_BENCH_DUMP_PARAMS"], eng.flat[True][::97].float().cpu().numpy())
     dp_info = None
@@ -598,7 +684,17 @@ def main():
                                "algorithmic_flops_per_launch": fl / len(rec)}
         else:
             out["roofline"] = None
-        out["parity"] = PARITY.get("headline")       # what the headline model's parity test allows and measured (tools/parity_measured.py)
+        out["parity"] = PARITY.get("headline")       # what the headline model's parity test allows and measured (tools/parity_measured.py):
+        #                                              B = 2 golden + `b32` (the benchmark's own batch) + `trajectory` (50 reference steps)
+        out["quality"] = PARITY.get("quality")       # tests/test_quality_gpu.py: AUC / MRR / nDCG against the reference-trained golden
+        if box is not None:
+            out["box"] = box
+            cal = box["calibration_launch"]["us"]
+            out["box"]["headline_normalised"] = {
+                "calibration_us_reference": CAL_REF_US, "value_at_reference_calibration": round(value * cal / CAL_REF_US, 2),
+                "note": "value x (this box's calibration us / %.1f us, the round-6 build box's median): a first-order removal of the box's "
+                        "clock from the headline; compare RAW values only between boxes with equal calibration_us" % CAL_REF_US}
+            out["step_breakdown_ms"] = breakdown
         if dp_info is not None:
             out["dp"] = dp_info
         if other is not None:

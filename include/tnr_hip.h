@@ -134,6 +134,12 @@ int tnr_gemm_nt_plan(int64_t M, int64_t N, int flags, int n_cu, int* mi, int* pa
  * after a launch on that stream was aborted (a device fault survived by the process), never in normal operation.
  * (Test hooks such as the CU hog live in libtnr_testhooks.so, built beside this library for tests/ and tools/ only.) */
 int tnr_gemm_queue_reset(void* stream);
+/* Measurement hook (bench.py's `box` object; no reference counterpart - the reference never reports a clock): while `buf` is
+ * non-NULL, workgroup b < n_pairs of every persistent NT launch (TNR_ROUTE_256x256 / 224x256) writes, as it leaves, the shader
+ * cycles (s_memtime) and the 100 MHz ticks (s_memrealtime) of its life to buf[2 b], buf[2 b + 1] (uint64, device memory owned
+ * by the caller, 8-byte aligned): cycles / ticks x 100 = the MHz the chip held UNDER that launch.  Process-wide like the
+ * options; NULL or n_pairs = 0 turns it off (the default; two scalar loads per workgroup when on).  Results unchanged. */
+int tnr_gemm_clock_stamps(void* buf, int64_t n_pairs);
 
 /* dW[N,K] (fp32) = dY[M,N]^T . X[M,K] : weight gradient of a Linear.  Reduction over M is split into
  * `splits` slabs in `ws` (fp32, splits*N*K elements) and summed in fixed order (deterministic).

@@ -18,7 +18,7 @@ void tnr_set_error(const char* fmt, ...) {
 extern "C" const char* tnr_last_error(void) { return g_err; }
 extern "C" int tnr_version(void) { return 1; }
 
-static TnrGemmOpts g_gemm_opts = {3, 8, 60, 1, 0, 0, 1, 2, 1, 0, 0};
+static TnrGemmOpts g_gemm_opts = {3, 8, 60, 1, 0, 0, 1, 2, 1, 0, 0, nullptr, 0};
 TnrGemmOpts* tnr_gemm_opts() { return &g_gemm_opts; }
 
 extern "C" int tnr_gemm_set_option(const char* key, int value) {
@@ -36,5 +36,12 @@ extern "C" int tnr_gemm_set_option(const char* key, int value) {
     else if (!strcmp(key, "probe")) o.probe = value;
     else if (!strcmp(key, "cus")) o.cus = value;
     else { tnr_set_error("tnr_gemm_set_option: unknown key %s", key); return TNR_EINVAL; }
+    return TNR_OK;
+}
+
+extern "C" int tnr_gemm_clock_stamps(void* buf, int64_t n_pairs) {
+    if (n_pairs < 0 || (buf && ((uintptr_t)buf % 8) != 0)) { tnr_set_error("tnr_gemm_clock_stamps: bad buffer"); return TNR_EINVAL; }
+    g_gemm_opts.clock_buf = n_pairs > 0 ? buf : nullptr;
+    g_gemm_opts.clock_n = buf ? (int)(n_pairs > (1 << 20) ? (1 << 20) : n_pairs) : 0;
     return TNR_OK;
 }

@@ -46,6 +46,8 @@ struct TnrGemmOpts {
     int mix;         // ping-pong NT kernel: 1 = row panels of two heights so that the tiles fill whole rounds, 0 = one height
     int probe;       // timing probes of the ping-pong kernel (only in -DTNR_PROBES builds, tools/probe_build.sh)
     int cus;         // 0 = plan and size the persistent GEMM grids for the device's CUs ; n = for n of them (two kernels side by side)
+    void* clock_buf; // tnr_gemm_clock_stamps: device buffer of clock_n (cycles, 100 MHz ticks) pairs the persistent NT kernel fills, or NULL
+    int clock_n;
 };
 TnrGemmOpts* tnr_gemm_opts();
 // The tile-queue counter set of (current device, stream) for the persistent GEMM kernels of BOTH builds (defined once, in the

@@ -37,6 +37,8 @@ struct NTArgs {
     int probe;                 // timing probes (tools only, TNR_PROBES builds): 1 no staging loads in the K loop, 2 no
                                // fragment reads / MFMAs (512: no MFMAs only, 1024: no reads only), 4 every row tile reads A rows
                                // 0-255 (A resident in L2), 8 no epilogue
+    unsigned long long* clock; // ping-pong kernel, measurement hook (tnr_gemm_clock_stamps): workgroup b < clock_n writes the shader
+    int clock_n;               // cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of its life at clock[2 b], clock[2 b + 1]; NULL = off
 };
 
 constexpr int TILE_BYTES = 128 * 128;   // one operand tile: 128 rows x 64 bf16
@@ -1174,9 +1176,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
                     __hip_atomic_store(g.queue + i * PP_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-#ifdef TNR_PROBES
-    const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();   // shader clock probe
-#endif
+    unsigned long long pt0 = 0, pr0 = 0;                 // tnr_gemm_clock_stamps: the clock the chip holds under THIS kernel
+    if (g.clock) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
 
     // staging: every wave issues pieces 2w, 2w+1 of every half tile (wave 7 has no A pieces in the 224-row variant)
     const bf16* srcA[2][2];
@@ -1445,13 +1446,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 #endif
     nt_epilogue_cols<MI, CF>(g, acc, lut, bias_lds + par * 256, bm, bn, rs, tall ? MI : MI - 1, wm, wn, lane);
     par ^= 1;
-#ifdef TNR_PROBES
-    if ((g.probe & 64) && next < 0 && g.colsum_part && tid == 0) {   // shader cycles / 100 MHz ticks of this workgroup's life
-        unsigned long long* o = (unsigned long long*)g.colsum_part + 2 * blockIdx.x;
+    if (g.clock && next < 0 && tid == 0 && (int)blockIdx.x < g.clock_n) {   // shader cycles / 100 MHz ticks of this workgroup's life
+        unsigned long long* o = g.clock + 2 * blockIdx.x;
         o[0] = __builtin_amdgcn_s_memtime() - pt0;
         o[1] = __builtin_amdgcn_s_memrealtime() - pr0;
     }
-#endif
     if (next < 0) break;
     tile = next;
   }
@@ -2326,6 +2325,8 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
 #ifdef TNR_PROBES
     g.probe = o.probe;
 #endif
+    g.clock = (unsigned long long*)o.clock_buf;
+    g.clock_n = o.clock_n;
 #define TNR_PP_ATTR(CF)                                                                                                     \
         (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<8, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS); \
         (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<7, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);

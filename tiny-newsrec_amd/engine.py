@@ -261,8 +261,10 @@ class LossScaler:
 
 
 class Engine:
-    def __init__(self, cfg, device="cuda:0", max_batch=32, dtype="fp16", share=None):
-        """dtype: 16-bit activation / weight-copy type, "fp16" (default: meets the 1e-3 logit / loss bound) or "bf16".
+    def __init__(self, cfg, device="cuda:0", max_batch=32, dtype="fp16", share=None, extra_rows=0, extra_seqs=0):
+        """extra_rows / extra_seqs: room for that many more token rows / sequences behind this engine's own in every per-token /
+        per-sequence workspace (stage 1's joint passes: the body pass's rows directly behind the title pass's, stage1.py).
+        dtype: 16-bit activation / weight-copy type, "fp16" (default: meets the 1e-3 logit / loss bound) or "bf16".
         fp16 has the same MFMA rate and 3 more mantissa bits; its backward runs on activation gradients scaled by LOSS_SCALE from the
         pooling backward down (everything 16-bit); the kernels that write parameter gradients multiply by 1 / LOSS_SCALE (exact)."""
         T.lib()                      # fail loudly if the HIP library is missing
@@ -286,6 +288,7 @@ class Engine:
                       "grads", "lo", "sh", "sh_a1", "sh_a1T", "b_a1", "desc_all", "desc_train"):
                 setattr(self, k, getattr(share, k))
         self.max_batch = max_batch
+        self.extra_rows, self.extra_seqs = int(extra_rows), int(extra_seqs)
         self.drop = None             # set_dropout(): train-mode dropout of the stage-0 / stage-1 notebooks
         self.drop_calls = 0
         self._alloc_workspace(max_batch)
@@ -494,8 +497,9 @@ class Engine:
         cfg, dev, bf = self.cfg, self.dev, self.tdt
         H, I, D, L = cfg.H, cfg.I, cfg.D, cfg.L
         N = B * (cfg.U + cfg.C)
-        Mp = _rup(N * L, 128)
+        Mp = _rup(N * L + self.extra_rows, 128)
         self.B_alloc, self.N_alloc, self.Mp = B, N, Mp
+        Nx = N + self.extra_seqs           # per-sequence partials / pooled vectors with room for a second pass's sequences
         if self.f16:
             # the losses are batch means, so activation gradients shrink as 1 / B: the scale grows with the batch in powers of two
             # beyond the B = 32 it was set for (B = 512 at the fixed scale: parameter gradients 1.8e-3 off the mean of their
@@ -524,7 +528,7 @@ class Engine:
         self.scr = mk() if self.lo > 0 else None           # scratch for frozen layers below lo
         self.scr_y = [z(Mp, H), z(Mp, H)] if self.lo > 0 else None
         self.e = f(Mp, QPAD)
-        self.nv, self.alpha, self.den = f(N, H), f(N, Lr), f(N)
+        self.nv, self.alpha, self.den = f(Nx, H), f(N, Lr), f(N)
         Rt = N + B
         self.Rt = Rt
         if hasattr(self, "dyprem"):
@@ -558,24 +562,24 @@ class Engine:
             self.hpos = torch.arange(BU, device=dev, dtype=torch.int32).view(B, cfg.U)
             self.cpos = (BU + torch.arange(max(BC, 1), device=dev, dtype=torch.int32))[:BC].view(B, cfg.C)
         # backward buffers
-        self.dnv = f(N, H)
+        self.dnv = f(Nx, H)
         self.dy, self.dy2 = z(Mp, H), z(Mp, H)
         self.dpre = z(Mp, QPAD)
-        self.dw2p, self.db2p = f(N, cfg.Qn), f(N)
+        self.dw2p, self.db2p = f(Nx, cfg.Qn), f(Nx)
         self.dypre, self.dh1, self.dh1pre, self.dctx = z(Mp, H), z(Mp, H), z(Mp, H), z(Mp, H)
         self.du = z(Mp, I)
         self.dqkv = z(Mp, 3 * H)
         # partial sums of the bias / LayerNorm gradients: a set per trainable layer, so that ONE batched reduction at the end of the
         # backward can sum them all (they are a few tens of MB per layer)
         self.lpart = {l: dict(ln_part=f(T.query("tnr_ln_bwd_part_elems", Mp, H)), ln_part1=f(T.query("tnr_ln_bwd_part_elems", Mp, H)),
-                              gcs_part=f(T.query("tnr_gemm_colsum_rows", Mp), I), qkvb_part=f(N, 3 * H), cs_tmp=f(I), cs_tmp2=f(3 * H))
+                              gcs_part=f(T.query("tnr_gemm_colsum_rows", Mp), I), qkvb_part=f(Nx, 3 * H), cs_tmp=f(I), cs_tmp2=f(3 * H))
                       for l in cfg.trainable_layers}
         self.red = {}                                                      # gradient bucket -> _ReduceBatch
         self.cs_part = f(max(T.query("tnr_colsum_part_elems", Mp, 3 * H if L > 32 else QPAD),
                              T.query("tnr_colsum_part_elems", 128, I),
                              T.query("tnr_colsum_part_elems", max(B * cfg.U, 1), 3 * D),
                              T_ * T.query("tnr_colsum_part_elems", Rt, D)))
-        self.db1p = f(N, QPAD)
+        self.db1p = f(Nx, QPAD)
         # chunked pooling kernels for few, long sequences (stage-1 bodies): their workspace
         self.ap_ws = f(T.query("tnr_attpool_long_ws_elems", N, L, H, cfg.Qn, QPAD)) if (L > AP_LONG and cfg.pooling == "att") else None
         self.epre_u = f(B * cfg.U, cfg.Qu)
@@ -733,6 +737,63 @@ class Engine:
             self._pos_cache = (key, pid)
         return pid
 
+    # pieces of encode() / backward_encoder_steps() that depend on the sequence length, with their per-token operands explicit
+    # (stage 1's joint passes run them per pass on row ranges of buffers both passes share, stage1.py)
+    def _embed_fwd(self, tok, n_seq, nidx, x0):
+        cfg, g, ds = self.cfg, self.p, self._dsite
+        L, H = cfg.L, cfg.H
+        emb = (g(BERT + "embeddings.word_embeddings.weight"), g(BERT + "embeddings.position_embeddings.weight"),
+               g(BERT + "embeddings.token_type_embeddings.weight"), g(BERT + "embeddings.LayerNorm.weight"),
+               g(BERT + "embeddings.LayerNorm.bias"), cfg.ln_eps, x0, self.mask_add)
+        de = ds(T.DROP_EMB, 0)
+        pid = self._pos_ids(tok if nidx is not None else tok[:n_seq]) if cfg.pos_pad_id is not None else None
+        if nidx is None:
+            self._c("tnr_embed_ln_fwd_do", tok, n_seq, L, H, *emb, de, pid) if (de or pid is not None) else \
+                self._c("tnr_embed_ln_fwd", tok, n_seq, L, H, *emb)
+        else:
+            self._c("tnr_embed_ln_fwd_indexed_do", tok, nidx, n_seq, L, H, *emb, de, pid) if (de or pid is not None) else \
+                self._c("tnr_embed_ln_fwd_indexed", tok, nidx, n_seq, L, H, *emb)
+
+    def _attn_fwd(self, qkv, ctx, lse, n_seq, dp):
+        cfg = self.cfg
+        if cfg.L <= 32:
+            if dp:
+                self._c("tnr_attn_l32_fwd_do", qkv, self.mask_add, self.rel, ctx, n_seq, cfg.L, cfg.A, dp)
+            else:
+                self._c("tnr_attn_l32_fwd", qkv, self.mask_add, self.rel, ctx, n_seq, cfg.L, cfg.A)
+        else:
+            largs = (qkv, self.mask_add, self.rel, ctx, lse, n_seq, cfg.L, cfg.A)
+            self._c("tnr_attn_long_fwd_do", *largs, dp) if dp else self._c("tnr_attn_long_fwd", *largs)
+
+    def _attpool_fwd(self, x, e, nv, n_seq):
+        cfg, g = self.cfg, self.p
+        if cfg.L > AP_LONG:                  # few, long sequences (stage-1 bodies): the chunked kernels fill the chip
+            self._c("tnr_attpool_fwd_long", x, e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
+                    nv, self.alpha, self.den, self.ap_ws, n_seq, cfg.L, cfg.H)
+        else:
+            self._c("tnr_attpool_fwd", x, e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
+                    nv, self.alpha, self.den, n_seq, cfg.L, cfg.H)
+
+    def _attpool_bwd(self, y, e, dnv, dy2, dpre, dw2p, db2p, db1p, n_seq):
+        cfg, g = self.cfg, self.p
+        if cfg.L > AP_LONG:
+            self._c("tnr_attpool_bwd_long", y, e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, dnv, self.alpha,
+                    dy2, dpre, QPAD, dw2p, db2p, db1p, self.ap_ws, n_seq, cfg.L, cfg.H)
+        else:
+            self._c("tnr_attpool_bwd", y, e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, dnv, self.alpha, self.den,
+                    dy2, dpre, QPAD, dw2p, db2p, db1p, n_seq, cfg.L, cfg.H)
+
+    def _attn_bwd(self, qkv, ctx, lse, dctx, dqkv, qkvb_part, n_seq, dPb):
+        """-> True if the q/k/v bias partial sums came out of the kernel (L <= 32), False if the caller sums dqkv's columns."""
+        cfg = self.cfg
+        if cfg.L <= 32:
+            bargs = (qkv, self.mask_add, self.rel, dctx, dqkv, qkvb_part, n_seq, cfg.L, cfg.A)
+            self._c("tnr_attn_l32_bwd_do", *bargs, dPb) if dPb else self._c("tnr_attn_l32_bwd", *bargs)
+            return True
+        bargs = (qkv, self.mask_add, self.rel, ctx, dctx, lse, self.delta, dqkv, n_seq, cfg.L, cfg.A)
+        self._c("tnr_attn_long_bwd_do", *bargs, dPb) if dPb else self._c("tnr_attn_long_bwd", *bargs)
+        return False
+
     def encode(self, tok, n_seq, nidx=None, out=None, stop_at=None, train=True, extra=None):
         """NewsEncoder.forward model_bert.py:119-137 -> news vectors S[:n_seq] (fp32).
         tok (n_seq, 2L) int64 on device, or (nidx given) tok = resident news_combined (n+1, 2L) int32 and
@@ -756,17 +817,7 @@ class Engine:
             T.call("tnr_gather_rows", fc[1], fc[3], nidx, n_seq, self.Lr, 1, self.mask_add, n_seq, 0)
             first = self.lo
         else:
-            emb = (g(BERT + "embeddings.word_embeddings.weight"), g(BERT + "embeddings.position_embeddings.weight"),
-                   g(BERT + "embeddings.token_type_embeddings.weight"), g(BERT + "embeddings.LayerNorm.weight"),
-                   g(BERT + "embeddings.LayerNorm.bias"), cfg.ln_eps, self.x0, self.mask_add)
-            de = ds(T.DROP_EMB, 0)
-            pid = self._pos_ids(tok if nidx is not None else tok[:n_seq]) if cfg.pos_pad_id is not None else None
-            if nidx is None:
-                self._c("tnr_embed_ln_fwd_do", tok, n_seq, L, H, *emb, de, pid) if (de or pid is not None) else \
-                    self._c("tnr_embed_ln_fwd", tok, n_seq, L, H, *emb)
-            else:
-                self._c("tnr_embed_ln_fwd_indexed_do", tok, nidx, n_seq, L, H, *emb, de, pid) if (de or pid is not None) else \
-                    self._c("tnr_embed_ln_fwd_indexed", tok, nidx, n_seq, L, H, *emb)
+            self._embed_fwd(tok, n_seq, nidx, self.x0)
         x = self.x0
         self.x_in = {}
         for l in range(first, cfg.n_layers):
@@ -780,15 +831,7 @@ class Engine:
             bqkv = self._view(names[3], 3 * H, (3 * H,))
             self.x_in[l] = x
             self._gemm(x, sh["qkv"], a["qkv"], M, bias=bqkv, flags=T.EPI_BIAS)
-            dp = ds(T.DROP_PROB, l)
-            if L <= 32:
-                if dp:
-                    self._c("tnr_attn_l32_fwd_do", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A, dp)
-                else:
-                    self._c("tnr_attn_l32_fwd", a["qkv"], self.mask_add, self.rel, a["ctx"], n_seq, L, cfg.A)
-            else:
-                largs = (a["qkv"], self.mask_add, self.rel, a["ctx"], a["lse"] if kept else self.lse, n_seq, L, cfg.A)
-                self._c("tnr_attn_long_fwd_do", *largs, dp) if dp else self._c("tnr_attn_long_fwd", *largs)
+            self._attn_fwd(a["qkv"], a["ctx"], a["lse"] if kept else self.lse, n_seq, ds(T.DROP_PROB, l))
             self._gemm(a["ctx"], sh["o"], a["h1pre"], M, bias=g(names[7]), res=x, flags=T.EPI_BIAS | T.EPI_RES,
                        drop=ds(T.DROP_ATTN_OUT, l))
             self._c("tnr_ln_fwd", a["h1pre"], g(names[8]), g(names[9]), cfg.ln_eps, a["h1"], a["st1"], M, H)
@@ -802,12 +845,7 @@ class Engine:
         # pooling (model_bert.py:130-135: AttentionPooling without mask | token 0 | mean) + dense (:136)
         if cfg.pooling == "att":
             self._gemm(x, self.sh_a1, self.e, M, bias=self.b_a1, flags=T.EPI_BIAS | T.EPI_TANH | T.EPI_OUTF32)
-            if L > AP_LONG:                  # few, long sequences (stage-1 bodies): the chunked kernels fill the chip
-                self._c("tnr_attpool_fwd_long", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
-                        self.nv, self.alpha, self.den, self.ap_ws, n_seq, L, H)
-            else:
-                self._c("tnr_attpool_fwd", x, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), g(PFX + "attn.att_fc2.bias"), cfg.Qn,
-                        self.nv, self.alpha, self.den, n_seq, L, H)
+            self._attpool_fwd(x, self.e, self.nv, n_seq)
         else:
             self._c("tnr_pool_fwd", x, self.nv, n_seq, L, H, int(cfg.pooling == "mean"))
         wd = g(PFX + "dense.weight")
@@ -1108,12 +1146,7 @@ class Engine:
         rb.add(dvec, N, D, D, gr[PFX + "dense.bias"], acc)       # column sums; in place, behind the two GEMMs that read dvec
         y = self.y_last
         if cfg.pooling == "att":
-            if L > AP_LONG:
-                self._c("tnr_attpool_bwd_long", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha,
-                        self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, self.ap_ws, N, L, H)
-            else:
-                self._c("tnr_attpool_bwd", y, self.e, QPAD, g(PFX + "attn.att_fc2.weight"), cfg.Qn, self.dnv, self.alpha, self.den,
-                        self.dy2, self.dpre, QPAD, self.dw2p, self.db2p, self.db1p, N, L, H)
+            self._attpool_bwd(y, self.e, self.dnv, self.dy2, self.dpre, self.dw2p, self.db2p, self.db1p, N)
             rb.add(self.dw2p, N, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], acc, gi)
             rb.add(self.db2p, N, 1, 1, gr[PFX + "attn.att_fc2.bias"], acc, gi)
             rb.add(self.db1p, N, QPAD, QPAD, self._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), acc, gi)
@@ -1188,17 +1221,12 @@ class Engine:
                 rba.add(P["ln_part1"][2 * H:], nblk, 3 * H, H, gr[names[7]], acc, gi)                               # attention.output.dense.bias
                 self._wgrad(dh1pre_lin, a["ctx"], gr[names[6]], M, acc)
             self._gemm(dh1pre_lin, sh["oT"], self.dctx, M)
-            if L <= 32:
-                bargs = (a["qkv"], self.mask_add, self.rel, self.dctx, self.dqkv, (P["qkvb_part"] if tr else None), N, L, cfg.A)
-                self._c("tnr_attn_l32_bwd_do", *bargs, dPb) if dPb else self._c("tnr_attn_l32_bwd", *bargs)
+            if self._attn_bwd(a["qkv"], a["ctx"], a["lse"], self.dctx, self.dqkv, (P["qkvb_part"] if tr else None), N, dPb):
                 if tr:
                     rba.add(P["qkvb_part"], N, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
-            else:
-                bargs = (a["qkv"], self.mask_add, self.rel, a["ctx"], self.dctx, a["lse"], self.delta, self.dqkv, N, L, cfg.A)
-                self._c("tnr_attn_long_bwd_do", *bargs, dPb) if dPb else self._c("tnr_attn_long_bwd", *bargs)
-                if tr:
-                    self._c("tnr_colsum", self.dqkv, 3 * H, T.BF16, M, 3 * H, P["cs_tmp2"][:3 * H], self.cs_part, 0)
-                    rba.add(P["cs_tmp2"], 1, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
+            elif tr:
+                self._c("tnr_colsum", self.dqkv, 3 * H, T.BF16, M, 3 * H, P["cs_tmp2"][:3 * H], self.cs_part, 0)
+                rba.add(P["cs_tmp2"], 1, 3 * H, 3 * H, self._view(names[3], 3 * H, (3 * H,), grad=True), acc, gi)
             if tr:
                 self._wgrad(self.dqkv, x_in, self._view(names[0], 3 * H * H, (3 * H, H), grad=True), M, acc)
                 if self._wg is not None:               # all four of the layer (two under a bucket hook), before the next layer overwrites their operands

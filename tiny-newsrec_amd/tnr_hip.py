@@ -46,7 +46,9 @@ def sgemm_group(problems):
         for k, _ in SgemmProblem._fields_:
             v = q.get(k, 0)
             setattr(arr[i], k, _ptr(v) if (isinstance(v, torch.Tensor) or v is None) else v)
+    ev = _all_begin()
     rc = lib().tnr_sgemm_group(arr, len(problems), stream())
+    _all_end(ev, "tnr_sgemm_group")
     if rc != 0:
         raise TnrError("tnr_sgemm_group failed (%d): %s" % (rc, lib().tnr_last_error().decode()))
 
@@ -64,7 +66,9 @@ def wgrad_group(problems, f16=False):
             v = q[k]
             setattr(arr[i], k, _ptr(v) if isinstance(v, torch.Tensor) else v)
     name = "tnr_gemm_tn_wgrad_group" + ("_f16" if f16 else "")
+    ev = _all_begin()
     rc = getattr(lib(), name)(arr, len(problems), stream())
+    _all_end(ev, name)
     if rc != 0:
         raise TnrError("%s failed (%d): %s" % (name, rc, lib().tnr_last_error().decode()))
 
@@ -97,6 +101,7 @@ _SIG = {
     "tnr_gemm_nt_route": [_L, _L, _L, _I],
     "tnr_gemm_nt_plan": [_L, _L, _I, _I, _P, _P, _P],
     "tnr_gemm_queue_reset": [_P],
+    "tnr_gemm_clock_stamps": [_P, _L],
     "tnr_gemm_set_option": [_c.c_char_p, _I],
     "tnr_gemm_tn_wgrad": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _P],
     "tnr_gemm_tn_wgrad_ex": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _F, _P],
@@ -219,6 +224,24 @@ def stream():
 # name -> list of (start_event, end_event, work) filled while a name is in TIMED (bench.py's roofline leg):
 # events are recorded on torch's current stream, which is the stream the kernel is launched on.
 TIMED = {}
+# a list -> EVERY call is bracketed and recorded as (start_event, end_event, entry point name) (bench.py's step_breakdown_ms: a few
+# extra steps AFTER the timed region, so the timed region carries none of it)
+TIMED_ALL = None
+
+
+def _all_begin():
+    if TIMED_ALL is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _all_end(e0, name):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        TIMED_ALL.append((e0, e1, name))
 
 
 def _work(name, conv):
@@ -234,13 +257,16 @@ def call(name, *args):
     L = lib()
     conv = [_conv(a) for a in args]
     rec = TIMED.get(name)
-    if rec is not None:
+    if rec is not None or TIMED_ALL is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = getattr(L, name)(*conv, stream())
     if rec is not None:
         e1.record()
         rec.append((e0, e1, _work(name, conv), (conv[6], conv[7], conv[8], conv[14]) if "gemm_nt" in name else None))
+    elif TIMED_ALL is not None:
+        e1.record()
+        TIMED_ALL.append((e0, e1, name))
     if rc != 0:
         raise TnrError("%s failed (%d): %s" % (name, rc, L.tnr_last_error().decode()))
 
