@@ -25,7 +25,8 @@ import torch         # noqa: E402
 
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 N_NEWS = 51282          # MIND-small-train sized news table (+ pad row 0)
-CAL_REF_US = 100.0      # calibration launch on the round-6 build boxes (median of the leases in README.md); set after measuring
+CAL_REF_US = 62.0       # `box` references = medians over the round-6 build leases (README.md): the calibration launch in step
+CLOCK_REF_MHZ = 2000.0  # context, and the shader clock under the step's NT launches
 EVENT_EVERY = 4         # roofline leg: every 4th timed step has its NT GEMM launches bracketed by HIP events
 
 
@@ -125,42 +126,51 @@ def family_of(name):
     return "heads_kd_misc"
 
 
-def box_probe(T, dev, dtype, reps=20):
+class BoxProbe:
     """What this BOX does with a fixed piece of work, so that two bench lines can be told apart into box and build: ONE fixed
-    persistent NT launch (M = 52 800, N = K = 768, plain epilogue, random operands) timed over `reps` back-to-back launches behind
-    60 warm ones, and the shader clock the chip holds under it (tnr_gemm_clock_stamps: cycles / 100 MHz ticks per workgroup)."""
-    sfx = "_f16" if dtype == "fp16" else ""
-    td = torch.float16 if dtype == "fp16" else torch.bfloat16
-    M, N, K = 52800, 768, 768
-    g = torch.Generator(device=dev)
-    g.manual_seed(7)
-    a_ = (torch.randn((M, K), device=dev, generator=g) * 0.5).to(td)
-    b_ = (torch.randn((N, K), device=dev, generator=g) * 0.05).to(td)
-    c_ = torch.zeros((M, N), device=dev, dtype=td)
-    stamps = torch.zeros((256, 2), device=dev, dtype=torch.int64)
+    persistent NT launch (M = 52 800, N = K = 768, plain epilogue, random operands) and the shader clock the chip holds under it
+    (tnr_gemm_clock_stamps: cycles / 100 MHz ticks per workgroup).  launch() is called right BEHIND a training step (the step
+    breakdown's extra steps, after the timed region): the chip is then in the power state the step's own GEMMs see - the same
+    launch repeated back to back for milliseconds runs at another clock (1.5 against 2.06 GHz in-step on one of this round's boxes)."""
 
-    def run():
-        T.call("tnr_gemm_nt_ex" + sfx, a_, K, b_, K, c_, N, M, N, K, None, None, 0, None, 0, 0, None)
-    for _ in range(60):
-        run()
-    T.lib().tnr_gemm_clock_stamps(stamps.data_ptr(), 256)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    T.lib().tnr_gemm_clock_stamps(None, 0)
-    us = 1e3 * e0.elapsed_time(e1) / reps
-    st = stamps.cpu().numpy()
-    ok = st[:, 1] > 0
-    mhz = 100.0 * st[ok, 0] / st[ok, 1]
-    return {"calibration_launch": {"M": M, "N": N, "K": K, "epilogue": "plain", "reps": reps, "us": round(us, 2),
-                                   "tflops": round(2.0 * M * N * K / us / 1e6, 1),
-                                   "route": T.query("tnr_gemm_nt_route" + sfx, M, N, K, 0)},
-            "mfma_clock_mhz_under_calibration": round(float(np.median(mhz)), 0) if ok.any() else None,
-            "mfma_clock_mhz_min_max": [round(float(mhz.min()), 0), round(float(mhz.max()), 0)] if ok.any() else None,
-            "workgroups_stamped": int(ok.sum())}
+    def __init__(self, T, dev, dtype):
+        self.T, self.sfx = T, "_f16" if dtype == "fp16" else ""
+        td = torch.float16 if dtype == "fp16" else torch.bfloat16
+        self.M, self.N, self.K = 52800, 768, 768
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        self.a = (torch.randn((self.M, self.K), device=dev, generator=g) * 0.5).to(td)
+        self.b = (torch.randn((self.N, self.K), device=dev, generator=g) * 0.05).to(td)
+        self.c = torch.zeros((self.M, self.N), device=dev, dtype=td)
+        self.stamps = [torch.zeros((256, 2), device=dev, dtype=torch.int64) for _ in range(16)]
+        self.ev = []
+
+    def launch(self):
+        T, M, N, K = self.T, self.M, self.N, self.K
+        i = len(self.ev)
+        T.lib().tnr_gemm_clock_stamps(self.stamps[i].data_ptr(), 256)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        T.call("tnr_gemm_nt_ex" + self.sfx, self.a, K, self.b, K, self.c, N, M, N, K, None, None, 0, None, 0, 0, None)
+        e1.record()
+        T.lib().tnr_gemm_clock_stamps(None, 0)
+        self.ev.append((e0, e1))
+
+    def result(self):
+        T, M, N, K = self.T, self.M, self.N, self.K
+        us = sorted(1e3 * e0.elapsed_time(e1) for e0, e1 in self.ev)
+        med = us[len(us) // 2]
+        mhz = []
+        for st in self.stamps[:len(self.ev)]:
+            st = st.cpu().numpy()
+            ok = st[:, 1] > 0
+            if ok.any():
+                mhz.append(float(np.median(100.0 * st[ok, 0] / st[ok, 1])))
+        return {"calibration_launch": {"M": M, "N": N, "K": K, "epilogue": "plain", "samples": len(us), "us": round(med, 2),
+                                       "us_min_max": [round(us[0], 2), round(us[-1], 2)], "tflops": round(2.0 * M * N * K / med / 1e6, 1),
+                                       "route": T.query("tnr_gemm_nt_route" + self.sfx, M, N, K, 0),
+                                       "protocol": "one launch right behind each of the step breakdown's extra training steps; median"},
+                "mfma_clock_mhz_under_calibration": round(float(np.median(mhz)), 0) if mhz else None}
 
 
 def self_launch(a):
@@ -353,7 +363,7 @@ def main():
             nd = 20000
             s1 = Stage1Engine(n_layers=2, trainable_layers=(0, 1), num_teachers=4, npratio=Kn, title_len=Lt, body_len=Lb, device=dev,
                               batch=B, dtype="fp16")
-            for knob in ("chain_wgrad", "two_streams"):              # A/B switches of tools/ only (defaults = the class's)
+            for knob in ("chain_wgrad", "two_streams", "joint", "joint_streams"):              # A/B switches of tools/ only (defaults = the class's)
                 if os.environ.get("TNR_S1_" + knob.upper()) is not None:
                     setattr(s1, knob, os.environ["TNR_S1_" + knob.upper()] == "1")
             s1.load_state_dict({k: torch.from_numpy(hashinit.init_tensor(seed, k, tuple(sh))) for k, sh in s1.shapes.items()})
@@ -480,18 +490,23 @@ def main():
         # OUTSIDE the timed region's clock; `step_breakdown_ms`: 8 more steps (untimed) with EVERY library call bracketed by events
         st_ = clock_stamps.cpu().numpy()
         ok_ = st_[:, 1] > 0
-        box = box_probe(T, dev, a.dtype)
-        box["mfma_clock_mhz_under_load"] = round(float(np.median(100.0 * st_[ok_, 0] / st_[ok_, 1])), 0) if ok_.any() else None
-        box["note"] = ("under_load: median over the workgroups of the last event-sampled step's last persistent NT launch inside the timed "
-                       "region (shader cycles / 100 MHz ticks of a workgroup's life); calibration: right after the timed region")
+        probe = BoxProbe(T, dev, a.dtype)
         n_bd = min(8, K)
         T.TIMED_ALL = []
         torch.cuda.synchronize()
-        tb0 = time.perf_counter()
+        tb = 0.0
         for i in range(W, W + n_bd):
+            tb0 = time.perf_counter()
             one_step(eng, gs, i, a.dedup == "only")
-        torch.cuda.synchronize()
-        tb = 1e3 * (time.perf_counter() - tb0) / n_bd
+            all_, T.TIMED_ALL = T.TIMED_ALL, None
+            probe.launch()                                   # the calibration launch, in the step's own power state
+            T.TIMED_ALL = all_
+            torch.cuda.synchronize()
+            tb += 1e3 * (time.perf_counter() - tb0) / n_bd
+        box = probe.result()
+        box["mfma_clock_mhz_under_load"] = round(float(np.median(100.0 * st_[ok_, 0] / st_[ok_, 1])), 0) if ok_.any() else None
+        box["note"] = ("under_load: median over the workgroups of the last event-sampled step's last persistent NT launch INSIDE the timed "
+                       "region (shader cycles / 100 MHz ticks of a workgroup's life)")
         rec_all, T.TIMED_ALL = T.TIMED_ALL, None
         fam_ms, fam_calls = {}, {}
         for e0_, e1_, nm_ in rec_all:
@@ -500,10 +515,10 @@ def main():
             fam_calls[f_] = fam_calls.get(f_, 0) + 1
         breakdown = {k_: round(v_, 4) for k_, v_ in sorted(fam_ms.items(), key=lambda kv: -kv[1])}
         breakdown["sum_of_calls"] = round(sum(fam_ms.values()), 4)
-        breakdown["step_with_events"] = round(tb, 4)
+        breakdown["step_with_events_and_calibration_launch"] = round(tb, 4)
         breakdown["calls_per_step"] = {k_: v_ // n_bd for k_, v_ in fam_calls.items()}
         breakdown["note"] = ("%d extra steps AFTER the timed region, every C-ABI call bracketed by two HIP events on its stream (weight_gradient "
-                             "includes its slab reductions; step_with_events carries the ~170 event records, ms_per_step does not)" % n_bd)
+                             "includes its slab reductions; the steps are drained one by one here, ms_per_step's are not)" % n_bd)
     if rank == 0 and os.environ.get("TNR_BENCH_DUMP_PARAMS"):
         np.save(os.environ["TNR_BENCH_DUMP_PARAMS"], eng.flat[True][::97].float().cpu().numpy())
     dp_info = None
@@ -689,11 +704,14 @@ def main():
         out["quality"] = PARITY.get("quality")       # tests/test_quality_gpu.py: AUC / MRR / nDCG against the reference-trained golden
         if box is not None:
             out["box"] = box
-            cal = box["calibration_launch"]["us"]
+            cal, clk = box["calibration_launch"]["us"], box["mfma_clock_mhz_under_load"]
             out["box"]["headline_normalised"] = {
-                "calibration_us_reference": CAL_REF_US, "value_at_reference_calibration": round(value * cal / CAL_REF_US, 2),
-                "note": "value x (this box's calibration us / %.1f us, the round-6 build box's median): a first-order removal of the box's "
-                        "clock from the headline; compare RAW values only between boxes with equal calibration_us" % CAL_REF_US}
+                "reference": {"calibration_us": CAL_REF_US, "mfma_clock_mhz": CLOCK_REF_MHZ},
+                "value_at_reference_calibration": round(value * cal / CAL_REF_US, 2),
+                "value_at_reference_clock": round(value * CLOCK_REF_MHZ / clk, 2) if clk else None,
+                "note": "first-order removal of the box from the headline: value x (this box's calibration us / reference us) and value x "
+                        "(reference MHz / this box's MHz under load); the references are the medians of the round-6 build leases "
+                        "(README.md) - compare RAW values only between boxes whose calibration and clock agree"}
             out["step_breakdown_ms"] = breakdown
         if dp_info is not None:
             out["dp"] = dp_info

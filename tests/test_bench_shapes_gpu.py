@@ -218,13 +218,15 @@ def test_gemm_tn_wgrad_plain_loop_variant_bit_exact():
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 def test_gemm_tn_wgrad_register_staged_variant_bit_identical(dtype):
-    """The weight-gradient kernel's two ping-pong main loops (tnr_gemm_set_option "tnpp": 1 = operands by LDS-DMA + transposing
-    fragment reads, 2 = operands through registers, transposed there, fragment-ready LDS image) feed every MFMA the same operand
-    registers in the same order: integer-exact on the step's launches, and the SAME BITS on random operands."""
+    """The weight-gradient kernel's two main loops (tnr_gemm_set_option "tnpp": 0 = the plain two-buffer loop, operands by LDS-DMA +
+    transposing fragment reads; 2 = the persistent ping-pong loop, operands through registers, transposed there, fragment-ready LDS
+    image - the default) feed every MFMA the same operand registers in the same order: integer-exact on the step's launches, and
+    the SAME BITS on random operands.  (Rounds 3-5 kept a third loop, tnpp = 1 - LDS-DMA under the ping-pong schedule - as the
+    middle term of this comparison; round 6 removed it from the library.)"""
     L = T.lib()
     M, Mp = M_BENCH, (M_BENCH + 127) // 128 * 128
     try:
-        for tnpp in (1, 2):
+        for tnpp in (0, 2):
             assert L.tnr_gemm_set_option(b"tnpp", tnpp) == 0
             for name, N, K in WGRAD_LAUNCHES:
                 test_gemm_tn_wgrad_bit_exact_at_bench_shape(dtype, name, N, K)
@@ -237,7 +239,7 @@ def test_gemm_tn_wgrad_register_staged_variant_bit_identical(dtype):
             splits = E.Engine._wgrad_splits(N, K)[0]
             ws = torch.zeros(T.query("tnr_gemm_tn_ws_elems" + _sfx(dtype), N, K, splits), device=DEV)
             outs = []
-            for tnpp in (1, 2):
+            for tnpp in (0, 2):
                 L.tnr_gemm_set_option(b"tnpp", tnpp)
                 dW = torch.zeros((N, K), device=DEV)
                 T.call("tnr_gemm_tn_wgrad" + _sfx(dtype), dy, N, x, K, dW, K, M, N, K, ws, splits, 0)

@@ -523,6 +523,20 @@ def test_fp16_overflow_skips_the_step_and_halves_the_scale():
     # half the scale: the same values one binade lower (exact but for what drops into fp16's subnormals)
     d = float((eng.flat[True] - ref.flat[True]).abs().max())
     assert d < 2e-6, d
+    # a BACKWARD at the halved scale: bias / LayerNorm gradients leave through batched reductions that replay a recorded job table
+    # with 1 / scale in its descriptors - the table has to follow the scale (round 6: it was recorded once and went stale)
+    for e in (eng, ref):
+        e.forward(*args)
+        e.backward()
+    torch.cuda.synchronize()
+    assert eng.ginv == 2.0 * ref.ginv
+    rel = float((eng.flat_g - ref.flat_g).norm() / ref.flat_g.norm())
+    assert rel < 2e-3, rel
+    for name in [n for n in eng.grads if n.endswith(("LayerNorm.weight", "dense.bias", "att_fc1.bias", "query.bias"))]:
+        ge, gr_ = eng.grad(name), ref.grad(name)
+        assert float((ge - gr_).norm()) <= 1e-2 * float(gr_.norm()) + 1e-9, name
+    for e in (eng, ref):
+        e.step(1e-3)
     # growth: `growth_interval` clean answers in a row double the multiplier
     sc.growth_interval = 3
     for _ in range(6):

@@ -8,8 +8,8 @@ taken twice or a garbage tile index all leave a residue:
   * NT kernels (256- and 224-row tiles): C <- (+-A) B^T + C in place (TNR_EPI_RES with res = C), the sign of A alternating - after
     every pair of launches C is back at its start value exactly; a tile computed twice in a launch adds its product twice, a
     skipped one misses it.
-  * weight-gradient kernels (register-staged default and the LDS-DMA loop, option "tnpp" = 1): dW += (+-dY)^T X - a unit that
-    nobody computed leaves the previous launch's slab (opposite sign) in the sum.
+  * weight-gradient kernel (gemm_tn_rs_kernel; its grouped launch with two chained problems as well): dW += (+-dY)^T X - a unit
+    that nobody computed leaves the previous launch's slab (opposite sign) in the sum.
 Operands are small integers: every product and sum is exact in fp16 / fp32, so "back at the start" is bit-for-bit."""
 import numpy as np
 import pytest
@@ -62,8 +62,8 @@ def test_nt_persistent_tiles_are_taken_exactly_once_over_500_launches_on_three_s
             s, bad.shape[0], LAUNCHES, bad[0].tolist(), int(bad[0, 0]) // 32, int(bad[0, 1]) // 256)
 
 
-@pytest.mark.parametrize("tnpp", [2, 1])
-def test_wgrad_persistent_units_are_taken_exactly_once_over_500_launches_on_three_streams(tnpp):
+@pytest.mark.parametrize("grouped", [False, True])
+def test_wgrad_persistent_units_are_taken_exactly_once_over_500_launches_on_three_streams(grouped):
     import engine as E
     td, sfx, M, N, K = torch.float16, "_f16", 20000, 768, 768
     g = torch.Generator(device=DEV).manual_seed(13)
@@ -78,22 +78,29 @@ def test_wgrad_persistent_units_are_taken_exactly_once_over_500_launches_on_thre
         x[:M] = _ints((M, K), -1, 1, g, td)
         dw0 = _ints((N, K), -8, 8, g, torch.float32)
         sets.append((dy, (-dy).contiguous(), x, dw0, dw0.clone(), torch.zeros(elems, device=DEV)))
-    assert T.lib().tnr_gemm_set_option(b"tnpp", tnpp) == 0
-    try:
-        dy, ndy, x, dw0, dw, ws = sets[0]
-        T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy, N, x, K, dw, K, M, N, K, ws, splits, 1, 1.0)
-        torch.cuda.synchronize()
-        assert torch.equal(dw, dy[:M].float().t() @ x[:M].float() + dw0)
-        T.call("tnr_gemm_tn_wgrad_ex" + sfx, ndy, N, x, K, dw, K, M, N, K, ws, splits, 1, 1.0)
-        torch.cuda.synchronize()
-        assert torch.equal(dw, dw0)
-        for i in range(LAUNCHES):
-            for st, (dy, ndy, x, dw0, dw, ws) in zip(streams, sets):
-                with torch.cuda.stream(st):
-                    T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy if i % 2 == 0 else ndy, N, x, K, dw, K, M, N, K, ws, splits, 1, 1.0)
-        torch.cuda.synchronize()
-    finally:
-        T.lib().tnr_gemm_set_option(b"tnpp", 2)
+    def launch(dy_, x, dw, ws):
+        if not grouped:
+            T.call("tnr_gemm_tn_wgrad_ex" + sfx, dy_, N, x, K, dw, K, M, N, K, ws, splits, 1, 1.0)
+            return
+        # the same sum as two chained problems of one grouped launch (stage 1's form): rows [0, M1) then rows [M1, M)
+        M1 = 12800
+        s1 = max(1, splits * M1 // M)
+        common = dict(dW=dw, lddw=K, N=N, K=K, out_scale=1.0)
+        T.wgrad_group([dict(common, dY=dy_, lddy=N, X=x, ldx=K, M=M1, ws=ws, splits=s1, accumulate=1),
+                       dict(common, dY=dy_[M1:], lddy=N, X=x[M1:], ldx=K, M=M - M1, ws=None, splits=splits - s1, accumulate=2)], f16=True)
+
+    dy, ndy, x, dw0, dw, ws = sets[0]
+    launch(dy, x, dw, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dy[:M].float().t() @ x[:M].float() + dw0)
+    launch(ndy, x, dw, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw0)
+    for i in range(LAUNCHES):
+        for st, (dy, ndy, x, dw0, dw, ws) in zip(streams, sets):
+            with torch.cuda.stream(st):
+                launch(dy if i % 2 == 0 else ndy, x, dw, ws)
+    torch.cuda.synchronize()
     for s, (dy, ndy, x, dw0, dw, ws) in enumerate(sets):
         bad = (dw != dw0).nonzero()
         assert bad.numel() == 0, "stream %d: %d elements off after %d launches, first at %s" % (s, bad.shape[0], LAUNCHES, bad[0].tolist())

@@ -18,7 +18,7 @@ void tnr_set_error(const char* fmt, ...) {
 extern "C" const char* tnr_last_error(void) { return g_err; }
 extern "C" int tnr_version(void) { return 1; }
 
-static TnrGemmOpts g_gemm_opts = {3, 8, 60, 1, 0, 0, 1, 2, 1, 0, 0, nullptr, 0};
+static TnrGemmOpts g_gemm_opts = {3, 8, 60, 1, 0, 0, 1, 2, 1, 0, nullptr, 0};
 TnrGemmOpts* tnr_gemm_opts() { return &g_gemm_opts; }
 
 extern "C" int tnr_gemm_set_option(const char* key, int value) {
@@ -33,7 +33,6 @@ extern "C" int tnr_gemm_set_option(const char* key, int value) {
     else if (!strcmp(key, "pp")) o.pp = value;
     else if (!strcmp(key, "tnpp")) o.tnpp = value;
     else if (!strcmp(key, "mix")) o.mix = value;
-    else if (!strcmp(key, "probe")) o.probe = value;
     else if (!strcmp(key, "cus")) o.cus = value;
     else { tnr_set_error("tnr_gemm_set_option: unknown key %s", key); return TNR_EINVAL; }
     return TNR_OK;

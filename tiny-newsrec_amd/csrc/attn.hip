@@ -75,13 +75,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const int row = lane & 31, h = lane >> 5;
     const int rowc = row < L ? row : L - 1;
     char* my = lds[w];
-#ifdef TNR_ATTN_STAMPS
-    unsigned long long tst[6];
-    tst[0] = __builtin_amdgcn_s_memtime();
-#define TNR_STAMP(i, dep) { asm volatile("" ::"v"(dep)); tst[i] = __builtin_amdgcn_s_memtime(); }
-#else
-#define TNR_STAMP(i, dep)
-#endif
 
     // additive mask + rel-pos rows of this lane's query FIRST: they are needed right after the score MFMAs, and a load issued
     // there is a second full trip through a saturated memory pipeline (stamps: 7.7 k of a wave's 45 k cycles, tools/attn_stamps.py)
@@ -97,21 +90,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     }
     const bf16* qp = qkv + (n * L + rowc) * ldq + a * 64 + 8 * h;
     bf16x8 qf[4], kf[4];
-#ifdef TNR_ATTN_PROBE      // timing probe only (wrong results): Q / K loaded in full 128-byte lines, 8 rows per instruction
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        int idx = s * 64 + lane, r = idx >> 3, c = idx & 7;
-        int rc = r < L ? r : L - 1;
-        qf[s] = *(const bf16x8*)(qkv + (n * L + rc) * ldq + a * 64 + c * 8);
-        kf[s] = *(const bf16x8*)(qkv + (n * L + rc) * ldq + HD + a * 64 + c * 8);
-    }
-#else
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         qf[s] = *(const bf16x8*)(qp + 16 * s);
         kf[s] = *(const bf16x8*)(qp + HD + 16 * s);
     }
-#endif
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
@@ -121,7 +104,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     f32x16 st = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) st = TNR_MFMA_32x32x16(kf[s], qf[s], st, 0, 0, 0);
-    TNR_STAMP(1, st[0])
 
     float mx = NEG_BIG;
 #pragma unroll
@@ -156,7 +138,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     }
     bf16x8 pf[2];
     acc_to_frags(st, pf);
-    TNR_STAMP(2, pf[0][0])
 
     f32x16 o[2];
 #pragma unroll
@@ -166,7 +147,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         for (int s = 0; s < 2; ++s)
             o[ct] = TNR_MFMA_32x32x16(pf[s], tr_frag(my, s, ct, lane), o[ct], 0, 0, 0);
     }
-    TNR_STAMP(3, o[1][0])
     acc_to_lds(my, o[0], 0, lane, 1.0f);
     acc_to_lds(my, o[1], 1, lane, 1.0f);
 #pragma unroll
@@ -174,14 +154,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         int idx = p * 64 + lane, r = idx >> 3, c = idx & 7;
         if (valid && r < L) *(bf16x8*)(ctx + (n * L + r) * HD + a * 64 + c * 8) = *(const bf16x8*)(my + r * TS + c * 16);
     }
-#ifdef TNR_ATTN_STAMPS
-    tst[4] = __builtin_amdgcn_s_memtime();
-    // stamps of one wave per block for the first 4096 blocks, written over the (probe-only) tail of rel: never read by anyone
-    if (lane == 0 && w == 0 && blockIdx.x < 4096) {
-        unsigned long long* o64 = (unsigned long long*)(rel + 12 * 1024) + blockIdx.x * 8;
-        for (int i = 0; i < 5; ++i) o64[i] = tst[i];
-    }
-#endif
 }
 
 // Backward: recompute P in both orientations, then dV = P^T dO, dS = P*(dP - rowsum(dP*P)),

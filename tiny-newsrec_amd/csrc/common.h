@@ -42,9 +42,8 @@ struct TnrGemmOpts {
     int bm;          // 0 = pick the tile height per launch ; 224 / 256 = force it
     int nt;          // 1 = non-temporal accesses for once-touched epilogue operands
     int pp;          // 1 = ping-pong main loop (two wave groups staggered by a barrier), 0 = plain two-buffer loop
-    int tnpp;        // weight gradient: 2 = register-staged ping-pong loop (default), 1 = LDS-DMA ping-pong loop, 0 = plain two-buffer loop
+    int tnpp;        // weight gradient: non-zero (default 2) = register-staged persistent ping-pong loop, 0 = plain two-buffer loop
     int mix;         // ping-pong NT kernel: 1 = row panels of two heights so that the tiles fill whole rounds, 0 = one height
-    int probe;       // timing probes of the ping-pong kernel (only in -DTNR_PROBES builds, tools/probe_build.sh)
     int cus;         // 0 = plan and size the persistent GEMM grids for the device's CUs ; n = for n of them (two kernels side by side)
     void* clock_buf; // tnr_gemm_clock_stamps: device buffer of clock_n (cycles, 100 MHz ticks) pairs the persistent NT kernel fills, or NULL
     int clock_n;

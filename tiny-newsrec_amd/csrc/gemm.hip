@@ -34,9 +34,8 @@ struct NTArgs {
     int mix_p, mix_x;          // ping-pong kernel: mix_p row panels, mix_x of them full height (32 MI rows), the others 32 rows
                                // shorter, spread evenly (pp_panel); mix_x == mix_p: the uniform tiling
     unsigned* queue;           // ping-pong kernel: 8 tile counters (one per XCD label) + a done counter, all zero between launches
-    int probe;                 // timing probes (tools only, TNR_PROBES builds): 1 no staging loads in the K loop, 2 no
-                               // fragment reads / MFMAs (512: no MFMAs only, 1024: no reads only), 4 every row tile reads A rows
-                               // 0-255 (A resident in L2), 8 no epilogue
+    int probe;                 // unused by the product: the slot the probe builds' switches take (tools/probes/README.md); kept so that the
+                               // kernel arguments of both builds have ONE layout (the kernels' scalar loads are scheduled around it)
     unsigned long long* clock; // ping-pong kernel, measurement hook (tnr_gemm_clock_stamps): workgroup b < clock_n writes the shader
     int clock_n;               // cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of its life at clock[2 b], clock[2 b + 1]; NULL = off
 };
@@ -916,17 +915,10 @@ __device__ __forceinline__ void nt_epilogue_cols(const NTArgs& g, f32x4 (&acc)[M
     const int row0 = rs + wm * 16 * nblk + m16;
     const bool odd = (m16 & 1) != 0;
     const int rowp = row0 - (m16 & 1), n0p = n0 + (odd ? 32 : 0);   // full-line stores: the pair's even row, this lane's column piece
-#if defined(TNR_PROBES) && TNR_PROBES >= 2
-    const int n0s = (g.probe & 32) ? wn * 64 + qd * 8 : n0, row0s = (g.probe & 32) ? wm * 16 * MI + m16 : row0;
-    const int n0ps = (g.probe & 32) ? wn * 64 + qd * 8 + (odd ? 32 : 0) : n0p, rowps = (g.probe & 32) ? wm * 16 * MI + m16 - (m16 & 1) : rowp;
-    const bool do_store = !(g.probe & 16);
-    const bool do_lut = !(g.probe & 2048), do_xload = !(g.probe & 4096);      // 2048: no table lookups ; 4096: no operand loads
-#else
     constexpr bool do_lut = true, do_xload = true;
     const int n0s = n0, row0s = row0;
     const int n0ps = n0p, rowps = rowp;
     constexpr bool do_store = true;
-#endif
     (void)n0s; (void)row0s;
     float bb[16];
     if (flags & TNR_EPI_BIAS) {
@@ -1131,9 +1123,6 @@ __device__ __forceinline__ void pp_q_fetch(unsigned& dst, unsigned* ctr, bool on
 }
 __device__ __forceinline__ void pp_q_wait(unsigned& v) { asm volatile("s_waitcnt vmcnt(0) ; tile queue: %0" : "+v"(v) :: "memory"); }
 
-#ifdef TNR_NT_STAMPS
-__device__ unsigned tnr_nt_stamp_buf[256][8][264];
-#endif
 template <int N_> __device__ __forceinline__ void tnr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 template <int MI, int CF>
@@ -1162,10 +1151,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     const int c0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int c1 = c0 + (xcd < r8 ? q8 + 1 : q8);
     int* const qlds = (int*)(smem + LDS3_BYTES);
-#ifdef TNR_NT_STAMPS
-    unsigned* const nstamps = (unsigned*)(smem + LDS3_BYTES + 64);
-    bool stamped = false;
-#endif
     unsigned q0;                                         // the first tile: in flight while the tables below are set up
     pp_q_fetch(q0, g.queue + xcd * PP_Q_STRIDE, w == 0);
     auto leave = [&]() {                                 // last workgroup out zeroes the counters for the next launch
@@ -1196,9 +1181,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int gm = rs_ + h * pr_ + (row < pr_ ? row : pr_ - 1);
-#if defined(TNR_PROBES) && TNR_PROBES >= 2
-                if (g.probe & 4) gm = h * PR + row;
-#endif
                 gm = gm < g.M ? gm : g.M - 1;
                 srcA[h][q] = g.A + (int64_t)gm * g.lda + chunk * 8;
                 srcB[h][q] = g.B + (int64_t)(bn_ * 256 + h * 128 + row) * g.ldb + chunkb * 8;
@@ -1208,9 +1190,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     };
     // half tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of K tile kt into stage buffer kt & 1
     auto issue = [&](int which, int kt) {
-#if defined(TNR_PROBES) && TNR_PROBES >= 2
-        if ((g.probe & 1) && kt > 1) return;
-#endif
         char* base = smem + (kt & 1) * STAGE3 + which * TILE_BYTES + (2 * w) * 1024;
         if (which < 2) {
             if (a_live) {
@@ -1257,18 +1236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 
     constexpr int ILO = MI < 4 ? MI : 4, IHI = MI - ILO; // 16-row blocks of the wave's lower / upper A half
     bf16x8 af[4][2], bfr[4][2];
-#ifdef TNR_NT_STAMPS
-// probe build only (make BUILD=../../tools/_ntst EXTRA=-DTNR_NT_STAMPS, NT=1 tools/tn_stamps.py): every wave's s_memtime on arrival at
-// each of the 8 barriers of K tiles 0-31 of the workgroup's FIRST tile, as in gemm_tn_rs_kernel's probe
-#define TNR_NT_BARRIER(K)                                                                                      \
-    do {                                                                                                       \
-        unsigned long long ts_;                                                                                \
-        asm volatile("s_memtime %0\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");              \
-        if (lane == 0 && !stamped && kt < 32) nstamps[w * 264 + 8 + 8 * kt + (K)] = (unsigned)ts_;             \
-    } while (0)
-#else
 #define TNR_NT_BARRIER(K) __builtin_amdgcn_s_barrier()
-#endif
 #define TNR_PP_SEG_END(K)                                           \
     __builtin_amdgcn_sched_barrier(0);                              \
     TNR_NT_BARRIER(K);                                              \
@@ -1280,12 +1248,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     __builtin_amdgcn_sched_barrier(0);                              \
     TNR_NT_BARRIER(K);                                              \
     __builtin_amdgcn_sched_barrier(0)
-#if defined(TNR_PROBES) && TNR_PROBES >= 2
-    const bool compute = !(g.probe & 2);
-    const bool reads_on = compute && !(g.probe & 1024), mfma_on = compute && !(g.probe & 512);   // 512: no MFMAs ; 1024: no fragment reads
-#else
     constexpr bool reads_on = true, mfma_on = true;
-#endif
   while (true) {
     int bm, bn, rs;
     bool tall_v;
@@ -1323,27 +1286,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     // -> B(kt+1) has landed one barrier (two for the staggered group) before phase 3 reads it; end of phase 3 vmcnt(2) =
     // all but A0(kt+2) -> A1(kt+1) landed before the next K tile.  WAR: B(kt-1) was last read in phase 1 of K tile kt-1 (its
     // columns 0-31 in phase 3 of kt-2), A1(kt-1) in group 1's phase 2 of kt-1, A0(kt) in group 0's phase 2 of kt.
-#if defined(TNR_PROBES) && TNR_PROBES >= 2
-    /* probe 128: can stores spread thinly over the K loop hide beside the MFMAs?  One 16-byte store per lane in the load segment
-       of every phase of K tiles 0, 3, 6, 9 (16 per wave and tile, what the epilogue issues), into this tile's own C rows; the waits
-       count them as younger than the LDS-DMA pieces they follow.  Outputs are garbage; use with probe 8 (no epilogue). */
-    const unsigned dlc = (unsigned)(((rs + wm * PR + (lane & 15)) * (int)g.ldc + bn * 256 + wn * 64 + (lane >> 4) * 8) * 2);
-    const __amdgpu_buffer_rsrc_t drC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((int64_t)g.M * g.ldc * 2), 0x00020000);
-#define TNR_PP_DUMMY_ON ((g.probe & 128) && (kt % 3) == 0)
-#define TNR_PP_DUMMY_STORE(P)                                                                                    \
-    if (TNR_PP_DUMMY_ON) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, af[P][0]), drC, dlc + (unsigned)((P) * 16 * (int)g.ldc * 2), 0, 0)
-#define TNR_PP_DUMMY_WAIT(P)                                                                                     \
-    if (TNR_PP_DUMMY_ON) {                                                                                       \
-        if ((P) == 2) { if (more && a_live) tnr_wait_vm<2 + 2>(); else tnr_wait_vm<2>(); }                       \
-        else { if (kt + 2 < nk && a_live) tnr_wait_vm<2 + 2>(); else tnr_wait_vm<2>(); }                         \
-    } else if ((P) == 2) { if (more && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0); }                      \
-    else { if (kt + 2 < nk && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0); }
-#else
 #define TNR_PP_DUMMY_STORE(P)
 #define TNR_PP_DUMMY_WAIT(P)                                                                                     \
     if ((P) == 2) { if (more && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0); }                             \
     else { if (kt + 2 < nk && a_live) TNR_WAIT_VMCNT(2); else TNR_WAIT_VMCNT(0); }
-#endif
 #define TNR_PP_KTILE(KT, BL, BH)                                                                                 \
     {                                                                                                            \
         const int kt = (KT);                                                                                     \
@@ -1412,15 +1358,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
 #undef TNR_PP_DUMMY_WAIT
 #undef TNR_PP_SEG_END
 #undef TNR_PP_MFMA_END
-#ifdef TNR_NT_STAMPS
-    if (!stamped) {
-        if (lane == 0) nstamps[w * 264 + 4] = (unsigned)nk;
-        __syncthreads();
-        if (blockIdx.x < 256)
-            for (int i = tid; i < 8 * 264; i += 512) (&tnr_nt_stamp_buf[blockIdx.x][0][0])[i] = nstamps[i];
-        stamped = true;
-    }
-#endif
     pp_q_wait(qn);                                       // (the K loop's last waits were vmcnt(0) already)
     if (tid == 0) {
         qlds[1] = c0 + (int)qn;
@@ -1432,18 +1369,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NTArgs g) {
     // every fragment read of this tile has completed (group 1's last MFMA segment is behind the barrier above): the stage
     // ring is free, so the next tile's first loads go out BEFORE this tile's epilogue and land under it
     if (next >= 0) prologue(next, par ^ 1);
-#if defined(TNR_PROBES) && TNR_PROBES >= 2
-    if (g.probe & 8) {                                   // no epilogue: keep the accumulators alive, store nothing
-        if (acc[0][0][0] == 12345.678f) *(f32x4*)g.C = acc[1][1];
-    } else
-#endif
-#ifdef TNR_NOEPI   // tools only (make BUILD=../../tools/_noepi EXTRA=-DTNR_NOEPI): the product's code minus the epilogue, no probe code
-#pragma unroll     // in the K loop - the probe build's runtime switches slow its K loop by ~15 %, which misled one A/B (EXPERIMENTS.md)
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
-    if (false)
-#endif
     nt_epilogue_cols<MI, CF>(g, acc, lut, bias_lds + par * 256, bm, bn, rs, tall ? MI : MI - 1, wm, wn, lane);
     par ^= 1;
     if (g.clock && next < 0 && tid == 0 && (int)blockIdx.x < g.clock_n) {   // shader cycles / 100 MHz ticks of this workgroup's life
@@ -1556,237 +1481,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256x256_kernel(TNArgs g) {
     }
 }
 
-// wgrad v4 "ping-pong": the v3 tile and stage image (256 n x 256 k output, 64-row m steps, [dY0 | dY1 | X0 | X1] sub-tiles of
-// [64 m][256 B]) under the schedule of gemm_nt_pp_kernel: the two wave groups (wn = 0 / 1: the two 128-column halves of dY)
-// run one interval apart, each alternating a LOAD segment (transposed fragment reads + the LDS-DMA of a later sub-tile)
-// with an MFMA segment of 16 MFMAs; dY0 / dY1 are private to a group (the A0 / A1 of the NT kernel), X0 / X1 shared (its
-// B0 / B1).  m step = 4 phases: L0 reads dY blocks 0-3 + X blocks 0-1, L1 X blocks 2-3, L2 dY blocks 4-7, L3 nothing;
-// M0..M3 = quadrants (y lo, x lo), (y lo, x hi), (y hi, x hi), (y hi, x lo).  DMA: phase 0 of step t issues dY1(t+1), phase 3
-// dY0(t+2), X0(t+2), X1(t+2) and waits vmcnt(6) (everything of step t+1 has landed).  Both operands stream from HBM here, so
-// the order is chosen for latency budget (8 intervals for three of the four sub-tiles, 6 for dY1): with the NT kernel's old
-// order (X1 two intervals before its wait) this kernel was 3-5 % slower.
-__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNGroup grp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = w >> 2, wk = w & 3;          // wave tile: 128 n x 64 k
-    // Persistent: the work units (split z, output tile) -- one fp32 slab tile each, unit id = z * ntile + tile -- are PULLED from the
-    // stream's queue counters exactly as the NT kernel pulls its tiles: the workgroups of an XCD label take consecutive units of
-    // that label's contiguous run (units of one split read the same rows of dY / X: they share them through the XCD's L2), and a
-    // workgroup whose CU is held by another stream's kernel (the all-reduce of a finished gradient bucket) simply takes fewer.
-    // With one unit per workgroup -- the single-GPU choice of splits, one round -- this is the old static grid; the data-parallel
-    // engine cuts the M range finer (Engine._wgrad_splits) so that a late workgroup costs a fraction of a unit, not a round.
-    // The partition into units is fixed by (N, K, splits, M) alone and the slabs are summed in a fixed order: who computes a unit
-    // never changes a bit of the result.
-    unsigned* const queue = grp.queue;
-    const int xcd = blockIdx.x & 7;
-    int c0 = grp.xb[0], c1 = grp.xb[1];
-#pragma unroll
-    for (int x = 1; x < 8; ++x)
-        if (xcd == x) { c0 = grp.xb[x]; c1 = grp.xb[x + 1]; }
-    int* const qlds = (int*)(smem + RING3);
-    unsigned q0;
-    pp_q_fetch(q0, queue + xcd * PP_Q_STRIDE, w == 0);
-    auto leave = [&]() {                                 // last workgroup out zeroes the counters for the next launch
-        if (tid == 0) {
-            const unsigned d = __hip_atomic_fetch_add(queue + 8 * PP_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == gridDim.x - 1)
-                for (int i = 0; i < 9; ++i)
-                    __hip_atomic_store(queue + i * PP_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    int roff[2][2], rswz[2][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int row = 32 * s + 8 * g16 + q4 + 4 * h;
-            roff[s][h] = row * 256 + (p4 & 1) * 8;
-            rswz[s][h] = tn_swz(row);
-        }
-    pp_q_wait(q0);
-    if (tid == 0) qlds[0] = c0 + (int)q0;
-    __syncthreads();
-    int unit = qlds[0];
-    if (unit >= c1) { leave(); return; }                 // whole workgroup, before any other barrier
-  while (true) {
-    // the problem this unit belongs to (wave-uniform: scalar selects, the descriptor stays in SGPRs)
-    const int su = __builtin_amdgcn_readfirstlane(unit);
-    TNArgs g = grp.p[0];
-    int lu = su;
-    if (su >= grp.ubase[1]) { g = grp.p[1]; lu = su - grp.ubase[1]; }
-    if (su >= grp.ubase[2]) { g = grp.p[2]; lu = su - grp.ubase[2]; }
-    if (su >= grp.ubase[3]) { g = grp.p[3]; lu = su - grp.ubase[3]; }
-    const int nbk = g.K >> 8;
-    const int ntile = (g.N >> 8) * nbk;
-    const int z = lu / ntile, tile = lu - z * ntile;
-    const int bn = tile / nbk, bk = tile - bn * nbk;
-    const int mt0 = z * g.tiles_per_split;
-    int mt1 = mt0 + g.tiles_per_split;
-    if (mt1 > g.Mt) mt1 = g.Mt;
-    const int nk = mt1 - mt0;
-    unsigned qn;                                         // lane 0 of wave 0: the next unit, in flight during this one (oldest operation)
-    pp_q_fetch(qn, queue + xcd * PP_Q_STRIDE, w == 0);
-
-    // staging: every wave issues pieces 2w, 2w+1 (4 rows x 256 B each) of every sub-tile
-    const bf16* srcY[2][2];
-    const bf16* srcX[2][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = (2 * w + q) * 4 + (lane >> 4);
-        const int chunk = (lane & 15) ^ tn_swz(row);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            srcY[h][q] = g.dY + (int64_t)(mt0 * 64 + row) * g.lddy + bn * 256 + h * 128 + chunk * 8;
-            srcX[h][q] = g.X + (int64_t)(mt0 * 64 + row) * g.ldx + bk * 256 + h * 128 + chunk * 8;
-        }
-    }
-    const int64_t stepY = 64 * g.lddy, stepX = 64 * g.ldx;
-    auto issue = [&](int which, int t) {        // sub-tile `which` (0 dY0, 1 dY1, 2 X0, 3 X1) of m step t into stage t & 1
-        char* base = smem + (t & 1) * STAGE3 + which * TILE_BYTES + (2 * w) * 1024;
-        if (which < 2) {
-            glds16(srcY[which][0] + t * stepY, base);
-            glds16(srcY[which][1] + t * stepY, base + 1024);
-        } else {
-            glds16(srcX[which - 2][0] + t * stepX, base);
-            glds16(srcX[which - 2][1] + t * stepX, base + 1024);
-        }
-    };
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    if (nk > 0) {
-        issue(0, 0);
-        issue(1, 0);
-        issue(2, 0);
-        issue(3, 0);
-        if (nk > 1) {
-            issue(0, 1);
-            issue(2, 1);
-            issue(3, 1);
-        }
-        bf16x8 yf[4][2], xf[4][2];
-        auto read_y = [&](const char* sy, int blk, bf16x8 (&dst)[2]) {      // dY block blk (16 n) of the group's 128, both m halves
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int cy = 2 * blk + (p4 >> 1);
-                bf16x4 y0 = ds_read_tr16(sy + roff[s][0] + ((cy ^ rswz[s][0]) << 4));
-                bf16x4 y1 = ds_read_tr16(sy + roff[s][1] + ((cy ^ rswz[s][1]) << 4));
-                dst[s] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-        };
-        auto read_x = [&](const char* sx, int blk, bf16x8 (&dst)[2]) {      // X block blk (16 k) of the wave's 64
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int cx = 2 * ((wk & 1) * 4 + blk) + (p4 >> 1);
-                bf16x4 x0 = ds_read_tr16(sx + roff[s][0] + ((cx ^ rswz[s][0]) << 4));
-                bf16x4 x1 = ds_read_tr16(sx + roff[s][1] + ((cx ^ rswz[s][1]) << 4));
-                dst[s] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-        };
-#define TNR_PP_SEG_END()                                            \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    __builtin_amdgcn_s_barrier();                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    __builtin_amdgcn_s_setprio(1)
-#define TNR_PP_MFMA_END()                                           \
-    __builtin_amdgcn_s_setprio(0);                                  \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    __builtin_amdgcn_s_barrier();                                   \
-    __builtin_amdgcn_sched_barrier(0)
-        if (nk > 1) TNR_WAIT_VMCNT(6); else TNR_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();                    // m step 0 is in LDS
-        if (wn == 1) __builtin_amdgcn_s_barrier();       // the stagger: group 1 runs one interval behind
-        for (int t = 0; t < nk; ++t) {
-            const char* sy = smem + (t & 1) * STAGE3 + wn * TILE_BYTES;
-            const char* sx = smem + (t & 1) * STAGE3 + (2 + (wk >> 1)) * TILE_BYTES;
-            const bool more = t + 1 < nk;
-            // ---- phase 0: dY blocks 0-3, X blocks 0-1 ; quadrant (lo, lo)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) read_x(sx, j, xf[j]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) read_y(sy, i, yf[i]);
-            if (more) issue(1, t + 1);                   // dY1(t+1): its buffer's last reader is group 1's phase 2 of step t-1
-            TNR_PP_SEG_END();
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = TNR_MFMA_16x16x32(xf[j][s], yf[i][s], acc[i][j], 0, 0, 0);
-            TNR_PP_MFMA_END();
-            // ---- phase 1: X blocks 2-3 ; quadrant (lo, hi)
-#pragma unroll
-            for (int j = 2; j < 4; ++j) read_x(sx, j, xf[j]);
-            TNR_PP_SEG_END();
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 2; j < 4; ++j) acc[i][j] = TNR_MFMA_16x16x32(xf[j][s], yf[i][s], acc[i][j], 0, 0, 0);
-            TNR_PP_MFMA_END();
-            // ---- phase 2: dY blocks 4-7 ; quadrant (hi, hi)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) read_y(sy, 4 + i, yf[i]);
-            TNR_PP_SEG_END();
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 2; j < 4; ++j) acc[4 + i][j] = TNR_MFMA_16x16x32(xf[j][s], yf[i][s], acc[4 + i][j], 0, 0, 0);
-            TNR_PP_MFMA_END();
-            // ---- phase 3: no reads ; quadrant (hi, lo) ; dY0, X0, X1 of step t+2 (their buffers' last readers are phases 2 / 1 of
-            // this step: both operands stream from HBM, so everything but dY1 goes out two steps ahead); step t+1 must have
-            // landed before the next phase 0
-            if (t + 2 < nk) {
-                issue(0, t + 2);
-                issue(2, t + 2);
-                issue(3, t + 2);
-                TNR_WAIT_VMCNT(6);
-            } else {
-                TNR_WAIT_VMCNT(0);
-            }
-            TNR_PP_SEG_END();
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[4 + i][j] = TNR_MFMA_16x16x32(xf[j][s], yf[i][s], acc[4 + i][j], 0, 0, 0);
-            TNR_PP_MFMA_END();
-        }
-#undef TNR_PP_SEG_END
-#undef TNR_PP_MFMA_END
-        if (wn == 0) __builtin_amdgcn_s_barrier();       // all waves execute the same number of barriers
-    }
-    // the next unit: the answer is older than anything the loop's last wait left in flight (and behind a vmcnt(0) when nk == 0)
-    pp_q_wait(qn);
-    if (tid == 0) qlds[1] = c0 + (int)qn;
-    float* slab = g.ws + (int64_t)z * g.N * g.K;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int n = bn * 256 + wn * 128 + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int k = bk * 256 + wk * 64 + j * 16 + (lane >> 4) * 4;
-            *(f32x4*)(slab + (int64_t)n * g.K + k) = acc[i][j];
-        }
-    }
-    __syncthreads();                                     // qlds[1] visible ; every fragment read of this unit is long complete
-    const int next = qlds[1];
-    if (next >= c1) break;
-    unit = next;
-    __syncthreads();                                     // qlds[1] is rewritten only after everybody has read it
-  }
-    leave();
-}
 
 // wgrad v5 "register-staged": the v4 tile, (split, tile) units, queue and ping-pong of two wave groups, with a different path from
 // memory to the MFMA operands and a different cut of the m step into phases.  Every MFMA gets the operand registers v4 gives it
@@ -1822,24 +1516,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(TNGroup grp) {
 //   WAR  half 0 of step t - 1 (same stage): last read in interval 1 of step t - 1 ... overwritten from interval 1 of step t;
 //        half 1: last read in interval 3 of step t - 1, overwritten from interval 3 of step t.
 constexpr int RS_OP = 2 * TILE_BYTES;        // dY image | X image, 32 KB each per stage
-#ifdef TNR_TN_STAMPS
-// probe build only (make BUILD=../../tools/_tnst EXTRA=-DTNR_TN_STAMPS, tools/tn_stamps.py): every wave records s_memtime at its
-// ARRIVAL at each of the 4 barriers of m steps 32-95 (the stamp rides in front of the barrier, its latency under the barrier wait)
-// into LDS; copied out after the workgroup's first unit: [wg][wave][0..3] = memtime / memrealtime at the unit's start and end,
-// [4] = its m steps, [8 + 4 (t - 32) + k] = arrival at barrier k of step t.  The product library has none of this.
-constexpr int TN_STAMP_WORDS = 264, TN_STAMP_T0 = 32, TN_STAMP_NT = 64, TN_STAMP_NB = 4;     // per wave: 8 header words + 64 steps x 4 barriers
-__device__ unsigned tnr_tn_stamp_buf[256][8][TN_STAMP_WORDS];
-constexpr int RS_LDS = RING3 + 64 + 8 * TN_STAMP_WORDS * 4;
-#define TNR_RS_BARRIER(K)                                                                                      \
-    do {                                                                                                       \
-        unsigned long long ts_;                                                                                \
-        asm volatile("s_memtime %0\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");              \
-        if (lane == 0 && t >= TN_STAMP_T0 && t < TN_STAMP_T0 + TN_STAMP_NT) stamps[w * TN_STAMP_WORDS + 8 + TN_STAMP_NB * (t - TN_STAMP_T0) + (K)] = (unsigned)ts_; \
-    } while (0)
-#else
 constexpr int RS_LDS = RING3 + 64;
 #define TNR_RS_BARRIER(K) __builtin_amdgcn_s_barrier()
-#endif
 __global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1852,10 +1530,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
     for (int x = 1; x < 8; ++x)
         if (xcd == x) { c0 = grp.xb[x]; c1 = grp.xb[x + 1]; }
     int* const qlds = (int*)(smem + RING3);
-#ifdef TNR_TN_STAMPS
-    unsigned* const stamps = (unsigned*)(smem + RING3 + 64);
-    bool stamped = false;
-#endif
     unsigned q0;
     pp_q_fetch(q0, queue + xcd * PP_Q_STRIDE, w == 0);
     auto leave = [&]() {                                 // last workgroup out zeroes the counters for the next launch
@@ -1922,13 +1596,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#ifdef TNR_TN_STAMPS
-    if (lane == 0) {
-        stamps[w * TN_STAMP_WORDS + 0] = (unsigned)__builtin_amdgcn_s_memtime();
-        stamps[w * TN_STAMP_WORDS + 1] = (unsigned)__builtin_amdgcn_s_memrealtime();
-        stamps[w * TN_STAMP_WORDS + 4] = (unsigned)nk;
-    }
-#endif
     if (nk > 0) {
 // end of a load segment: the wave's LDS operations complete BEFORE the barrier (the other group reads this wave's stores of the MFMA
 // segment before, and overwrites what it has just read, right behind barriers; see Hazards)
@@ -1968,14 +1635,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
     }
-#if defined(TNR_TN_STAMPS) && defined(TNR_TN_NOLOADSEG)      /* probe: empty load segments (what do the MFMA segments cost alone?) */
-#define TNR_RS_READS(S) __builtin_amdgcn_sched_barrier(0)
-#else
 #define TNR_RS_READS(S)                                                                                              \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[j] = TNR_LDS(const bf16x8, rax[j] + (j * 2 + (S)) * 1024);      \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) yf[i] = TNR_LDS(const bf16x8, ray[i & 3] + (i * 2 + (S)) * 1024);  \
     __builtin_amdgcn_sched_barrier(0)
-#endif
         bf16x8 yf[8], xf[4];
         unsigned ray[4], rax[4], wa[8];                     // LDS addresses: fragment reads (dY / X, by block & 3), the 8 stores
         const unsigned lds0 = lds_addr_of(smem);
@@ -2008,13 +1671,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // m step 0 is in LDS
         if (wn == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 runs one interval behind
-#if defined(TNR_TN_STAMPS) && defined(TNR_TN_NOLOADSEG)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) yf[i] = TNR_LDS(const bf16x8, ray[i & 3] + (i * 2) * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xf[j] = TNR_LDS(const bf16x8, rax[j] + (j * 2) * 1024);
-#define fetch(T_, H_) ((void)0)
-#endif
         for (int t = 0; t < nk; ++t) {
             TNR_RS_READS(0);
             fetch(t + 1, 1);                                // set B went to LDS in the MFMA segment before
@@ -2028,25 +1684,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_rs_kernel(TNGroup grp) {
             dlt = 0u - dlt;
             TNR_PP_MFMA_END(3);
         }
-#if defined(TNR_TN_STAMPS) && defined(TNR_TN_NOLOADSEG)
-#undef fetch
-#endif
         if (wn == 0) __builtin_amdgcn_s_barrier();          // all waves execute the same number of barriers
 #undef TNR_RS_READS
 #undef TNR_RS_MFMAS
 #undef TNR_PP_SEG_END
 #undef TNR_PP_MFMA_END
     }
-#ifdef TNR_TN_STAMPS
-    if (lane == 0) {
-        stamps[w * TN_STAMP_WORDS + 2] = (unsigned)__builtin_amdgcn_s_memtime();
-        stamps[w * TN_STAMP_WORDS + 3] = (unsigned)__builtin_amdgcn_s_memrealtime();
-    }
-    __syncthreads();
-    if (!stamped && blockIdx.x < 256)
-        for (int i = tid; i < 8 * TN_STAMP_WORDS; i += 512) (&tnr_tn_stamp_buf[blockIdx.x][0][0])[i] = stamps[i];
-    stamped = true;
-#endif
     pp_q_wait(qn);
     if (tid == 0) qlds[1] = c0 + (int)qn;
     float* slab = g.ws + (int64_t)z * g.N * g.K;
@@ -2203,11 +1846,7 @@ static int nt_route(int64_t M, int64_t N, int64_t K, int flags, int n_cu) {
 // ONE table for both builds of this file (bf16 and -DTNR_BUILD_F16): it is defined in the bf16 translation unit and the fp16
 // one calls into it (tnr_pp_queue_of, declared in common.h), so a stream that launches kernels of both builds is bound once and
 // tnr_gemm_queue_reset reaches the counters whichever build's kernel was aborted.
-#ifdef TNR_NT_STAMPS
-constexpr int PP_LDS = LDS3_BYTES + 64 + 8 * 264 * 4;
-#else
 constexpr int PP_LDS = LDS3_BYTES + 64;
-#endif
 [[maybe_unused]] constexpr int PP_QUEUE_SETS = 128;
 #ifdef TNR_BUILD_F16
 static unsigned* pp_queue_of(hipStream_t st, bool reset = false) { return tnr_pp_queue_of(st, reset); }
@@ -2245,15 +1884,6 @@ unsigned* tnr_pp_queue_of(void* stream, bool reset) {
         tnr_set_error("tnr_gemm_nt: could not zero the tile-queue counters");
         return nullptr;
     }
-#ifdef TNR_DEBUG_QUEUE
-    {   // debug builds: the counters must be zero between launches (a launch that died half way leaves them non-zero, and every
-        // later launch on the stream would then skip tiles silently)
-        unsigned host[PP_Q_SET];
-        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(host, set, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
-        for (int i = 0; i < 9; ++i)
-            if (host[i * PP_Q_STRIDE]) { tnr_set_error("tnr_gemm_nt: tile-queue counter %d is %u at launch", i, host[i * PP_Q_STRIDE]); return nullptr; }
-    }
-#endif
     return set;
 }
 #endif
@@ -2321,10 +1951,7 @@ extern "C" int TNR_NAME(tnr_gemm_nt_do)(const void* A, int64_t lda, const void* 
                   "tnr_gemm_nt: TNR_EPI_COLSUM needs a partial buffer, bf16 output and M > 128");
     const TnrGemmOpts& o = *tnr_gemm_opts();
     NTArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, bias,
-             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0, dd, 0, 0, nullptr, 0};
-#ifdef TNR_PROBES
-    g.probe = o.probe;
-#endif
+             (const bf16*)res, ldres, (bf16*)aux, ldaux, flags, colsum_part, o.gm > 0 ? o.gm : 8, o.nt, 0, dd, 0, 0, nullptr, 0, nullptr, 0};
     g.clock = (unsigned long long*)o.clock_buf;
     g.clock_n = o.clock_n;
 #define TNR_PP_ATTR(CF)                                                                                                     \
@@ -2403,7 +2030,6 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
     TNR_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING2);
         (void)hipFuncSetAttribute((const void*)gemm_tn256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
-        (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3 + 64);
         (void)hipFuncSetAttribute((const void*)gemm_tn_rs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
     });
     if (ver == 1 || (N % 256) != 0) {
@@ -2423,8 +2049,7 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_ex)(const void* dY, int64_t lddy, cons
             if (!(grp.queue = pp_queue_of((hipStream_t)stream))) return TNR_EUNSUPPORTED;
             const int n_cu = device_cus();
             dim3 pgrid((unsigned)std::min<int64_t>((int64_t)grid.x, std::max(n_cu, 8)));
-            if (tnr_gemm_opts()->tnpp == 2) hipLaunchKernelGGL(gemm_tn_rs_kernel, pgrid, dim3(512), RS_LDS, (hipStream_t)stream, grp);
-            else hipLaunchKernelGGL(gemm_tn_pp_kernel, pgrid, dim3(512), RING3 + 64, (hipStream_t)stream, grp);
+            hipLaunchKernelGGL(gemm_tn_rs_kernel, pgrid, dim3(512), RS_LDS, (hipStream_t)stream, grp);
         }
         else hipLaunchKernelGGL(gemm_tn256x256_kernel, grid, dim3(512), RING3, (hipStream_t)stream, g);
     }
@@ -2507,30 +2132,18 @@ extern "C" int TNR_NAME(tnr_gemm_tn_wgrad_group)(const tnr_wgrad_problem_t* p, i
     for (int i = n; i <= TN_MAXP; ++i) grp.ubase[i] = (int)units;
     tn_group_ranges(grp, n);
     TNR_ONCE_PER_DEVICE({
-        (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING3 + 64);
         (void)hipFuncSetAttribute((const void*)gemm_tn_rs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
     });
     if (!(grp.queue = pp_queue_of((hipStream_t)stream))) return TNR_EUNSUPPORTED;
     const int n_cu = device_cus();
     const dim3 ggrid((unsigned)std::min<int64_t>(units, std::max(n_cu, 8)));
-    if (tnr_gemm_opts()->tnpp == 2) hipLaunchKernelGGL(gemm_tn_rs_kernel, ggrid, dim3(512), RS_LDS, (hipStream_t)stream, grp);
-    else hipLaunchKernelGGL(gemm_tn_pp_kernel, ggrid, dim3(512), RING3 + 64, (hipStream_t)stream, grp);
+    hipLaunchKernelGGL(gemm_tn_rs_kernel, ggrid, dim3(512), RS_LDS, (hipStream_t)stream, grp);
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad_group");
     hipLaunchKernelGGL(slab_reduce_group_kernel, dim3((unsigned)maxblk, (unsigned)n), dim3(256), 0, (hipStream_t)stream, sg);
     TNR_CHECK_LAUNCH("tnr_gemm_tn_wgrad_group/reduce");
     return TNR_OK;
 }
 
-#ifdef TNR_NT_STAMPS
-extern "C" int TNR_NAME(tnr_debug_nt_stamps)(void* host_dst, int64_t bytes) {
-    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(tnr_nt_stamp_buf), (size_t)bytes) == hipSuccess ? 0 : -1;
-}
-#endif
-#ifdef TNR_TN_STAMPS
-extern "C" int TNR_NAME(tnr_debug_tn_stamps)(void* host_dst, int64_t bytes) {
-    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(tnr_tn_stamp_buf), (size_t)bytes) == hipSuccess ? 0 : -1;
-}
-#endif
 
 extern "C" int TNR_NAME(tnr_gemm_tn_wgrad)(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
                                  int64_t lddw, int64_t M, int64_t N, int64_t K, float* ws, int splits,

@@ -265,9 +265,6 @@ struct SgemmArgs {
 // a step costs about one memory latency OR its MFMA time (32 x 64 cycles), whichever is longer -- with 16-deep steps every
 // step paid a full latency for 8 MFMAs (44 us for the 1760 x 256 x 768 dense layer, 13 us for an M = 1 call).
 constexpr int SG_BK = 64;
-#ifndef TNR_SG_SKIP
-#define TNR_SG_SKIP 0                          // probe builds (tools/scratch/sgemm_probe.py): 1 no MFMAs, 2 no global loads after the first step, 4 no LDS stores / barriers
-#endif
 __device__ __forceinline__ void sgemm_tile(const SgemmArgs& g, int bx, int by, int bz, float (&As)[64][SG_BK + 1], float (&Bs)[64][SG_BK + 1]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     const int zb = bz / g.ksplit, zk = bz - zb * g.ksplit;
@@ -306,12 +303,11 @@ __device__ __forceinline__ void sgemm_tile(const SgemmArgs& g, int bx, int by, i
             Bs[rb][kb] = bv[q];
         }
         __syncthreads();
-        if (k0 + SG_BK < kend && !(TNR_SG_SKIP & 2)) fetch(k0 + SG_BK);    // next step's global loads fly under the MFMAs
+        if (k0 + SG_BK < kend) fetch(k0 + SG_BK);    // next step's global loads fly under the MFMAs
         const int kk_end = kend - k0 < SG_BK ? kend - k0 : SG_BK;
         for (int kk = 0; kk < kk_end; kk += 2) {      // fixed order: an fp32 fma chain over k (zero padding beyond kend)
             float a = As[wm * 32 + (lane & 31)][kk + (lane >> 5)];
             float b = Bs[wn * 32 + (lane & 31)][kk + (lane >> 5)];
-            if (TNR_SG_SKIP & 1) { acc[0] += a * b; continue; }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
@@ -574,9 +570,6 @@ __global__ __launch_bounds__(256) void user_score_fwd_kernel(
 // across the impressions): lane (j, h) of a 32 x 32 (slot, unit) block takes k = 8 t + 4 h .. + 3 of both operands with one
 // 16-byte access each and feeds four MFMAs - a fixed permutation of the fp32 sum over k.  fc1 of a masked slot is fc1 of the
 // blended row (= fc1(pad_doc) for a 0 / 1 mask, model_bert.py:162-164), so there is no separate pad path.
-#ifndef TNR_UF_SKIP
-#define TNR_UF_SKIP 0                          // probe builds: 1 no fc1 MFMA loop, 2 no tanh / e store, 4 no gather of the history rows
-#endif
 constexpr int UF_XTRA = 4;                     // LDS row pitch D + 4 floats: 16-byte aligned rows, banks shifted by 4 per row
 constexpr int UF_THREADS = 1024;               // four waves per SIMD: the 14 (slot block, unit block) pairs of U = 50, Q = 200 in ONE round of
                                                // 16 waves (512 threads: two rounds of 8; 42 -> 37 us), a wave's W1 loads under the others' MFMAs
@@ -604,7 +597,7 @@ __global__ __launch_bounds__(UF_THREADS) void user_fwd_fused_kernel(
     for (int t = tid; t < 64 * (D / 4); t += UF_THREADS) {
         const int u = t / (D / 4), c = (t - u * (D / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (u < U && !(TNR_UF_SKIP & 4)) {
+        if (u < U) {
             v = *(const f32x4*)(vec + (int64_t)hidx[u] * D + c);
             if (!user_log_mask) {
                 const float m = mask[u];
@@ -633,7 +626,6 @@ __global__ __launch_bounds__(UF_THREADS) void user_fwd_fused_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) bn[g] = *(const f32x4*)(bp + 8 * g);
         }
-        if (TNR_UF_SKIP & 1) t = D;
         for (; t + 32 <= D; t += 32) {
             f32x4 a4[4], b4[4];
 #pragma unroll
@@ -656,7 +648,7 @@ __global__ __launch_bounds__(UF_THREADS) void user_fwd_fused_kernel(
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m], b4[m], acc, 0, 0, 0);
         }
-        if (q < Q && !(TNR_UF_SKIP & 2)) {
+        if (q < Q) {
             const float bq = b1[q];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

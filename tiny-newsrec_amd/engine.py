@@ -1045,9 +1045,17 @@ class Engine:
         return l[0] + self.cfg.coef * l[1] + l[2]
 
     # ------------------------------------------------------------------ backward
+    def _red_check(self):
+        """The batched reductions replay a recorded job table that carries 1 / (loss scale) in its descriptors: when the dynamic
+        scale has moved since they were recorded (an fp16 overflow, a growth step) they are recorded afresh."""
+        if getattr(self, "_red_ginv", None) != self.ginv:
+            self.red.clear()
+            self._red_ginv = self.ginv
+
     def backward(self, after_bucket=None):
         """d total_loss / d trainable parameters -> self.flat_g.  after_bucket(i) is called when gradient
         bucket i (0 = heads, then one per layer from the top) is complete (dist.py overlaps its all-reduce)."""
+        self._red_check()
         cfg = self.cfg
         B, N, Rt = self.cur
         U, C, D, T_ = cfg.U, cfg.C, cfg.D, cfg.T
@@ -1127,6 +1135,7 @@ class Engine:
         trainable layer (and, split_ffn, after its FFN block: the point a gradient bucket completes) - so that a caller running
         two passes over the same parameters in step can launch both passes' contributions to a weight as ONE chained problem."""
         cfg = self.cfg
+        self._red_check()
         self._wg_defer = [] if defer else None
         L, D, H, I = cfg.L, cfg.D, cfg.H, cfg.I
         M = N * L

@@ -13,6 +13,12 @@ One model, two sequence lengths: two Engine instances share parameters / gradien
 weight copies and own their workspaces.  Their backwards run in step, layer by layer: the bias / LayerNorm sums of the title pass
 are written and those of the body pass added; every weight gradient is ONE chained problem over the title rows and the body rows
 (tnr_gemm_tn_wgrad_group, accumulate = 2).
+Round 6 - JOINT passes (`Stage1Engine.joint`, the default without dropout): a Linear, a LayerNorm and a weight gradient act on token
+rows one by one, so the body pass's rows are laid directly BEHIND the title pass's in every per-token buffer and each of them is
+ONE launch over M = N Lt + B Lb rows instead of one per pass (8 896 rows at 30 / 128, 24 064 at 24 / 512: tile orders large enough
+for the persistent 256-wide kernels); only what depends on the sequence length - embeddings, attention, pooling - still runs per
+pass, on its row range, the body's on a second stream beside the title's.  Every row goes through the same K order as in its own
+launch: scores and losses are bit-identical to the two-launch form; parameter gradients are the same sums in another order.
 Student rows live in one table S = [B*(1+K) title rows | B body rows], the layout tnr_kd_embed_loss and
 tnr_score_bwd already use in stage 2 with the body vector in the "user" slot.
 
@@ -25,7 +31,7 @@ csrc/dropout.h; the title and the body pass draw independent masks, as two passe
 import torch
 
 import tnr_hip as T
-from engine import Engine, EngineConfig, _ReduceBatch
+from engine import BERT, PFX, QPAD, Engine, EngineConfig, _ReduceBatch, layer_param_order
 
 
 class Stage1Engine:
@@ -37,7 +43,8 @@ class Stage1Engine:
                       temperature=1.0, coef=1.0, stage1=True, **dims)
         self.cfg_t = EngineConfig(npratio=npratio, num_words=title_len, **common)
         self.cfg_b = EngineConfig(npratio=0, num_words=body_len, **common)
-        self.title = Engine(self.cfg_t, device, max_batch=batch, dtype=dtype)
+        # the title engine's per-token / per-sequence workspaces have room for the body pass's rows / sequences behind its own (joint passes)
+        self.title = Engine(self.cfg_t, device, max_batch=batch, dtype=dtype, extra_rows=batch * body_len, extra_seqs=batch)
         self.body = Engine(self.cfg_b, device, max_batch=batch, dtype=dtype, share=self.title)
         self.dev = self.title.dev
         self.ws = None               # slabs of the chained weight gradients (allocated by the first backward)
@@ -72,22 +79,28 @@ class Stage1Engine:
         B = idx.shape[0]
         C, D, T_ = cfg.C, cfg.D, cfg.T
         assert idx.shape[1] == C
-        t._prepare(B)
-        b._prepare(B)
+        self._prepare(B)
         N, Rt = B * C, B * C + B
         self.cur = (B, N, Rt)
         t.label = label.to(torch.int64).contiguous()
         tidx = idx.reshape(-1).to(torch.int32).contiguous()
         bidx = idx[:, 0].to(torch.int32).contiguous() if body_idx is None else body_idx
-        def title_pass():
+        def teacher_side():
             # the teacher side (row gathers, teacher scores, projections) needs nothing of the student's: in front of the title pass,
             # where it runs beside the start of the body pass instead of alone between the encoders and the losses
             if T_:
                 T.call("tnr_gather_rows", t_title_tables, t_title_tables.shape[1], tidx, N, D, T_, t.X, t.X.shape[1], 0)
                 T.call("tnr_gather_rows", t_body_tables, t_body_tables.shape[1], bidx, B, D, T_, t.X, t.X.shape[1], N)
                 self._teacher_side(B, N, Rt)
+
+        def title_pass():
+            teacher_side()
             t.encode(title_table, N, nidx=tidx)
-        self._encode_both(lambda: b.encode(body_table, B, nidx=bidx, out=t.S[N:]), title_pass)
+        self.ran_joint = self._joint_ok()
+        if self.ran_joint:
+            self._encode_joint(B, N, title_table, tidx, body_table, bidx, teacher_side)
+        else:
+            self._encode_both(lambda: b.encode(body_table, B, nidx=bidx, out=t.S[N:]), title_pass)
         return self._heads(B, N, Rt)
 
     def forward(self, title, body, label, teacher_titles, teacher_bodies):
@@ -98,8 +111,7 @@ class Stage1Engine:
         B = title.shape[0]
         C, D, T_ = cfg.C, cfg.D, cfg.T
         assert title.shape[1:] == (C, 2 * cfg.L) and body.shape == (B, 2 * self.cfg_b.L)
-        t._prepare(B)
-        b._prepare(B)
+        self._prepare(B)
         N, Rt = B * C, B * C + B
         self.cur = (B, N, Rt)
         t.label = label.to(torch.int64).contiguous()
@@ -109,17 +121,190 @@ class Stage1Engine:
             t.X[i, :N].copy_(teacher_titles[i].reshape(N, D))
             t.X[i, N:Rt].copy_(teacher_bodies[i].reshape(B, D))
 
-        def title_pass():
+        def teacher_side():
             if T_:
                 self._teacher_side(B, N, Rt)
+
+        def title_pass():
+            teacher_side()
             t.encode(t.tok[:N], N)
-        self._encode_both(lambda: b.encode(b.tok[:B], B, out=t.S[N:]), title_pass)    # cell 12 encodes the bodies first
+        self.ran_joint = self._joint_ok()
+        if self.ran_joint:
+            self._encode_joint(B, N, t.tok[:N], None, b.tok[:B], None, teacher_side)
+        else:
+            self._encode_both(lambda: b.encode(b.tok[:B], B, out=t.S[N:]), title_pass)    # cell 12 encodes the bodies first
         return self._heads(B, N, Rt)
 
     # The body pass on a second stream beside the title pass: most launches of either pass are partial rounds (4 800 / 4 096 token
     # rows at 30 / 128: 228 / 192 tiles for 256 CUs), side by side they fill the chip.  The same kernels on the same operands:
     # bit-identical to one stream (test_stage1_chained_weight_gradients_equal_the_two_pass_form); 2.46 -> 2.14 ms per step.
     two_streams = True
+
+    def _prepare(self, B):
+        t, b = self.title, self.body
+        if B != t.B_alloc:                       # a short last batch: the body rows sit directly behind THIS batch's title rows
+            t.extra_rows, t.extra_seqs = B * self.cfg_b.L, B
+        t._prepare(B)
+        b._prepare(B)
+
+    # ------------------------------------------------------------------ joint passes (round 6)
+    joint = True            # False: one launch per pass for everything (the round-5 form; tools/ A/B, tests)
+    joint_streams = True    # the body's per-pass kernels (embeddings, attention, pooling) on the second stream beside the title's
+
+    def _joint_ok(self):
+        t, b = self.title, self.body
+        return bool(self.joint and t.drop is None and b.drop is None and self.cfg_t.pooling == "att" and self.dev.type == "cuda"
+                    and getattr(t, "fcache", None) is None and t.group_wgrad is False)
+
+    def _both(self, body_fn, title_fn):
+        """The two passes' own kernels of one stage of the joint passes: side by side on two streams, joined behind."""
+        if not self.joint_streams:
+            body_fn()
+            title_fn()
+            return
+        main, side = torch.cuda.current_stream(self.dev), self._side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            body_fn()
+        title_fn()
+        main.wait_stream(side)
+
+    def _encode_joint(self, B, N, title_tok, tidx, body_tok, bidx, teacher_side):
+        """Engine.encode for both passes at once (model_bert.py:119-137 twice): token rows [0, N Lt) are the titles', [N Lt, N Lt +
+        B Lb) the bodies'; news vectors -> S[:N] (titles), S[N:N + B] (bodies)."""
+        t, b = self.title, self.body
+        cfg = self.cfg_t
+        H, D = cfg.H, cfg.D
+        Mt = N * cfg.L
+        M = Mt + B * self.cfg_b.L
+        assert M <= t.Mp and N + B <= t.nv.shape[0]
+        g = t.p
+        for e in (t, b):
+            if e._rel_stale:
+                e.refresh_rel()
+            e.drop_cur = None
+        rows = lambda buf: buf[Mt:M]              # the body pass's rows of a per-token buffer
+        self._both(lambda: b._embed_fwd(body_tok, B, bidx, rows(t.x0)),
+                   lambda: (teacher_side(), t._embed_fwd(title_tok, N, tidx, t.x0)))
+        x = t.x0
+        t.x_in = {}
+        for l in range(cfg.n_layers):
+            names, sh = layer_param_order(l), t.sh[l]
+            kept = l >= t.lo
+            a = t.act[l - t.lo] if kept else t.scr
+            y = a["y"] if kept else t.scr_y[l & 1]
+            lse_b = b.act[l - b.lo]["lse"] if kept else b.lse
+            t.x_in[l] = x
+            t._gemm(x, sh["qkv"], a["qkv"], M, bias=t._view(names[3], 3 * H, (3 * H,)), flags=T.EPI_BIAS)
+            self._both(lambda: b._attn_fwd(rows(a["qkv"]), rows(a["ctx"]), lse_b, B, None),
+                       lambda: t._attn_fwd(a["qkv"], a["ctx"], a["lse"] if kept else t.lse, N, None))
+            t._gemm(a["ctx"], sh["o"], a["h1pre"], M, bias=g(names[7]), res=x, flags=T.EPI_BIAS | T.EPI_RES)
+            t._c("tnr_ln_fwd", a["h1pre"], g(names[8]), g(names[9]), cfg.ln_eps, a["h1"], a["st1"], M, H)
+            t._gemm(a["h1"], sh["w1"], a["g"], M, bias=g(names[11]), aux=a["u"] if kept else None,
+                    flags=T.EPI_BIAS | T.EPI_GELU | (T.EPI_AUXOUT if kept else 0))
+            t._gemm(a["g"], sh["w2"], a["ypre"], M, bias=g(names[13]), res=a["h1"], flags=T.EPI_BIAS | T.EPI_RES)
+            t._c("tnr_ln_fwd", a["ypre"], g(names[14]), g(names[15]), cfg.ln_eps, y, a["st2"], M, H)
+            x = y
+        t.y_last = x
+        t._gemm(x, t.sh_a1, t.e, M, bias=t.b_a1, flags=T.EPI_BIAS | T.EPI_TANH | T.EPI_OUTF32)
+        self._both(lambda: b._attpool_fwd(rows(x), rows(t.e), t.nv[N:N + B], B),
+                   lambda: t._attpool_fwd(x, t.e, t.nv, N))
+        t._sgemm(t.nv, H, 1, 0, g(PFX + "dense.weight"), H, 1, 0, t.S, D, 0, g(PFX + "dense.bias"), 0, N + B, D, H)
+
+    def _backward_joint(self, dS, B, N, after_bucket, pend, rb_heads, one):
+        """Engine.backward_encoder_steps for both passes at once: dS[:N + B] = d loss / d news vectors, titles then bodies."""
+        t, b = self.title, self.body
+        cfg = self.cfg_t
+        D, H, I = cfg.D, cfg.H, cfg.I
+        Ns = N + B
+        Mt = N * cfg.L
+        Mb = B * self.cfg_b.L
+        M = Mt + Mb
+        g, gr, gi = t.p, t.grads, t.ginv
+        t._wg = t._wg_defer = None
+        rows = lambda buf: buf[Mt:M]
+        seqs = lambda buf: buf[N:Ns]
+        rb = rb_heads
+        dvec = dS[:Ns]
+        t._sgemm_group(list(pend or []) + [
+            t._sgemm_problem(dvec, 1, D, 0, t.nv, 1, H, 0, gr[PFX + "dense.weight"], H, 0, None, 0, D, H, Ns, ksplit=t.KS),
+            t._sgemm_problem(dvec, D, 1, 0, g(PFX + "dense.weight"), 1, H, 0, t.dnv, H, 0, None, 0, Ns, H, D, alpha=t.gscale)])
+        rb.add(dvec, Ns, D, D, gr[PFX + "dense.bias"])
+        y = t.y_last
+        self._both(lambda: b._attpool_bwd(rows(y), rows(t.e), seqs(t.dnv), rows(t.dy2), rows(t.dpre), seqs(t.dw2p), seqs(t.db2p),
+                                          seqs(t.db1p), B),
+                   lambda: t._attpool_bwd(y, t.e, t.dnv, t.dy2, t.dpre, t.dw2p, t.db2p, t.db1p, N))
+        rb.add(t.dw2p, Ns, cfg.Qn, cfg.Qn, gr[PFX + "attn.att_fc2.weight"], 0, gi)
+        rb.add(t.db2p, Ns, 1, 1, gr[PFX + "attn.att_fc2.bias"], 0, gi)
+        rb.add(t.db1p, Ns, QPAD, QPAD, t._view(PFX + "attn.att_fc1.bias", QPAD, (QPAD,), grad=True), 0, gi)
+        if not one or not cfg.trainable_layers:
+            rb.flush()
+        t._wgrad(t.dpre, y, t._view(PFX + "attn.att_fc1.weight", QPAD * H, (QPAD, H), grad=True), M)
+        if after_bucket:
+            after_bucket(0)
+        if not cfg.trainable_layers:
+            return
+        t._gemm(t.dpre, t.sh_a1T, t.dy, M, res=t.dy2, flags=T.EPI_RES)
+        dy = t.dy
+        bucket = 1
+        nblk = T.query("tnr_ln_bwd_blocks", M)
+        # q / k / v bias: the short-sequence attention backward leaves one partial row per sequence, the long one none (its dqkv
+        # columns are summed into ONE row): both passes' partial rows in one buffer, one reduction job
+        nt_rows, nb_rows = (N if cfg.L <= 32 else 1), (B if self.cfg_b.L <= 32 else 1)
+        for l in range(cfg.n_layers - 1, t.lo - 1, -1):
+            names, sh, a = layer_param_order(l), t.sh[l], t.act[l - t.lo]
+            tr = l in cfg.trainable_layers
+            x_in = t.x_in[l]
+            rba = (rb_heads if one else t.red.setdefault((l, "joint", Ns, "att"), _ReduceBatch(t.dev))) if tr else None
+            rb = (rb_heads if one else t.red.setdefault((l, "joint", Ns, "ffn"), _ReduceBatch(t.dev))) if tr else None
+            P = t.lpart.get(l)
+            t._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), t.dypre, None, None, None, (P["ln_part"] if tr else None), M, H)
+            if tr:
+                rb.add(P["ln_part"], nblk, 3 * H, 2 * H, t._view(names[14], 2 * H, (2 * H,), grad=True), 0, gi)
+                rb.add(P["ln_part"][2 * H:], nblk, 3 * H, H, gr[names[13]], 0, gi)
+                t._wgrad(t.dypre, a["g"], gr[names[12]], M)
+            t._gemm(t.dypre, sh["w2T"], t.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if tr else 0),
+                    colsum=P["gcs_part"] if tr else None)
+            if tr:
+                rb.add(P["gcs_part"], t._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], 0, gi)
+                t._wgrad(t.du, a["h1"], gr[names[10]], M)
+                if not one:
+                    rb.flush()
+                if after_bucket:
+                    after_bucket(bucket)
+                    bucket += 1
+            t._gemm(t.du, sh["w1T"], t.dh1, M, res=t.dypre, flags=T.EPI_RES)
+            t._c("tnr_ln_bwd", t.dh1, a["h1pre"], a["st1"], g(names[8]), t.dh1pre, None, None, None, (P["ln_part1"] if tr else None), M, H)
+            if tr:
+                rba.add(P["ln_part1"], nblk, 3 * H, 2 * H, t._view(names[8], 2 * H, (2 * H,), grad=True), 0, gi)
+                rba.add(P["ln_part1"][2 * H:], nblk, 3 * H, H, gr[names[7]], 0, gi)
+                t._wgrad(t.dh1pre, a["ctx"], gr[names[6]], M)
+            t._gemm(t.dh1pre, sh["oT"], t.dctx, M)
+            qp = P["qkvb_part"] if tr else None
+
+            def body_attn():
+                if not b._attn_bwd(rows(a["qkv"]), rows(a["ctx"]), b.act[l - b.lo]["lse"], rows(t.dctx), rows(t.dqkv),
+                                   qp[nt_rows:] if tr else None, B, None) and tr:
+                    b._c("tnr_colsum", rows(t.dqkv), 3 * H, T.BF16, Mb, 3 * H, qp[nt_rows], b.cs_part, 0)
+
+            def title_attn():
+                if not t._attn_bwd(a["qkv"], a["ctx"], a["lse"], t.dctx, t.dqkv, qp, N, None) and tr:
+                    t._c("tnr_colsum", t.dqkv, 3 * H, T.BF16, Mt, 3 * H, qp[0], t.cs_part, 0)
+            self._both(body_attn, title_attn)
+            if tr:
+                rba.add(qp, nt_rows + nb_rows, 3 * H, 3 * H, t._view(names[3], 3 * H, (3 * H,), grad=True), 0, gi)
+                t._wgrad(t.dqkv, x_in, t._view(names[0], 3 * H * H, (3 * H, H), grad=True), M)
+                if not one:
+                    rba.flush()
+            if l > t.lo:
+                nxt = t.dy2 if dy is t.dy else t.dy
+                t._gemm(t.dqkv, sh["qkvT"], nxt, M, res=t.dh1pre, flags=T.EPI_RES)
+                dy = nxt
+            if tr and after_bucket:
+                after_bucket(bucket)
+                bucket += 1
+        if one:
+            rb_heads.flush()
 
     def _encode_both(self, body_pass, title_pass):
         if not self.two_streams or self.dev.type != "cuda":
@@ -185,12 +370,22 @@ class Stage1Engine:
         """Gradients of total_loss -> the shared flat_g.  Buckets complete (and after_bucket fires) during the body
         pass, the second and accumulating one."""
         t, b = self.title, self.body
+        t._red_check()
+        b._red_check()
         B, N, Rt = self.cur
         C, D = self.cfg_t.C, self.cfg_t.D
         S, dS = t.S[:Rt], t.dS
         # the title pass's heads batch (backward_encoder's key): merged into one reduction at its end unless it flushes by bucket
-        one_t = t.merge_reductions and not (self.chain_wgrad and after_bucket is not None)
         pend = []                 # the transform matrices' gradient GEMM rides in the title pass's first grouped launch
+        if self.ran_joint:
+            one = after_bucket is None and t.merge_reductions
+            rbh = t.red.setdefault(("heads", "joint", N + B, one), _ReduceBatch(t.dev))
+            if self.cfg_t.T:
+                t._transform_grads(Rt, rbh, pend)
+            T.call("tnr_score_bwd", S, t.cidx, S[N:], t.dscore, dS, dS[N:], B, C, D)
+            self._backward_joint(dS, B, N, after_bucket, pend, rbh, one)
+            return
+        one_t = t.merge_reductions and not (self.chain_wgrad and after_bucket is not None)
         if self.cfg_t.T:
             t._transform_grads(Rt, t.red.setdefault(("heads", 0, N, one_t), _ReduceBatch(t.dev)), pend)
         T.call("tnr_score_bwd", S, t.cidx, S[N:], t.dscore, dS, dS[N:], B, C, D)
