@@ -363,7 +363,7 @@ def main():
             nd = 20000
             s1 = Stage1Engine(n_layers=2, trainable_layers=(0, 1), num_teachers=4, npratio=Kn, title_len=Lt, body_len=Lb, device=dev,
                               batch=B, dtype="fp16")
-            for knob in ("chain_wgrad", "two_streams", "joint", "joint_streams"):              # A/B switches of tools/ only (defaults = the class's)
+            for knob in ("chain_wgrad", "two_streams", "joint", "joint_streams", "joint_group_wgrad"):              # A/B switches of tools/ only (defaults = the class's)
                 if os.environ.get("TNR_S1_" + knob.upper()) is not None:
                     setattr(s1, knob, os.environ["TNR_S1_" + knob.upper()] == "1")
             s1.load_state_dict({k: torch.from_numpy(hashinit.init_tensor(seed, k, tuple(sh))) for k, sh in s1.shapes.items()})
@@ -463,11 +463,25 @@ def main():
                 cands.append({"wgrad_units": units, "buckets": nb, "ms_per_step": round(1e3 * d_ / K, 4)})
                 del e_, g_
                 torch.cuda.empty_cache()
-        K, W = K_, W_
         best = min(cands, key=lambda c: c["ms_per_step"])
+        # ... and, with that pair, the persistent GEMM grids sized for 248 / 240 of the CUs: when RCCL's kernels wait for a CU
+        # behind a persistent launch that holds every CU's whole register file, leaving them a few CUs can be the cheaper step
+        if not any(kv.startswith("cus=") for kv in a.gemm_opt):
+            for n_cu in (248, 240):
+                E.Engine.WGRAD_UNITS, a.dp_buckets = best["wgrad_units"], best["buckets"]
+                T.lib().tnr_gemm_set_option(b"cus", n_cu)
+                e_, g_ = build(a.dtype)
+                d_ = timed_loop(e_, g_, False)
+                cands.append({"wgrad_units": best["wgrad_units"], "buckets": best["buckets"], "cus": n_cu, "ms_per_step": round(1e3 * d_ / K, 4)})
+                del e_, g_
+                torch.cuda.empty_cache()
+            best = min(cands, key=lambda c: c["ms_per_step"])
+            T.lib().tnr_gemm_set_option(b"cus", best.get("cus", 0))
+        K, W = K_, W_
         wgrad_units, a.dp_buckets = best["wgrad_units"], best["buckets"]
         E.Engine.WGRAD_UNITS = wgrad_units
-        autotune = {"candidates": cands, "chosen": best, "note": "3 + 10 untimed steps per candidate before the headline's warm-up; max over ranks"}
+        autotune = {"candidates": cands, "chosen": best, "note": "3 + 10 untimed steps per candidate before the headline's warm-up; max over ranks; "
+                                                                 "cus = CUs the persistent GEMM grids are sized for (absent: all)"}
     eng, gs = build(a.dtype)
     dt_dedup = dt_cache = None
     if a.dedup == "also":
@@ -557,6 +571,7 @@ def main():
         dp_info = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                    "fp16_tail_ms_per_step": tail,
                    "rccl_version": rccl, "algo": gs.algo, "wgrad_units_per_workgroup": wgrad_units, "buckets": a.dp_buckets,
+                   "cus_for_persistent_gemms": (autotune or {}).get("chosen", {}).get("cus", 0) or "all",
                    "autotune": autotune,
                    "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                           "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY")},
@@ -567,6 +582,22 @@ def main():
                    "note": "all-reduce(sum) of fp32 gradients, 1/world folded into AMSGrad; every bucket but the last is launched "
                            "while backward still runs"}
     loss = float(eng.total_loss().item())
+    if use_dp and world == 1 and not any(kv.startswith("cus=") for kv in a.gemm_opt):
+        # world-1 preflight for the first multi-GPU lease: what it costs THIS step to size the persistent GEMM grids for 248 / 240
+        # of the 256 CUs (the CUs RCCL's kernels would get), 5 + 30 steps each, interleaved with the full-chip setting
+        K_, W_ = K, W
+        K, W = min(30, K_), min(5, W_)
+        ms_cu = {}
+        for n_cu in (0, 248, 240, 0):
+            T.lib().tnr_gemm_set_option(b"cus", n_cu)
+            ms_cu.setdefault(n_cu or 256, []).append(1e3 * timed_loop(eng, gs, False) / K)
+        T.lib().tnr_gemm_set_option(b"cus", 0)
+        K, W = K_, W_
+        base = sum(ms_cu[256]) / len(ms_cu[256])
+        dp_info["cus_reserved_cost_ms"] = {"all_256": round(base, 4), "248": round(ms_cu[248][0] - base, 4), "240": round(ms_cu[240][0] - base, 4),
+                                           "note": "ms per step added by sizing the persistent GEMM grids (tnr_gemm_set_option \"cus\") for fewer CUs at "
+                                                   "world size 1, 5 + 30 steps each; with more than one rank the warm-up autotune weighs the same setting "
+                                                   "against what the collectives gain (dp.autotune)"}
     if use_dp and a.dp_sweep:
         # the knobs the first multi-GPU run should weigh, each as its own 5 + 30 steps (max over ranks), headline configuration first
         sweep = []

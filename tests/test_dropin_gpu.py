@@ -120,11 +120,14 @@ def test_bench_two_ranks_over_gloo_match_one_rank_on_the_concatenated_batch(tmp_
         outs[tag] = (d, np.load(dump))
     dp = outs["two"][0]["dp"]
     assert dp["backend"] == "gloo" and dp["algo"] == "allreduce"
-    # the warm-up autotune timed {2, 1 wgrad units} x {5, 3 buckets} and the headline ran with the fastest (the same on both ranks)
+    # the warm-up autotune timed {2, 1 wgrad units} x {5, 3 buckets}, then the best pair with the persistent GEMM grids sized for 248 /
+    # 240 CUs (round 6), and the headline ran with the fastest (the same on both ranks)
     at = dp["autotune"]
-    assert len(at["candidates"]) == 4 and all(c["ms_per_step"] > 0 for c in at["candidates"])
+    assert len(at["candidates"]) == 6 and all(c["ms_per_step"] > 0 for c in at["candidates"])
+    assert sorted(c.get("cus", 0) for c in at["candidates"]) == [0, 0, 0, 0, 240, 248]
     assert at["chosen"] == min(at["candidates"], key=lambda c: c["ms_per_step"])
     assert (dp["wgrad_units_per_workgroup"], dp["buckets"]) == (at["chosen"]["wgrad_units"], at["chosen"]["buckets"])
+    assert dp["cus_for_persistent_gemms"] == (at["chosen"].get("cus") or "all")
     assert len(dp["exposed_allreduce_ms_per_step_by_collective_rank0"]) == dp["buckets"] and dp["exposed_allreduce_ms_per_step_max_over_ranks"] > 0
     assert dp["fp16_tail_ms_per_step"]["amsgrad"] > 0 and dp["fp16_tail_ms_per_step"]["scans"] > 0
     sw = dp["sweep"]
@@ -386,6 +389,36 @@ def _tok_cfg_args(tmp_path):
     return ["--tokenizer_name", str(tmp_path / "vocab.txt"), "--config_name", str(tmp_path / "config.json"), "--model_name",
             str(tmp_path / "none.bin"), "--allow_random_init", "True", "--num_words_title", "30", "--news_dim", "256", "--user_log_mask", "False",
             "--model", "NAML", "--model_type", "tnlrv3"]
+
+
+def test_reference_feed_from_the_producer_thread_equals_the_host_tensors():
+    """DataLoaderTrain(resident=False) = the reference's 6-tuple (dataloader.py:151-172).  From the producer thread its tensors
+    leave as one pinned staging buffer + one asynchronous copy on the producer's stream (round 6) instead of 4 + 2 T pageable
+    `.cuda()` copies: every batch of an epoch - dtypes, shapes, values, the short last batch - equals the CPU loader's on the same
+    files and the same label draws."""
+    import random
+    import types as _types
+    import dataloader
+    import hashinit
+    z = np.load(os.path.join(GOLDEN, "datapath.npz"))
+    news_index = {str(k): int(v) for k, v in zip(z["news_ids"], z["news_index"])}
+    comb = z["news_combined"]
+    temb = [hashinit.hash_normal(11, "dp_temb%d" % i, (comb.shape[0], 8)) for i in range(2)]
+    args = _types.SimpleNamespace(npratio=4, user_log_length=50, batch_size=5, shuffle_buffer_size=7, num_teachers=2)
+    mk = lambda gpu: dataloader.DataLoaderTrain(os.path.join(GOLDEN, "data"), "behaviors_np4_*.tsv", args, 1, 0, 0, news_index, comb, temb,
+                                                enable_prefetch=True, enable_shuffle=False, enable_gpu=gpu, resident=False)
+    random.seed(5)
+    host = [b for b in mk(False)]
+    random.seed(5)
+    dev = [b for b in mk(True)]
+    assert len(host) == len(dev) == 3 and isinstance(dev[0], dataloader.RowBatch)
+    torch.cuda.synchronize()
+    for hb, db in zip(host, dev):
+        flat_h = list(hb[:4]) + list(hb[4]) + list(hb[5])
+        flat_d = list(db[:4]) + list(db[4]) + list(db[5])
+        assert len(flat_h) == len(flat_d) == 8
+        for a, b in zip(flat_h, flat_d):
+            assert b.is_cuda and a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b.cpu())
 
 
 @pytest.mark.parametrize("teachers", [0, 2])

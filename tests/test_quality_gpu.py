@@ -13,7 +13,9 @@ can exist here.
        top-1 agreement), news / user vectors within 1e-3 max(1, |ref|);
   (ii) the engine TRAINED in 16 bits from the same init on the same batches through the drop-in surface (model_bert.Model,
        TnrAdam, DataLoaderTrain: the loop of run.py), evaluated by its own `run.test`: metrics within a bound of 1.5 x the
-       measured gap, the gap printed."""
+       measured gap, the gap printed - beside two yardsticks: what two FP32 implementations of the same run end apart
+       (profiles/r06_quality_noise_floor.json: 0.02 pt - in fp32 this 400-step run IS reproducible) and how far the engine's own
+       metrics move over its last 60 steps (the model is still learning fast at step 400: loss 2.06 -> 0.88)."""
 import json
 import os
 import random
@@ -145,7 +147,10 @@ def test_engine_trained_from_the_same_init_reaches_the_reference_quality(tmp_pat
     random.seed(seed)
     lines = [str(l).encode() for l in z["train_lines"]]
     losses = np.zeros((steps, 4))
+    snaps = {}
     for step in range(steps):                                         # Tiny-NewsRec/run.py:175-195
+        if step in (steps - 60, steps - 40, steps - 20):
+            snaps[step] = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
         log_ids, log_mask, input_ids, targets, th, tc = loader._process(lines[step * B:(step + 1) * B])
         assert (targets.cpu().numpy() == z["labels"][step]).all()     # bit-exact index work: the label draws of the reference's loader
         total, distill, emb, target, y_student = model(log_ids, log_mask, input_ids, targets, th, tc)
@@ -161,8 +166,12 @@ def test_engine_trained_from_the_same_init_reaches_the_reference_quality(tmp_pat
     del model, optimizer, loader
     torch.cuda.empty_cache()
     got, per, n_metric = _evaluate(z, trained, comb, news_index, tmp_path, monkeypatch, dtype)
+    along = {st: _evaluate(z, sd, comb, news_index, tmp_path, monkeypatch, dtype)[0] for st, sd in sorted(snaps.items())}
+    along[steps] = got
     ref = z["metrics"]
     gap = got - ref
+    print("\n[quality ii %s] the engine's own metrics along its last 60 steps: " % dtype +
+          "  ".join("step %d: AUC %.4f nDCG@10 %.4f" % (st, m[0], m[3]) for st, m in sorted(along.items())))
     lerr = np.abs(losses - z["losses"])
     w = 20
     run_mean = lambda x: np.convolve(x, np.ones(w) / w, mode="valid")
@@ -178,13 +187,16 @@ def test_engine_trained_from_the_same_init_reaches_the_reference_quality(tmp_pat
                 "DataLoaderTrain), evaluated by run.test, against the reference's own trained + evaluated run" % steps,
         "reference": dict(zip(NAMES, [float(x) for x in ref])), "engine": dict(zip(NAMES, [float(x) for x in got])),
         "gap_pt": [round(100 * float(g), 3) for g in gap], "gap_bound_pt": [100 * b for b in QUALITY_GAP[dtype]],
+        "engine_auc_ndcg10_along_last_60_steps": {str(st): [round(float(m[0]), 5), round(float(m[3]), 5)] for st, m in sorted(along.items())},
+        "fp32_vs_fp32_noise_floor_pt": "profiles/r06_quality_noise_floor.json: oracle/torch_port.py against the reference, same run: 0.011 / 0.000 / -0.003 / -0.022",
         "total_loss_last20": [float(losses[-20:, 0].mean()), float(z["losses"][-20:, 0].mean())],
         "loss_err_first50_max": float(lerr[:50, 0].max()), "loss_err_first50_bound": FIRST50[dtype]}))
     # the model learned what the reference's did ...
     assert got[0] > 0.65 and losses[-20:, 0].mean() < 0.75 * losses[:20, 0].mean()
     # ... and ranks as well: bounds = 1.5 x the gaps measured on the GPU box (QUALITY_GAP below), never tighter than 0.5 pt.  For
-    # scale: two FP32 implementations of this run (the reference and oracle/torch_port.py) end profiles/r06_quality_noise_floor.json
-    # apart - a 400-step run under Adam does not reproduce to 0.1 pt in ANY arithmetic, only evaluation on the same weights does (i)
+    # scale: two FP32 implementations of this run (the reference and oracle/torch_port.py) end 0.02 pt apart
+    # (profiles/r06_quality_noise_floor.json) - the 16-bit run's gap is the arithmetic's, not chaos; at step 400 the model still
+    # learns fast (the metrics along the last 60 steps are printed above), the 16-bit runs happen to be AHEAD of the reference
     for n, g, bound in zip(NAMES, gap, QUALITY_GAP[dtype]):
         assert abs(g) <= bound, (n, g, bound)
     # the first 50 steps still follow the reference step by step (before the two runs' Adam sign flips have decorrelated them)

@@ -157,16 +157,19 @@ def test_stage1_joint_passes_equal_the_per_pass_form(dtype, case):
         assert torch.equal(res["joint"][k], res["per_pass"][k]), k
     for k in (0, 2, 3, 4):
         assert torch.equal(torch.nan_to_num(res["joint"][k]), torch.nan_to_num(res["joint_one_stream"][k])), k
-        assert torch.equal(torch.nan_to_num(res["joint"][k]), torch.nan_to_num(res["joint_hooked"][k])), k
+    for k in (2, 3, 4):
+        assert torch.equal(res["joint"][k], res["joint_hooked"][k]), k
     t = eng.title
     worst = 0.0
-    for k, gk in t.grads.items():
-        o = gk.storage_offset() - t.flat_g.storage_offset()
-        va, vb = res["joint"][0][o:o + gk.numel()], res["per_pass"][0][o:o + gk.numel()]
-        assert bool(torch.isfinite(va).all()), k                   # every gradient was written (flat_g was all NaN)
-        e = float((va - vb).norm()) / max(float(vb.norm()), 1e-30)
-        worst = max(worst, e)
-        assert e <= 2e-5, (k, e)
+    # (under a bucket hook a layer's weight gradients leave in two grouped launches of two instead of one of four: other splits)
+    for other in ("per_pass", "joint_hooked"):
+        for k, gk in t.grads.items():
+            o = gk.storage_offset() - t.flat_g.storage_offset()
+            va, vb = res["joint"][0][o:o + gk.numel()], res[other][0][o:o + gk.numel()]
+            assert bool(torch.isfinite(va).all()), k                   # every gradient was written (flat_g was all NaN)
+            e = float((va - vb).norm()) / max(float(vb.norm()), 1e-30)
+            worst = max(worst, e)
+            assert e <= 2e-5, (other, k, e)
     print("\n[stage1 joint %s %s] worst relative L2 gap of a parameter gradient to the per-pass form: %.2e" % (case, dtype, worst))
 
 

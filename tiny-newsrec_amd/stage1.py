@@ -258,6 +258,7 @@ class Stage1Engine:
             rba = (rb_heads if one else t.red.setdefault((l, "joint", Ns, "att"), _ReduceBatch(t.dev))) if tr else None
             rb = (rb_heads if one else t.red.setdefault((l, "joint", Ns, "ffn"), _ReduceBatch(t.dev))) if tr else None
             P = t.lpart.get(l)
+            t._wg = [] if (tr and self.joint_group_wgrad) else None      # the layer's weight gradients collected for one launch
             t._c("tnr_ln_bwd", dy, a["ypre"], a["st2"], g(names[14]), t.dypre, None, None, None, (P["ln_part"] if tr else None), M, H)
             if tr:
                 rb.add(P["ln_part"], nblk, 3 * H, 2 * H, t._view(names[14], 2 * H, (2 * H,), grad=True), 0, gi)
@@ -271,6 +272,7 @@ class Stage1Engine:
                 if not one:
                     rb.flush()
                 if after_bucket:
+                    self._wgrad_flush_joint()          # the FFN block's two gradients: its bucket goes out now
                     after_bucket(bucket)
                     bucket += 1
             t._gemm(t.du, sh["w1T"], t.dh1, M, res=t.dypre, flags=T.EPI_RES)
@@ -294,6 +296,7 @@ class Stage1Engine:
             if tr:
                 rba.add(qp, nt_rows + nb_rows, 3 * H, 3 * H, t._view(names[3], 3 * H, (3 * H,), grad=True), 0, gi)
                 t._wgrad(t.dqkv, x_in, t._view(names[0], 3 * H * H, (3 * H, H), grad=True), M)
+                self._wgrad_flush_joint()              # before the next layer overwrites their operands
                 if not one:
                     rba.flush()
             if l > t.lo:
@@ -303,8 +306,33 @@ class Stage1Engine:
             if tr and after_bucket:
                 after_bucket(bucket)
                 bucket += 1
+        t._wg = None
         if one:
             rb_heads.flush()
+
+    joint_group_wgrad = True    # the joint passes' weight gradients of a layer in ONE persistent launch + one slab sum
+
+    def _wgrad_flush_joint(self):
+        """The weight gradients collected since the last flush (a layer's four; two and two under a bucket hook) as one
+        tnr_gemm_tn_wgrad_group launch.  The joint passes have few rows (8 896 at 30 / 128): a launch per gradient with a full
+        round of (split, tile) units each (Engine._wgrad_splits) means 20 m steps per unit, 7 fp32 slabs per gradient and a slab
+        sum per gradient; here ALL the collected gradients share one round - every gradient gets the same number of splits, so
+        every unit runs the same number of m steps - and one slab sum."""
+        t = self.title
+        pend, t._wg = t._wg, ([] if t._wg is not None else None)
+        if not pend:
+            return
+        tiles = sum((N // 256) * (K // 256) for _, _, _, _, N, K, _ in pend)
+        assert all(N % 256 == 0 and K % 256 == 0 for _, _, _, _, N, K, _ in pend)
+        splits = max(1, min(64, (256 * Engine.WGRAD_UNITS) // tiles))
+        probs, off = [], 0
+        for dy, x, dw, M, N, K, acc in pend:
+            elems = T.query("tnr_gemm_tn_ws_elems", N, K, splits)
+            probs.append(dict(dY=dy, lddy=dy.stride(0), X=x, ldx=x.stride(0), dW=dw, lddw=dw.stride(0), M=M, N=N, K=K,
+                              ws=t.ws[off:off + elems], splits=splits, accumulate=acc, out_scale=t.ginv))
+            off += (elems + 63) // 64 * 64
+        assert off <= t.ws.numel() and len(probs) <= 4
+        T.wgrad_group(probs, f16=t.f16)
 
     def _encode_both(self, body_pass, title_pass):
         if not self.two_streams or self.dev.type != "cuda":

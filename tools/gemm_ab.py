@@ -6,7 +6,7 @@ import collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tiny-newsrec_amd"))
 import torch, tnr_hip as T
-if os.environ.get("LIB"):                 # another build of the library (e.g. tools/_noepi: make BUILD=../../tools/_noepi EXTRA=-DTNR_NOEPI)
+if os.environ.get("LIB"):                 # another build of the library (e.g. tools/_noepi: tools/probes/build.sh _noepi -DTNR_NOEPI)
     T.LIB_PATH = os.path.join(ROOT, os.environ["LIB"], "libtnr_hip.so")
 if os.environ.get("PROBE"):
     T.LIB_PATH = os.path.join(ROOT, "tools", "_probe", "libtnr_hip.so")

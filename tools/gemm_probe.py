@@ -1,5 +1,5 @@
 """Where does a K step of the ping-pong NT GEMM go?  Timing probes of the -DTNR_PROBES library copy (tools/_probe, built by
-`make -C tiny-newsrec_amd/csrc BUILD=../../tools/_probe EXTRA=-DTNR_PROBES`); the product library has none of this code.
+`tools/probes/build.sh _probe -DTNR_PROBES=2`); the product library has none of this code.
   probe 1: no staging loads after the first two K tiles (MFMA + fragment reads + barriers only)
   probe 2: no fragment reads / MFMAs (the LDS-DMA pipeline + barriers only)
   probe 4: every row tile reads A rows 0-255 (A resident in L2: the load pipeline at L2-hit rates)

@@ -1,6 +1,6 @@
 """Where a K tile of the ping-pong NT kernel (gemm_nt_pp_kernel) spends its cycles - the barrier-arrival stamps of tools/tn_stamps.py
 on the forward / dgrad GEMM; GPU box, probe build:
-    make -C tiny-newsrec_amd/csrc BUILD=../../tools/_ntst EXTRA=-DTNR_NT_STAMPS
+    tools/probes/build.sh _ntst -DTNR_NT_STAMPS
     N=3072 K=768 FLAGS=1 python tools/nt_stamps.py
 Intervals of a K tile (group 0's numbering; group 1 runs one barrier behind): L0 M0 L1 M1 L2 M2 L3 M3, 16 MFMAs per M."""
 import ctypes, os, sys

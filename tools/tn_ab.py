@@ -1,6 +1,6 @@
 """Interleaved same-process A/B of a library option on the weight-gradient GEMMs of the headline step (engine's split counts);
 GPU box.     AB=tnpp:0:1 DTYPE=fp16 python tools/tn_ab.py
-LIB=tools/_tnp2 ... : another build of the library (make BUILD=../../tools/_tnp2 EXTRA=-DTNR_TN_PROBE=2: the kernel without its
+LIB=tools/_tnp2 ... : another build of the library (a retired probe build: tools/retired/gemm_tn_probes_and_schedules.diff.txt: the kernel without its
 fragment reads; 1 = without LDS-DMA after the first two m steps, 4 = without MFMAs, sums combine)"""
 import collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

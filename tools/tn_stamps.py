@@ -1,5 +1,5 @@
 """Where an m step of the register-staged weight-gradient kernel (gemm_tn_rs_kernel) spends its cycles; GPU box, probe build:
-    make -C tiny-newsrec_amd/csrc BUILD=../../tools/_tnst EXTRA=-DTNR_TN_STAMPS
+    tools/probes/build.sh _tnst -DTNR_TN_STAMPS
     LIB=tools/_tnst python tools/tn_stamps.py            (N=3072 K=768 by default)
 Every wave stamps s_memtime on ARRIVAL at each of the 4 barriers of m steps 32-95.  Group 1 (waves 4-7) runs one barrier behind, so
 barrier n of group 0 is barrier n - 1 of group 1; release = the latest arrival.  Printed, as medians over the workgroups of means
