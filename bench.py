@@ -25,8 +25,7 @@ import torch         # noqa: E402
 
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 N_NEWS = 51282          # MIND-small-train sized news table (+ pad row 0)
-CAL_REF_US = 62.0       # `box` references = medians over the round-6 build leases (README.md): the calibration launch in step
-CLOCK_REF_MHZ = 2000.0  # context, and the shader clock under the step's NT launches
+CAL_REF_US = 78.0       # `box` reference = the calibration launch in step context on the round-6 build leases (77.8 / 77.8 / 78.7 us)
 EVENT_EVERY = 4         # roofline leg: every 4th timed step has its NT GEMM launches bracketed by HIP events
 
 
@@ -735,14 +734,12 @@ def main():
         out["quality"] = PARITY.get("quality")       # tests/test_quality_gpu.py: AUC / MRR / nDCG against the reference-trained golden
         if box is not None:
             out["box"] = box
-            cal, clk = box["calibration_launch"]["us"], box["mfma_clock_mhz_under_load"]
+            cal = box["calibration_launch"]["us"]
             out["box"]["headline_normalised"] = {
-                "reference": {"calibration_us": CAL_REF_US, "mfma_clock_mhz": CLOCK_REF_MHZ},
-                "value_at_reference_calibration": round(value * cal / CAL_REF_US, 2),
-                "value_at_reference_clock": round(value * CLOCK_REF_MHZ / clk, 2) if clk else None,
-                "note": "first-order removal of the box from the headline: value x (this box's calibration us / reference us) and value x "
-                        "(reference MHz / this box's MHz under load); the references are the medians of the round-6 build leases "
-                        "(README.md) - compare RAW values only between boxes whose calibration and clock agree"}
+                "reference_calibration_us": CAL_REF_US, "value_at_reference_calibration": round(value * cal / CAL_REF_US, 2),
+                "note": "value x (this box's calibration us / %.1f us, the round-6 build leases' median): first-order only - compare RAW "
+                        "values between boxes whose calibration agrees; the in-step clock is printed but did not order the round-6 "
+                        "leases' headlines (README.md)" % CAL_REF_US}
             out["step_breakdown_ms"] = breakdown
         if dp_info is not None:
             out["dp"] = dp_info

@@ -17,7 +17,8 @@ Round 6 - JOINT passes (`Stage1Engine.joint`, the default without dropout): a Li
 rows one by one, so the body pass's rows are laid directly BEHIND the title pass's in every per-token buffer and each of them is
 ONE launch over M = N Lt + B Lb rows instead of one per pass (8 896 rows at 30 / 128, 24 064 at 24 / 512: tile orders large enough
 for the persistent 256-wide kernels); only what depends on the sequence length - embeddings, attention, pooling - still runs per
-pass, on its row range, the body's on a second stream beside the title's.  Every row goes through the same K order as in its own
+pass, on its row range (one stream: `joint_streams` puts the body's on a second one, measured slower).  A layer's four weight
+gradients leave in ONE grouped persistent launch whose units share one round (`_wgrad_flush_joint`).  Every row goes through the same K order as in its own
 launch: scores and losses are bit-identical to the two-launch form; parameter gradients are the same sums in another order.
 Student rows live in one table S = [B*(1+K) title rows | B body rows], the layout tnr_kd_embed_loss and
 tnr_score_bwd already use in stage 2 with the body vector in the "user" slot.
@@ -149,7 +150,9 @@ class Stage1Engine:
 
     # ------------------------------------------------------------------ joint passes (round 6)
     joint = True            # False: one launch per pass for everything (the round-5 form; tools/ A/B, tests)
-    joint_streams = True    # the body's per-pass kernels (embeddings, attention, pooling) on the second stream beside the title's
+    joint_streams = False   # True: the body's per-pass kernels (embeddings, attention, pooling) on the second stream beside the title's.
+                            # Measured (interleaved legs, one box): 1.816 -> 1.718 ms at 30 / 128 and 3.830 -> 3.717 at 24 / 512 WITHOUT it -
+                            # ten fork / join pairs per step cost more than running two short kernels side by side wins
 
     def _joint_ok(self):
         t, b = self.title, self.body

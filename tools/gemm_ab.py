@@ -1,6 +1,6 @@
 """Interleaved same-process A/B of a library GEMM option (tnr_gemm_set_option) over the encoder's NT shapes; GPU box.
 Box-to-box variance on this pool is up to 15 %, so only interleaved same-box comparisons are meaningful.
-    AB=pp:0:1 python tools/gemm_ab.py        (two-phase main loop vs ping-pong)      DTYPE=fp16|bf16
+    AB=pp:0:1 python tools/gemm_ab.py        (two-phase main loop vs ping-pong)      DTYPE=fp16|bf16   M=rows   OPT=key=val,... (fixed for both sides)
     PROBE=8 ... : the same A/B in the probe build (tools/_probe, -DTNR_PROBES=2) with that probe set, e.g. 8 = K loops without epilogues"""
 import collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,8 @@ if os.environ.get("PROBE"):
 dev = "cuda:0"
 M = int(os.environ.get("M", 52800))
 KEY, *VALS = os.environ.get("AB", "pp:0:1").split(":")
+for kv in filter(None, os.environ.get("OPT", "").split(",")):          # options fixed for both sides, e.g. OPT=allow_fine=0
+    T.lib().tnr_gemm_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1]))
 F16 = os.environ.get("DTYPE", "fp16") == "fp16"
 td, sfx = (torch.float16, "_f16") if F16 else (torch.bfloat16, "")
 SHAPES = ((3072, 768, 0), (3072, 768, 67), (3072, 768, 3), (3072, 768, 16 | 128), (768, 3072, 9), (2304, 768, 1), (768, 768, 9), (768, 768, 0),
