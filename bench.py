@@ -25,7 +25,7 @@ import torch         # noqa: E402
 
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 N_NEWS = 51282          # MIND-small-train sized news table (+ pad row 0)
-CAL_REF_US = 78.0       # `box` reference = the calibration launch in step context on the round-6 build leases (77.8 / 77.8 / 78.7 us)
+CAL_REF_US = 230.0      # `box` reference = the MFMA-heavy calibration launch in step context, median over the round-6 build leases (README.md)
 EVENT_EVERY = 4         # roofline leg: every 4th timed step has its NT GEMM launches bracketed by HIP events
 
 
@@ -126,50 +126,59 @@ def family_of(name):
 
 
 class BoxProbe:
-    """What this BOX does with a fixed piece of work, so that two bench lines can be told apart into box and build: ONE fixed
-    persistent NT launch (M = 52 800, N = K = 768, plain epilogue, random operands) and the shader clock the chip holds under it
-    (tnr_gemm_clock_stamps: cycles / 100 MHz ticks per workgroup).  launch() is called right BEHIND a training step (the step
-    breakdown's extra steps, after the timed region): the chip is then in the power state the step's own GEMMs see - the same
-    launch repeated back to back for milliseconds runs at another clock (1.5 against 2.06 GHz in-step on one of this round's boxes)."""
+    """What this BOX does with fixed pieces of work, so that two bench lines can be told apart into box and build: two fixed
+    persistent NT launches on random operands, plain epilogue, M = 52 800 - "store_heavy" N = K = 768 (62 GFLOP, 81 MB out: the shape
+    the round-5 review named) and "mfma_heavy" N = 768, K = 3072 (249 GFLOP behind the same output) - and the shader clock the chip
+    holds under each (tnr_gemm_clock_stamps: cycles / 100 MHz ticks per workgroup).  launch() is called right BEHIND a training
+    step (the step breakdown's extra steps, after the timed region): the chip is then in the power state the step's own GEMMs see -
+    the same launch repeated back to back for milliseconds runs at another clock (1.5 against 2.06 GHz in-step on one of this
+    round's boxes).  Over the round-6 leases the store-heavy launch did NOT order the headlines (77.8 ... 80.7 us, the slowest on
+    the fastest box); the MFMA-heavy one is what `headline_normalised` uses."""
+    SHAPES = (("store_heavy", 768, 768), ("mfma_heavy", 768, 3072))
 
     def __init__(self, T, dev, dtype):
         self.T, self.sfx = T, "_f16" if dtype == "fp16" else ""
         td = torch.float16 if dtype == "fp16" else torch.bfloat16
-        self.M, self.N, self.K = 52800, 768, 768
+        self.M = 52800
         g = torch.Generator(device=dev)
         g.manual_seed(7)
-        self.a = (torch.randn((self.M, self.K), device=dev, generator=g) * 0.5).to(td)
-        self.b = (torch.randn((self.N, self.K), device=dev, generator=g) * 0.05).to(td)
-        self.c = torch.zeros((self.M, self.N), device=dev, dtype=td)
-        self.stamps = [torch.zeros((256, 2), device=dev, dtype=torch.int64) for _ in range(16)]
-        self.ev = []
+        self.ops = {}
+        for name, N, K in self.SHAPES:
+            self.ops[name] = ((torch.randn((self.M, K), device=dev, generator=g) * 0.5).to(td),
+                              (torch.randn((N, K), device=dev, generator=g) * 0.05).to(td), torch.zeros((self.M, N), device=dev, dtype=td))
+        self.ev = {name: [] for name, _, _ in self.SHAPES}
+        self.stamps = {name: [torch.zeros((256, 2), device=dev, dtype=torch.int64) for _ in range(16)] for name, _, _ in self.SHAPES}
 
     def launch(self):
-        T, M, N, K = self.T, self.M, self.N, self.K
-        i = len(self.ev)
-        T.lib().tnr_gemm_clock_stamps(self.stamps[i].data_ptr(), 256)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        T.call("tnr_gemm_nt_ex" + self.sfx, self.a, K, self.b, K, self.c, N, M, N, K, None, None, 0, None, 0, 0, None)
-        e1.record()
+        T, M = self.T, self.M
+        for name, N, K in self.SHAPES:
+            a_, b_, c_ = self.ops[name]
+            i = len(self.ev[name])
+            T.lib().tnr_gemm_clock_stamps(self.stamps[name][i].data_ptr(), 256)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            T.call("tnr_gemm_nt_ex" + self.sfx, a_, K, b_, K, c_, N, M, N, K, None, None, 0, None, 0, 0, None)
+            e1.record()
+            self.ev[name].append((e0, e1))
         T.lib().tnr_gemm_clock_stamps(None, 0)
-        self.ev.append((e0, e1))
 
     def result(self):
-        T, M, N, K = self.T, self.M, self.N, self.K
-        us = sorted(1e3 * e0.elapsed_time(e1) for e0, e1 in self.ev)
-        med = us[len(us) // 2]
-        mhz = []
-        for st in self.stamps[:len(self.ev)]:
-            st = st.cpu().numpy()
-            ok = st[:, 1] > 0
-            if ok.any():
-                mhz.append(float(np.median(100.0 * st[ok, 0] / st[ok, 1])))
-        return {"calibration_launch": {"M": M, "N": N, "K": K, "epilogue": "plain", "samples": len(us), "us": round(med, 2),
-                                       "us_min_max": [round(us[0], 2), round(us[-1], 2)], "tflops": round(2.0 * M * N * K / med / 1e6, 1),
-                                       "route": T.query("tnr_gemm_nt_route" + self.sfx, M, N, K, 0),
-                                       "protocol": "one launch right behind each of the step breakdown's extra training steps; median"},
-                "mfma_clock_mhz_under_calibration": round(float(np.median(mhz)), 0) if mhz else None}
+        T, M = self.T, self.M
+        out = {"protocol": "each launch once right behind each of the step breakdown's extra training steps; medians"}
+        for name, N, K in self.SHAPES:
+            us = sorted(1e3 * e0.elapsed_time(e1) for e0, e1 in self.ev[name])
+            med = us[len(us) // 2]
+            mhz = []
+            for st in self.stamps[name][:len(us)]:
+                st = st.cpu().numpy()
+                ok = st[:, 1] > 0
+                if ok.any():
+                    mhz.append(float(np.median(100.0 * st[ok, 0] / st[ok, 1])))
+            out[name] = {"M": M, "N": N, "K": K, "epilogue": "plain", "samples": len(us), "us": round(med, 2),
+                         "us_min_max": [round(us[0], 2), round(us[-1], 2)], "tflops": round(2.0 * M * N * K / med / 1e6, 1),
+                         "route": T.query("tnr_gemm_nt_route" + self.sfx, M, N, K, 0),
+                         "mfma_clock_mhz": round(float(np.median(mhz)), 0) if mhz else None}
+        return {"calibration_launches": out}
 
 
 def self_launch(a):
@@ -734,12 +743,11 @@ def main():
         out["quality"] = PARITY.get("quality")       # tests/test_quality_gpu.py: AUC / MRR / nDCG against the reference-trained golden
         if box is not None:
             out["box"] = box
-            cal = box["calibration_launch"]["us"]
+            cal = box["calibration_launches"]["mfma_heavy"]["us"]
             out["box"]["headline_normalised"] = {
-                "reference_calibration_us": CAL_REF_US, "value_at_reference_calibration": round(value * cal / CAL_REF_US, 2),
-                "note": "value x (this box's calibration us / %.1f us, the round-6 build leases' median): first-order only - compare RAW "
-                        "values between boxes whose calibration agrees; the in-step clock is printed but did not order the round-6 "
-                        "leases' headlines (README.md)" % CAL_REF_US}
+                "reference_mfma_heavy_calibration_us": CAL_REF_US, "value_at_reference_calibration": round(value * cal / CAL_REF_US, 2),
+                "note": "value x (this box's MFMA-heavy calibration us / %.1f us, the round-6 build leases' median): first-order only - "
+                        "compare RAW values between boxes whose calibration agrees" % CAL_REF_US}
             out["step_breakdown_ms"] = breakdown
         if dp_info is not None:
             out["dp"] = dp_info

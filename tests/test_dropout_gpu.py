@@ -113,6 +113,7 @@ def test_stage1_train_mode_step_matches_notebook_and_oracle(dtype):
 def test_dropout_p_zero_is_the_eval_path_bit_for_bit():
     z, P, cfg, inp = load_stage1_case("stage1_cfg4.npz")
     eng, B = _make(z, cfg, "fp16")
+    eng.joint = False            # dropout runs the per-pass form (its masks are numbered per pass): compare like with like
     eng.load_state_dict(P)
     l0, s0 = eng.forward(*_dev(inp))
     l0, s0 = l0.clone(), s0.clone()
