@@ -25,7 +25,7 @@ import torch         # noqa: E402
 
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 N_NEWS = 51282          # MIND-small-train sized news table (+ pad row 0)
-CAL_REF_US = 230.0      # `box` reference = the MFMA-heavy calibration launch in step context, median over the round-6 build leases (README.md)
+CAL_REF_US = 232.0      # `box` reference = the MFMA-heavy calibration launch in step context, median over the round-6 build leases (README.md)
 EVENT_EVERY = 4         # roofline leg: every 4th timed step has its NT GEMM launches bracketed by HIP events
 
 

@@ -58,6 +58,10 @@ for case in range(8):
 for case in range(10):
     nl = int(rs.randint(1, 3)); tr = tuple(sorted(rs.choice(nl, size=rs.randint(1, nl + 1), replace=False).tolist()))
     B, C, Lt, Lb, T_ = int(rs.randint(1, 5)), int(rs.randint(2, 7)), int(rs.randint(3, 33)), int(rs.randint(33, 200)), int(rs.randint(0, 4))
+    if case % 5 == 3:
+        Lt = int(rs.randint(33, 90))          # round 6 (joint passes): both passes on the long-sequence kernels ...
+    if case % 5 == 4:
+        Lb = int(rs.randint(8, 33))           # ... or both on the L <= 32 kernels
     D = int(rs.choice([64, 256]))
     shapes = {k: v for k, v in state_shapes(FULL, nl, D, T_).items() if k.startswith("student.news_encoder.") or k.startswith("transform_matrix.")}
     P = hashinit.init_state_dict(3000 + case, shapes)
