@@ -221,8 +221,9 @@ def main():
     ap.add_argument("--no-dp-autotune", action="store_true",
                     help="more than one rank: skip the pre-pass that times {wgrad units 2, 1} x {5, 3 buckets} for 3 + 10 untimed steps each "
                          "and runs the headline with the fastest (max over ranks; knobs given explicitly are kept) - defaults 2 / 5 then")
-    ap.add_argument("--dp-algo", choices=["allreduce", "rs_ag"], default="allreduce",
-                    help="one all-reduce per bucket, or reduce-scatter + all-gather (direct exchange on the xGMI mesh)")
+    ap.add_argument("--dp-algo", choices=["allreduce", "rs_ag", "native", "native_rs_ag"], default="allreduce",
+                    help="one all-reduce per bucket, or reduce-scatter + all-gather (direct exchange on the xGMI mesh); native*: the same "
+                         "two through the library's own C ABI (tnr_comm_*: RCCL bound inside libtnr_hip.so) instead of ProcessGroupNCCL")
     ap.add_argument("--dp-sweep", action="store_true",
                     help="data-parallel runs only: after the headline also time {wgrad units 1, 2} x {5, 3 buckets} x {allreduce, rs_ag} "
                          "(30 steps each) and report them in the dp object")

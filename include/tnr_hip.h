@@ -518,6 +518,27 @@ int tnr_attn_long_bwd_do_f16(const void* qkv, const float* mask_add, const float
                          const float* lse, float* delta, void* dqkv, int64_t n_seq, int L, int A,
                          const tnr_dropout_t* drop, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Collectives of the data-parallel step.  Replace hvd.init / hvd.broadcast_parameters /
+ * hvd.broadcast_optimizer_state (Tiny-NewsRec/run.py:141-144, utils.py:43-60) and the gradient all-reduce inside
+ * hvd.DistributedOptimizer (run.py:145-149: average of the trainable parameters' gradients, fp32, no compression).
+ * One process per GPU; the communicator lives on the caller's CURRENT device (the library never calls hipSetDevice); every
+ * collective is asynchronous on `stream` and in place; RCCL is bound at run time (dlopen librccl.so.1: inside a PyTorch-ROCm
+ * process the copy torch has loaded) - without it these return TNR_EUNSUPPORTED and nothing else in the library is affected.
+ * tnr_comm_unique_id: rank 0 fills 128 bytes that reach the other ranks out of band (the host side uses the rendezvous store
+ * torch.distributed already has, dist.py).  tnr_comm_allreduce_avg: average = 1 divides by the world size inside the reduction
+ * (ncclAvg), 0 sums (the engine folds 1 / world into tnr_amsgrad_step's grad_scale).  tnr_comm_reduce_scatter_allgather: the same
+ * result by direct exchange on the fully connected xGMI mesh (n a multiple of the world size, `shard` n / world floats of the
+ * caller's).  Errors: RCCL's own code and text in tnr_last_error(), status TNR_ELAUNCH. */
+typedef struct tnr_comm tnr_comm_t;
+int tnr_comm_unique_id(void* id128);
+int tnr_comm_init(const void* id128, int world, int rank, tnr_comm_t** comm);
+int tnr_comm_world(const tnr_comm_t* comm, int* world, int* rank);
+int tnr_comm_broadcast(tnr_comm_t* comm, float* buf, int64_t n, int root, void* stream);
+int tnr_comm_allreduce_avg(tnr_comm_t* comm, float* buf, int64_t n, int average, void* stream);
+int tnr_comm_reduce_scatter_allgather(tnr_comm_t* comm, float* buf, float* shard, int64_t n, int average, void* stream);
+int tnr_comm_destroy(tnr_comm_t* comm);
+
 #ifdef __cplusplus
 }
 #endif

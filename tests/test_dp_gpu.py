@@ -152,3 +152,68 @@ def test_fp16_guarded_step_scans_bucket_by_bucket_and_skips_as_one():
         outs.append([x.clone() for x in (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax)] + [eng.sh[1]["w1"].clone()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_native_communicator_through_the_c_abi_at_world_size_one():
+    """include/tnr_hip.h tnr_comm_* (the gradient exchange behind the C ABI; replaces hvd.init / broadcast_parameters /
+    DistributedOptimizer, Tiny-NewsRec/run.py:141-149): RCCL bound at run time inside libtnr_hip.so.  One GPU here, so world size 1:
+    the communicator comes up on the current device, all-reduce (sum and average), reduce-scatter + all-gather and broadcast run
+    asynchronously on the given stream and leave a one-rank buffer bit for bit as it was; bad arguments are refused with a message;
+    and dist.GradSync(algo="native" / "native_rs_ag") drives a training step's bucketed exchange through it with the same results
+    as no exchange at all.  (More than one rank needs more than one GPU: never run, like every RCCL path of this repository.)"""
+    import ctypes
+    import torch
+    import dist as D
+    import engine as E
+    import hashinit
+    import tnr_hip as T
+    from schema import FULL, state_shapes
+    L = T.lib()
+    torch.cuda.set_device(0)
+    ident = ctypes.create_string_buffer(128)
+    assert L.tnr_comm_unique_id(ident) == 0, L.tnr_last_error()
+    assert any(ident.raw)
+    h = ctypes.c_void_p()
+    assert L.tnr_comm_init(ident, 1, 1, ctypes.byref(h)) == -1 and b"rank" in L.tnr_last_error()        # rank out of range
+    assert L.tnr_comm_init(ident, 1, 0, ctypes.byref(h)) == 0, L.tnr_last_error()
+    w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert L.tnr_comm_world(h, ctypes.byref(w), ctypes.byref(r)) == 0 and (w.value, r.value) == (1, 0)
+    st = torch.cuda.Stream()
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    x = torch.randn(1 << 20, device="cuda:0", generator=g)
+    x0 = x.clone()
+    shard = torch.empty_like(x)
+    torch.cuda.synchronize()
+    for avg in (0, 1):
+        assert L.tnr_comm_allreduce_avg(h, x.data_ptr(), x.numel(), avg, st.cuda_stream) == 0, L.tnr_last_error()
+        assert L.tnr_comm_reduce_scatter_allgather(h, x.data_ptr(), shard.data_ptr(), x.numel(), avg, st.cuda_stream) == 0, L.tnr_last_error()
+    assert L.tnr_comm_broadcast(h, x.data_ptr(), x.numel(), 0, st.cuda_stream) == 0, L.tnr_last_error()
+    assert L.tnr_comm_broadcast(h, x.data_ptr(), x.numel(), 1, st.cuda_stream) == -1                   # root out of range
+    st.synchronize()
+    assert torch.equal(x, x0)
+    assert L.tnr_comm_destroy(h) == 0 and L.tnr_comm_destroy(None) == 0
+    # a training step's bucketed exchange through it
+    cfg = E.EngineConfig(n_layers=2, trainable_layers=(0, 1), num_teachers=2)
+    P = hashinit.init_state_dict(3, state_shapes(FULL, 2, cfg.D, 2))
+    outs = {}
+    for algo in (None, "native", "native_rs_ag"):
+        eng = E.Engine(cfg, "cuda:0", max_batch=2, dtype="bf16")
+        eng.load_state_dict(P)
+        gs = D.GradSync(eng.flat_g, eng.bucket_ranges(), 1, force=True, algo=algo) if algo else None
+        assert algo is None or (gs.native is not None and gs.algo == algo)
+        gen = torch.Generator(device="cuda:0").manual_seed(5)
+        for step in range(3):
+            eng.flat_g.copy_(torch.randn(eng.n_train, device="cuda:0", generator=gen) * 1e-3)
+            if gs is not None:
+                for b in range(len(gs.ranges)):
+                    gs.launch(b)
+                assert len(gs.pending) == len(gs.groups)
+            eng.step(1e-4, grad_scale=1.0, sync=gs)
+            assert gs is None or not gs.pending
+        torch.cuda.synchronize()
+        outs[algo] = [t.clone() for t in (eng.flat[True], eng.adam_m, eng.adam_v, eng.adam_vmax)]
+        if gs is not None:
+            gs.native.close()
+    for algo in ("native", "native_rs_ag"):
+        for a, b in zip(outs[None], outs[algo]):
+            assert torch.equal(a, b), algo

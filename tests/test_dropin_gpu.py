@@ -95,6 +95,13 @@ def test_bench_dp_path_under_torchrun_single_rank():
     sw = dp["sweep"]
     assert len(sw) == 8 and all("error" not in x and x["value"] > 0 for x in sw), sw
     assert {(x["wgrad_units"], x["buckets"], x["algo"]) for x in sw} == {(u, b, g) for u in (1, 2) for b in (5, 3) for g in ("allreduce", "rs_ag")}
+    # the same step with the gradient exchange through the library's own C ABI (tnr_comm_*, round 6) instead of ProcessGroupNCCL
+    cmd2 = [c for c in cmd if c != "--dp-sweep"] + ["--dp-algo", "native", "--no-larger-batch", "--no-other-dtype", "--dedup", "off"]
+    cmd2[cmd2.index("29547")] = "29548"
+    r2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-3000:]
+    d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["dp"]["algo"] == "native" and d2["value"] > 0 and d2["config"]["final_loss"] == d["config"]["final_loss"]
 
 
 def test_bench_two_ranks_over_gloo_match_one_rank_on_the_concatenated_batch(tmp_path):

@@ -24,6 +24,69 @@ def init(backend=None):
     return world, rank, local
 
 
+class NativeComm:
+    """The C-ABI communicator (include/tnr_hip.h tnr_comm_*: RCCL bound at run time inside libtnr_hip.so) on a stream of its own.
+    The 128-byte unique id goes from rank 0 to the others through the process group torch.distributed already has (any
+    backend: it is host bytes), or nowhere at world size 1."""
+
+    def __init__(self, world, rank, device):
+        import ctypes
+        import tnr_hip as T
+        self.T, self.world, self.rank = T, world, rank
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            rc = T.lib().tnr_comm_unique_id(ident)
+            if rc != 0:
+                raise T.TnrError("tnr_comm_unique_id failed (%d): %s" % (rc, T.lib().tnr_last_error().decode()))
+        if world > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = T.lib().tnr_comm_init(ident, world, rank, ctypes.byref(handle))
+        if rc != 0:
+            raise T.TnrError("tnr_comm_init failed (%d): %s" % (rc, T.lib().tnr_last_error().decode()))
+        self.handle = handle
+        self.stream = torch.cuda.Stream(device)
+
+    def _run(self, name, *args):
+        """`name`(comm, *args, comm stream) behind everything enqueued on the current stream so far -> an event-backed work handle."""
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        rc = getattr(self.T.lib(), name)(self.handle, *args, self.stream.cuda_stream)
+        if rc != 0:
+            raise self.T.TnrError("%s failed (%d): %s" % (name, rc, self.T.lib().tnr_last_error().decode()))
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return _EventWork(ev)
+
+    def allreduce_sum(self, t):
+        return self._run("tnr_comm_allreduce_avg", t.data_ptr(), t.numel(), 0)
+
+    def reduce_scatter_allgather_sum(self, t, shard):
+        return self._run("tnr_comm_reduce_scatter_allgather", t.data_ptr(), shard.data_ptr(), t.numel(), 0)
+
+    def broadcast(self, t, src=0):
+        self._run("tnr_comm_broadcast", t.data_ptr(), t.numel(), src).wait()
+
+    def close(self):
+        if self.handle is not None:
+            self.stream.synchronize()
+            self.T.lib().tnr_comm_destroy(self.handle)
+            self.handle = None
+
+
+class _EventWork:
+    """What GradSync needs of a work handle: wait() puts the CURRENT stream behind the collective."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class GradSync:
     """Bucketed all-reduce of a flat gradient buffer. ranges: [(start, end)] in completion order.
 
@@ -48,7 +111,7 @@ class GradSync:
         exchanges directly with every other; nccl backend only, falls back to all-reduce elsewhere).  Both are knobs for the
         first multi-GPU run (bench.py --dp-sweep); results are the same sums."""
         self.flat_g, self.ranges, self.world = flat_g, list(ranges), world
-        self.force = force and dist.is_initialized()      # exercise the collective path even with one rank
+        self.force = force and (dist.is_initialized() or algo in ("native", "native_rs_ag"))   # the collective path even with one rank
         self.pending = {}                                 # collective -> (work handle, pinned host mirror or None)
         self.host_staged = dist.is_initialized() and dist.get_backend() == "gloo" and flat_g.is_cuda
         self._mirror = {}
@@ -69,6 +132,14 @@ class GradSync:
         self._arrived = {}
         self.algo = algo if (dist.is_initialized() and dist.get_backend() == "nccl") else "allreduce"
         self._shard = {}
+        # algo "native" / "native_rs_ag": the same collectives through the library's own C ABI (tnr_comm_*) instead of
+        # ProcessGroupNCCL; every in-flight collective of a size gets a shard of its own (the communicator's one stream orders them,
+        # as ProcessGroupNCCL's does, but nothing is assumed about it here)
+        self.native = None
+        if algo in ("native", "native_rs_ag") and flat_g.is_cuda and (world > 1 or force):
+            self.native = NativeComm(world, dist.get_rank() if dist.is_initialized() else 0, flat_g.device)
+            self.algo = algo
+            self.host_staged = False
 
     def bucket_bytes(self):
         return [4 * (e - s) for s, e in self.ranges]
@@ -78,6 +149,14 @@ class GradSync:
 
     def _collective(self, t):
         """sum over ranks of the flat slice t, in place, asynchronously -> work handle"""
+        if self.native is not None:
+            if self.algo == "native_rs_ag" and t.numel() % max(self.world, 1) == 0:
+                key = (t.data_ptr(), t.numel())
+                shard = self._shard.get(key)
+                if shard is None:
+                    shard = self._shard[key] = torch.empty(t.numel() // max(self.world, 1), dtype=t.dtype, device=t.device)
+                return self.native.reduce_scatter_allgather_sum(t, shard)
+            return self.native.allreduce_sum(t)
         if self.algo == "rs_ag" and t.numel() % max(self.world, 1) == 0:
             w = max(self.world, 1)
             k = t.numel() // w

@@ -267,10 +267,15 @@ class Stage1Engine:
                 rb.add(P["ln_part"], nblk, 3 * H, 2 * H, t._view(names[14], 2 * H, (2 * H,), grad=True), 0, gi)
                 rb.add(P["ln_part"][2 * H:], nblk, 3 * H, H, gr[names[13]], 0, gi)
                 t._wgrad(t.dypre, a["g"], gr[names[12]], M)
-            t._gemm(t.dypre, sh["w2T"], t.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if tr else 0),
-                    colsum=P["gcs_part"] if tr else None)
+            fused_cs = tr and M > 128            # the column-sum epilogue needs more than one 128-row strip (a toy batch has less)
+            t._gemm(t.dypre, sh["w2T"], t.du, M, aux=a["u"], flags=T.EPI_MULDGELU | (T.EPI_COLSUM if fused_cs else 0),
+                    colsum=P["gcs_part"] if fused_cs else None)
             if tr:
-                rb.add(P["gcs_part"], t._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], 0, gi)
+                if fused_cs:
+                    rb.add(P["gcs_part"], t._q("tnr_gemm_colsum_rows", M), I, I, gr[names[11]], 0, gi)
+                else:
+                    t._c("tnr_colsum", t.du, I, T.BF16, M, I, P["cs_tmp"][:I], t.cs_part, 0)
+                    rb.add(P["cs_tmp"], 1, I, I, gr[names[11]], 0, gi)
                 t._wgrad(t.du, a["h1"], gr[names[10]], M)
                 if not one:
                     rb.flush()

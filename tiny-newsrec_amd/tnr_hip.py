@@ -102,6 +102,13 @@ _SIG = {
     "tnr_gemm_nt_plan": [_L, _L, _I, _I, _P, _P, _P],
     "tnr_gemm_queue_reset": [_P],
     "tnr_gemm_clock_stamps": [_P, _L],
+    "tnr_comm_unique_id": [_P],
+    "tnr_comm_init": [_P, _I, _I, _c.POINTER(_P)],
+    "tnr_comm_world": [_P, _c.POINTER(_I), _c.POINTER(_I)],
+    "tnr_comm_broadcast": [_P, _P, _L, _I, _P],
+    "tnr_comm_allreduce_avg": [_P, _P, _L, _I, _P],
+    "tnr_comm_reduce_scatter_allgather": [_P, _P, _P, _L, _I, _P],
+    "tnr_comm_destroy": [_P],
     "tnr_gemm_set_option": [_c.c_char_p, _I],
     "tnr_gemm_tn_wgrad": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _P],
     "tnr_gemm_tn_wgrad_ex": [_P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _I, _I, _F, _P],
