@@ -173,6 +173,35 @@ def test_stage1_joint_passes_equal_the_per_pass_form(dtype, case):
     print("\n[stage1 joint %s %s] worst relative L2 gap of a parameter gradient to the per-pass form: %.2e" % (case, dtype, worst))
 
 
+def test_stage1_per_pass_step_after_joint_steps_sees_a_clean_workspace():
+    """The joint passes put body rows where the title engine's own kernels expect zero rows (the weight gradient reads up to the
+    next multiple of 64 behind the N Lt title rows): a per-pass step that follows joint ones (dropout switched on mid-run, a tools/
+    A/B) must not see them.  B = 3 of the golden batch: 450 title rows, not a multiple of 64 - every gradient bit for bit what a
+    fresh engine's per-pass step gives."""
+    z, P, cfg, inp = load_stage1_case("stage1_cfg4.npz")
+    d = _dev(inp)
+    sub = (d[0][:3], d[1][:3], d[2][:3], [x[:3] for x in d[3]], [x[:3] for x in d[4]])
+    eng, B = _make(z, cfg, "fp16")
+    eng.load_state_dict(P)
+    for _ in range(2):
+        eng.forward(*sub)
+        assert eng.ran_joint
+        eng.backward()
+    eng.joint = False
+    eng.forward(*sub)
+    assert not eng.ran_joint
+    eng.backward()
+    torch.cuda.synchronize()
+    g1, l1 = eng.title.flat_g.clone(), eng.title.losses.clone()
+    fresh, _ = _make(z, cfg, "fp16")
+    fresh.joint = False
+    fresh.load_state_dict(P)
+    fresh.forward(*sub)
+    fresh.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(l1, fresh.title.losses) and torch.equal(g1, fresh.title.flat_g)
+
+
 def test_stage1_joint_training_follows_the_per_pass_form():
     """Eight optimiser steps of the joint passes against the per-pass form from the same start (no dropout): the first step's
     losses bit for bit, every later loss within 1e-3 (the gradients differ by fp32 summation order only - 2e-5 relative, the test

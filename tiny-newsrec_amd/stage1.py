@@ -81,6 +81,7 @@ class Stage1Engine:
         C, D, T_ = cfg.C, cfg.D, cfg.T
         assert idx.shape[1] == C
         self._prepare(B)
+        self.ran_joint = self._joint_ok()      # (before anything is copied into the workspaces: it may lay them out afresh)
         N, Rt = B * C, B * C + B
         self.cur = (B, N, Rt)
         t.label = label.to(torch.int64).contiguous()
@@ -97,7 +98,6 @@ class Stage1Engine:
         def title_pass():
             teacher_side()
             t.encode(title_table, N, nidx=tidx)
-        self.ran_joint = self._joint_ok()
         if self.ran_joint:
             self._encode_joint(B, N, title_table, tidx, body_table, bidx, teacher_side)
         else:
@@ -113,6 +113,7 @@ class Stage1Engine:
         C, D, T_ = cfg.C, cfg.D, cfg.T
         assert title.shape[1:] == (C, 2 * cfg.L) and body.shape == (B, 2 * self.cfg_b.L)
         self._prepare(B)
+        self.ran_joint = self._joint_ok()      # (before anything is copied into the workspaces: it may lay them out afresh)
         N, Rt = B * C, B * C + B
         self.cur = (B, N, Rt)
         t.label = label.to(torch.int64).contiguous()
@@ -129,7 +130,6 @@ class Stage1Engine:
         def title_pass():
             teacher_side()
             t.encode(t.tok[:N], N)
-        self.ran_joint = self._joint_ok()
         if self.ran_joint:
             self._encode_joint(B, N, t.tok[:N], None, b.tok[:B], None, teacher_side)
         else:
@@ -156,8 +156,15 @@ class Stage1Engine:
 
     def _joint_ok(self):
         t, b = self.title, self.body
-        return bool(self.joint and t.drop is None and b.drop is None and self.cfg_t.pooling == "att" and self.dev.type == "cuda"
-                    and getattr(t, "fcache", None) is None and t.group_wgrad is False)
+        ok = bool(self.joint and t.drop is None and b.drop is None and self.cfg_t.pooling == "att" and self.dev.type == "cuda"
+                  and getattr(t, "fcache", None) is None and t.group_wgrad is False)
+        if not ok and getattr(self, "_joint_rows_written", False):
+            # a per-pass step after joint ones (dropout switched on, a tools/ A/B): the title engine's own kernels rely on ZERO rows
+            # behind its N Lt rows (the weight gradient reads up to the next multiple of 64), where the joint passes have put body
+            # rows - lay the title workspace out afresh, once
+            t._alloc_workspace(t.B_alloc)
+        self._joint_rows_written = ok
+        return ok
 
     def _both(self, body_fn, title_fn):
         """The two passes' own kernels of one stage of the joint passes: side by side on two streams, joined behind."""
