@@ -371,7 +371,11 @@ __device__ __forceinline__ bf16x8 ld_frag(const bf16* base, int64_t ld, int row,
 // registers into a double-buffered LDS pair, the next tile's loads in flight under the current tile's MFMAs and softmax.  Before,
 // every wave loaded every K fragment (strided 16-byte pieces) and V tile of its (sequence, head) by itself, one after the other
 // with nothing in flight: 2.8 x the algorithmic fabric traffic, 2 TB/s, MFMA busy 0.08 (profiles/r05_stage1_24_512_pmc.json).
-__global__ __launch_bounds__(256) void attn_long_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
+// Round 6: __launch_bounds__(256, 3).  Left alone the compiler takes 196 registers (2 waves per SIMD); held to 168 it spills two dwords
+// and three waves per SIMD hide more of the per-element fp32 work between the MFMAs: 128.5 -> 114.3 us at L = 128, 299 -> 260 us at
+// L = 512 (tools/attn_bench.py, interleaved, same results).  Four waves (128 registers) spill 51 dwords inside the loop: 2.6 x slower;
+// the dQ pass at three waves spills 50: +45 % - both stay as they are (EXPERIMENTS item 51).
+__global__ __launch_bounds__(256, 3) void attn_long_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ mask_add,
                                                             const float* __restrict__ rel, bf16* __restrict__ ctx,
                                                             float* __restrict__ lse, int64_t n_items, int L, int Lr, int A,
                                                             TnrDrop drop) {
