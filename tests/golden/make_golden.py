@@ -351,8 +351,8 @@ def _quality_eval(R, model, a, c, B):
     """run.py:219-379 on `model`: -> dict(news_scoring, user_vecs, scores, score_offsets, per_impression, metrics)."""
     import importlib
     comb = c["news_combined"]
-    was_training = model.training
-    model.eval()
+    modes = [(m, m.training) for m in model.modules()]       # per module: the UniLM inside is in eval mode while the model trains
+    model.eval()                                             # (ref_shim: from_pretrained -> .eval(); run.py never calls .train())
     torch.set_grad_enabled(False)
     try:
         scoring = np.concatenate([model.student.news_encoder(torch.from_numpy(comb[i:i + 4 * B])).numpy()
@@ -382,7 +382,8 @@ def _quality_eval(R, model, a, c, B):
                 per.append([RM.roc_auc_score(lab, sc), RM.mrr_score(lab, sc), RM.ndcg_score(lab, sc, k=5), RM.ndcg_score(lab, sc, k=10)])
     finally:
         torch.set_grad_enabled(True)
-        model.train(was_training)
+        for m, flag in modes:                                # NOT model.train(was_training): that would switch the UniLM's dropout on
+            m.training = flag
     per = np.array(per)
     return dict(news_scoring=scoring.astype(np.float32), user_vecs=np.array(users, np.float32),
                 score_offsets=np.concatenate([[0], np.cumsum([len(x) for x in scores])]), scores=np.concatenate(scores),

@@ -268,8 +268,10 @@ def test_engine_trained_to_the_plateau_against_the_reference_trained_to_the_plat
     assert (np.abs(gap[late].mean(0)) <= LONG_GAP_PT).all(), gap[late].mean(0)
 
 
-# (iii): |mean gap| over the second half's evaluations, AUC / MRR / nDCG@5 / nDCG@10, in points (1.5 x measured, floor 0.3 pt)
-LONG_GAP_PT = (0.6, 0.3, 0.6, 0.6)
+# (iii): |mean gap| over the second half's evaluations, AUC / MRR / nDCG@5 / nDCG@10, in points: 1.5 x measured, floor 0.3 pt
+# (measured -0.08 / -0.06 / -0.20 / -0.17 pt; single evaluations +-0.9 pt with changing sign - the reference's own metrics move
+# 0.5 ... 1 pt between neighbouring evaluations on its plateau)
+LONG_GAP_PT = (0.3, 0.3, 0.3, 0.3)
 # per-impression score allowance of (i): 1.5 x the 2.54e-3 measured (r.m.s. measured separately and held to 1e-3)
 SCORE_TOL = 4e-3
 # absolute metric gaps allowed in (ii) (AUC, MRR, nDCG@5, nDCG@10) = 1.5 x measured on the GPU box, floor 0.5 pt
