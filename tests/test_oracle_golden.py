@@ -456,3 +456,20 @@ def test_quality_golden_pins_the_oracle_eval_path_and_the_metrics():
     want = z["losses"][0]                              # total, distill, emb, target
     got = [out["total_loss"], out["distill_loss"], out["emb_loss"], out["target_loss"]]
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+
+
+def test_quality_long_continues_quality_0():
+    """tests/golden/quality_long.npz (the reference's loop for 1 600 steps, its own test() every 200; tests/test_quality_gpu.py (iii))
+    is the SAME run as quality_0.npz for its first 400 steps: same corpus lines, same label draws, the same 400 x 4 losses bit for
+    bit, and its step-400 metrics are quality_0's unquantised ones to the run-to-run spread of the reference's CPU backward
+    (make_golden.golden_quality: 1e-4)."""
+    a, b = np.load(os.path.join(GOLDEN, "quality_0.npz")), np.load(os.path.join(GOLDEN, "quality_long.npz"))
+    n = int(a["steps"][0])
+    assert int(b["steps"][0]) == 4 * n and np.array_equal(a["meta"], b["meta"]) and float(a["lr"][0]) == float(b["lr"][0])
+    assert np.array_equal(a["train_lines"], b["train_lines"][:len(a["train_lines"])]) and np.array_equal(a["test_lines"], b["test_lines"])
+    assert np.array_equal(a["labels"], b["labels"][:n]) and np.array_equal(a["losses"], b["losses"][:n])
+    i = list(b["metrics_at_steps"]).index(n)
+    assert np.abs(b["metrics_at"][i] - a["metrics_unquantised"]).max() <= 1e-4
+    # a plateau: from step 1 000 on the reference's AUC stays above 0.87 and within 1.5 pt (10 % of the dev labels are noise)
+    auc = np.concatenate([b["metrics_at"][:, 0], b["metrics"][:1]])[-4:]
+    assert auc.min() > 0.87 and auc.max() - auc.min() < 0.015
