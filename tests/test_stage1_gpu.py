@@ -408,3 +408,53 @@ def test_stage0_script_trains_and_exports(tmp_path):
     a = pickle.load(open(str(tmp_path / "teacher_title_emb_0.pkl"), "rb"))
     b = pickle.load(open(str(tmp_path / "teacher_title_emb_1.pkl"), "rb"))
     assert not np.array_equal(a, b)                       # two different checkpoints = two different teachers
+
+
+@pytest.mark.parametrize("Lt,Lb,Kn", [(30, 128, 4), (24, 512, 9)])       # bench.py's two stage-1 legs (the second: the notebook's own shape)
+def test_stage1_bench_shape_step_matches_oracle(Lt, Lb, Kn):
+    """bench.py's "configs[4] stage 1" leg at its OWN size (B = 32, 2-layer student training both layers, 4 teachers, 1 + 4 titles of
+    30 tokens, bodies of 128: the joint passes over M = 8 896 token rows - the persistent 224 / 192-row tile plans, the grouped weight
+    gradients sharing one round, the long-sequence kernels on 32 bodies) against the numpy oracle on the same synthetic inputs: the
+    three losses and the (32, 5) scores at 1e-3, EVERY parameter gradient at the suite's fp16 bound (1.5e-2 relative L2)."""
+    import hashinit
+    import synth
+    nl, T_, B, nd = 2, 4, 32, 3000
+    eng = Stage1Engine(n_layers=nl, trainable_layers=(0, 1), num_teachers=T_, npratio=Kn, title_len=Lt, body_len=Lb, device=DEV, batch=B,
+                       dtype="fp16")
+    P = {k: hashinit.init_tensor(1234, k, tuple(sh)) for k, sh in eng.shapes.items()}
+    eng.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    d_title = synth.news_table(11, nd - 1, Lt)
+    d_body = synth.news_table(12, nd - 1, Lb, mean_len=0.6 * Lb, std_len=0.25 * Lb)
+    d_tt = np.ascontiguousarray(synth.teacher_tables(13, T_, nd - 1, eng.cfg_t.D))
+    d_tb = np.ascontiguousarray(synth.teacher_tables(14, T_, nd - 1, eng.cfg_t.D))
+    rs = np.random.RandomState(1234)
+    pidx = rs.randint(1, nd, (B, 1 + Kn)).astype(np.int32)
+    label = rs.randint(0, 1 + Kn, B).astype(np.int64)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    losses, score = eng.forward_indexed(t(d_title), t(d_body), t(pidx), t(label), t(d_tt), t(d_tb))
+    assert eng.ran_joint
+    eng.backward()
+    torch.cuda.synchronize()
+    title = d_title.astype(np.int64)[pidx]                                # (B, 1 + K, 2 Lt) [ids | mask]
+    body = d_body.astype(np.int64)[pidx[:, 0]]
+    tt = [d_tt[i][pidx] for i in range(T_)]
+    tb = [d_tb[i][pidx[:, 0]] for i in range(T_)]
+    cfg = dict(n_layers=nl, heads=12, trainable_layers=[0, 1])
+    out = O.distill_fwd(P, cfg, title, body, label, tt, tb)
+    G = O.distill_bwd(P, cfg, out)
+    le = abs(float(eng.total_loss().item()) - float(out["total_loss"])) / max(1.0, float(out["total_loss"]))
+    se = np.abs(score.cpu().numpy() - out["student_score"]).max() / max(1.0, np.abs(out["student_score"]).max())
+    nrm = lambda a: float(np.sqrt((a.astype(np.float64) ** 2).sum()))
+    worst, worst_k = 0.0, None
+    for k in eng.title.grads:
+        got, ref = eng.grad(k).cpu().numpy(), G[k]
+        if k.endswith("self.key.bias") or k.endswith("att_fc2.bias"):
+            assert np.abs(got).max() < 1e-3 and np.abs(ref).max() < 1e-3, k
+            continue
+        err = nrm(got - ref) / (nrm(ref) + 1e-30)
+        if err > worst:
+            worst, worst_k = err, k
+        assert err < GTOL["fp16"], "%s: relative L2 error %.3e (|ref| %.3e)" % (k, err, nrm(ref))
+    print("\n[stage 1, bench shape %d / %d, 1 + %d titles, joint passes] total loss err %.2e  score err %.2e  worst gradient relative L2 error %.3e (%s)" % (
+        Lt, Lb, Kn, le, se, worst, worst_k))
+    assert le <= TOL["fp16"] and se <= TOL["fp16"]
