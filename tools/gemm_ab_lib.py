@@ -15,6 +15,9 @@ def load(tag, path):
     return m
 libs = [load("old", os.path.join(ROOT, os.environ.get("OLD", "tools/_probe/libtnr_old.so"))),
         load("new", os.path.join(ROOT, "tiny-newsrec_amd", "csrc", "libtnr_hip.so"))]
+for kv in filter(None, os.environ.get("OPT", "").split(",")):          # options fixed for BOTH libraries, e.g. OPT=allow_fine=0
+    for m_ in libs:
+        m_.lib().tnr_gemm_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1]))
 dev, M = "cuda:0", int(os.environ.get("M", 52800))
 td, sfx = torch.float16, "_f16"
 SHAPES = ((3072, 768, 0), (3072, 768, 67), (3072, 768, 3), (3072, 768, 16 | 128), (768, 3072, 9), (2304, 768, 1), (768, 768, 9), (768, 768, 0),
